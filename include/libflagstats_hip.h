@@ -1,0 +1,104 @@
+/*
+ * libflagstats_hip.h -- C ABI of libflagstats_hip.so, the MI355X (gfx950) engine
+ * behind libflagstats' flagstat entry points.
+ *
+ * Plain C, plain pointers and sizes; no HIP or torch types in any signature
+ * (streams travel as void*).  Every symbol below is exported by
+ * libflagstats_amd/libflagstats_hip.so (tests/test_capi_symbols.py checks that).
+ *
+ * Semantics (all entry points): counters follow the reference's FLAGSTAT_scalar
+ * exactly (libflagstats.h:118-142, :170-176): 32 slots, [0..15] pass-QC,
+ * [16..31] fail-QC, slot index = FLAGSTAT_*_OFF (libflagstats.h:69-112);
+ * the 19 live slots are {2,6,7,8,10,11,12,13,14} and {18,22..30}; the other
+ * slots are never written.  Counters are ACCUMULATED (+=), never zeroed by the
+ * callee (libflagstats.h:118-142 `++f[...]`; python/libflagstats.pyx:19 zeroes
+ * in the caller).
+ *
+ * There is NO CPU fallback in this library: if the GPU path cannot run, the
+ * call fails loudly (message on stderr + non-zero return).
+ */
+#ifndef LIBFLAGSTATS_HIP_H_
+#define LIBFLAGSTATS_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- drop-in symbols: same names, argument meaning and return as the reference ---- */
+
+/* replaces: typedef at libflagstats.h:2970 */
+typedef int (*FLAGSTATS_func)(const uint16_t*, uint32_t, uint32_t*);
+
+/* replaces: `static uint64_t FLAGSTATS_u16(const uint16_t* array, uint32_t n_len,
+ * uint32_t* flags)` libflagstats.h:3024-3070 (callers: python/libflagstats.pyx:22).
+ * `array` is a HOST pointer (any 2-byte alignment); flags[32] += counters.
+ * Returns 0 like the reference; non-zero only if the GPU path failed. */
+uint64_t FLAGSTATS_u16(const uint16_t* array, uint32_t n_len, uint32_t* flags);
+
+/* replaces: `static FLAGSTATS_func FLAGSTATS_get_function(uint32_t n_len)`
+ * libflagstats.h:2976-3022 (callers: benchmark/flagstats.cpp:328,450,665).
+ * This library has one kernel family, so it returns &FLAGSTAT_hip for every n. */
+FLAGSTATS_func FLAGSTATS_get_function(uint32_t n_len);
+
+/* the kernel itself, shaped like every FLAGSTAT_<impl> of the reference
+ * (e.g. FLAGSTAT_avx512 libflagstats.h:1644, FLAGSTAT_scalar :170): host pointer
+ * in, flags[32] += counters, returns 0 on success. */
+int FLAGSTAT_hip(const uint16_t* array, uint32_t len, uint32_t* flags);
+
+/* ---- extensions the reference's uint32 ABI cannot express ---- */
+
+/* 64-bit length, 64-bit counters, HOST pointer: out[32] += counters.
+ * Streams the array through two device buffers (H2D copy of chunk k+1 overlaps
+ * the kernel on chunk k; truly asynchronous when `array` is pinned, e.g. from
+ * FLAGSTATS_hip_host_alloc).  Returns 0 on success. */
+int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out);
+
+/* DEVICE-resident array (any 2-byte alignment), DEVICE counters:
+ * d_out[32] (uint64, device memory) += counters, asynchronously on `stream`
+ * (a hipStream_t passed as void*; NULL = the library's own stream). */
+int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream);
+
+/* DEVICE-resident array, HOST counters: out[32] += counters; synchronous. */
+int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t* out);
+
+/* ---- context ---- */
+int FLAGSTATS_hip_available(void);          /* 1 if a gfx950-capable device can be used */
+int FLAGSTATS_hip_init(int device);         /* optional; lazily called with FLAGSTATS_HIP_DEVICE or 0 */
+void FLAGSTATS_hip_shutdown(void);          /* releases streams and workspaces */
+const char* FLAGSTATS_hip_last_error(void); /* text of the last failure on this thread ("" if none) */
+int FLAGSTATS_hip_device_id(void);          /* device the context is bound to, -1 before init */
+int FLAGSTATS_hip_compute_units(void);      /* CU count of that device, -1 before init */
+
+/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _CHUNK_FLAGS):
+ * key = "blocks_per_cu" | "variant" | "chunk_flags".  Returns 0 on success. */
+int FLAGSTATS_hip_set(const char* key, uint64_t value);
+uint64_t FLAGSTATS_hip_get(const char* key);
+
+/* ---- memory helpers for callers without a HIP runtime of their own ---- */
+void* FLAGSTATS_hip_host_alloc(size_t bytes);   /* pinned host memory */
+void FLAGSTATS_hip_host_free(void* p);
+void* FLAGSTATS_hip_device_alloc(size_t bytes); /* device memory */
+void FLAGSTATS_hip_device_free(void* p);
+int FLAGSTATS_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int FLAGSTATS_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int FLAGSTATS_hip_synchronize(void);
+
+/* ---- synthetic inputs on device (counterpart of benchmark/generate.cpp:8-14) ----
+ * d_array[k] = flag(kind, seed, mask, first_index + k), k in [0, n).
+ * kind 0 uniform (& mask), 1 NA12878-like (mask bit0 = +eps), 2 ramp. Asynchronous. */
+int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, uint32_t mask,
+                               uint64_t first_index, void* stream);
+
+/* ---- measurement: `reps` back-to-back K1+K2 launches between two hipEvents on
+ * the library's stream, after `warmup` untimed ones.  *ms_total = elapsed ms of
+ * the timed region; out[32] += counters of ONE pass.  Returns 0 on success. */
+int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmup, int reps, float* ms_total,
+                                  uint64_t* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,78 @@
+"""ctypes binding of the C-ABI library ``libflagstats_hip.so`` (include/libflagstats_hip.h).
+
+The library is built in-tree by ``__graft_entry__.build()`` (or
+``make -C libflagstats_amd/csrc``).  If it is missing this module raises -- there
+is no Python or CPU fallback for the hot path.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libflagstats_hip.so")
+
+_U16P = ctypes.POINTER(ctypes.c_uint16)
+_U32P = ctypes.POINTER(ctypes.c_uint32)
+_U64P = ctypes.POINTER(ctypes.c_uint64)
+FLAGSTATS_func = ctypes.CFUNCTYPE(ctypes.c_int, _U16P, ctypes.c_uint32, _U32P)
+
+# name -> (restype, argtypes); mirrors include/libflagstats_hip.h one to one
+SIGNATURES = {
+    "FLAGSTATS_u16": (ctypes.c_uint64, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "FLAGSTATS_get_function": (FLAGSTATS_func, [ctypes.c_uint32]),
+    "FLAGSTAT_hip": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
+    "FLAGSTATS_u16_x64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "FLAGSTATS_hip_device_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
+    "FLAGSTATS_hip_device_u16_sync": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "FLAGSTATS_hip_available": (ctypes.c_int, []),
+    "FLAGSTATS_hip_init": (ctypes.c_int, [ctypes.c_int]),
+    "FLAGSTATS_hip_shutdown": (None, []),
+    "FLAGSTATS_hip_last_error": (ctypes.c_char_p, []),
+    "FLAGSTATS_hip_device_id": (ctypes.c_int, []),
+    "FLAGSTATS_hip_compute_units": (ctypes.c_int, []),
+    "FLAGSTATS_hip_set": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64]),
+    "FLAGSTATS_hip_get": (ctypes.c_uint64, [ctypes.c_char_p]),
+    "FLAGSTATS_hip_host_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),
+    "FLAGSTATS_hip_host_free": (None, [ctypes.c_void_p]),
+    "FLAGSTATS_hip_device_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),
+    "FLAGSTATS_hip_device_free": (None, [ctypes.c_void_p]),
+    "FLAGSTATS_hip_memcpy_h2d": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "FLAGSTATS_hip_memcpy_d2h": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]),
+    "FLAGSTATS_hip_synchronize": (ctypes.c_int, []),
+    "FLAGSTATS_hip_generate_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64,
+                                                  ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
+    "FLAGSTATS_hip_time_device_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                                     ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]),
+}
+
+_lib = None
+
+
+class FlagstatsHipError(RuntimeError):
+    """The GPU path failed; there is no CPU fallback to hide it."""
+
+
+def lib() -> ctypes.CDLL:
+    """Load libflagstats_hip.so (once) and attach the prototypes."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: the HIP extension has not been built. Run "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C libflagstats_amd/csrc`). "
+            "libflagstats_amd has no CPU fallback for the flagstat hot path.")
+    handle = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(handle, name)  # AttributeError here = header/library drift
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = handle
+    return handle
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = lib().FLAGSTATS_hip_last_error().decode(errors="replace")
+        raise FlagstatsHipError(f"{what} failed (rc={rc}): {msg}")

@@ -1,0 +1,39 @@
+// flagstat_kernels.h -- internal interface between the HIP kernels and the C-ABI shim.
+#ifndef FLAGSTAT_KERNELS_H_
+#define FLAGSTAT_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace fsk {
+
+constexpr int kThreads = 256;                       // 4 waves per workgroup
+constexpr int kUnroll = 8;                          // 16-B vectors per lane per step
+constexpr int kVecPerStep = kThreads * kUnroll;     // 2048 vectors = 32 KiB = 16384 flags
+constexpr int kInternal = 19;                       // live counters (libflagstats.h:118-142)
+
+struct CountArgs {
+    const void* a0;        // 16-B aligned-down base of the array
+    uint64_t lo, hi;       // caller's flags occupy positions [lo, hi) of that grid
+    uint64_t nsteps;       // ceil(ceil(hi/8) / kVecPerStep)
+    uint64_t fast_begin;   // steps in [fast_begin, fast_end) are fully in range
+    uint64_t fast_end;
+    uint32_t grid;
+    uint64_t* partials;    // [grid][kInternal]
+};
+
+}  // namespace fsk
+
+extern "C" {
+// bytes of workspace K1 needs for `grid` workgroups
+size_t fsk_partials_bytes(uint32_t grid);
+// K1 + K2 on `stream`: d_out32[32] += counters of d_array[0..n).  Asynchronous.
+hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
+                      uint64_t* d_out32, hipStream_t stream);
+// on-device input makers (flagstat_generate.hip)
+hipError_t fsk_generate(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, uint32_t mask, uint64_t first_index,
+                        hipStream_t stream);
+}
+
+#endif

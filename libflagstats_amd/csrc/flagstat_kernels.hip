@@ -1,0 +1,414 @@
+// flagstat_kernels.hip -- the flagstat hot path as hand-written HIP for gfx950 (CDNA4).
+//
+// What it replaces (reference, /root/reference): the FLAGSTAT_* kernels of
+// libflagstats.h -- mask-select / propagate-carry front end (:1695-1704 and the
+// LUT forms :1908-1935, :2474-2489), the Harley-Seal carry-save tree (:1706-1767,
+// python/libalgebra.h:2311-2319), the counter flush (:1769-1840) and the scalar
+// tail (:1649-1651) -- with FLAGSTAT_scalar's exact 19-counter semantics
+// (:118-142), which of the reference's SIMD variants only _avx512_improved3
+// (:2321-2644) has.  Nothing here is a translation of those x86 kernels; the
+// design is for wave64 / VALU / HBM3E:
+//
+//  K1 flagstat_count   grid-stride over 32 KiB "steps"; each lane loads 8 x 16 B
+//                      (global_load_dwordx4, 1 KiB per wave-instruction, fully
+//                      coalesced), straight to VGPRs (read-once stream: an LDS
+//                      round trip buys nothing).  Per 16 B (8 flags):
+//                        * v_perm_b32 splits 2 dwords (4 flags) into a dword of
+//                          low bytes L and a dword of high bytes H  (byte-planar:
+//                          every later op works on 4 flags at once);
+//                        * three v_perm_b32 LUTs evaluate the flagstat decision
+//                          tree: (proper,unmap,munmap) -> n_pair_good/n_sgltn/
+//                          n_pair_map bits; (secondary,paired,supplementary) ->
+//                          category keep-mask; (qcfail,dup) -> fail mask + one-hot;
+//                        * result: T = 8 counter bits per flag (any QC),
+//                          F = T & fail-QC mask, S3 = one-hot(QC-only, DUP-only, both);
+//                        * T/F/S3 dwords go into bit-sliced carry-save counters:
+//                          one CSA = 2 x v_bitop3_b32 (0x96 sum, 0xE8 majority).
+//                      16 T-inputs per step collapse through a Harley-Seal tree;
+//                      the weight-16 carry enters a binary-counter chain of
+//                      (accumulator, pending) plane pairs driven by the *scalar*
+//                      step count, so the amortised cost stays 1 CSA per input at
+//                      any depth and the cross-lane transpose happens once per
+//                      epoch (2^DEPTH-1 steps), not per block as on x86 (:1751).
+//                      Epoch flush: v_bcnt_u32_b32 per (plane, counter) into 19
+//                      u32 lane counters; kernel end: wave butterfly + LDS ->
+//                      per-block uint64[19] partials.
+//  K2 flagstat_finalize sums partials on device, maps the 19 internal counters
+//                      to the reference's 32 slots and ADDS into out[32]
+//                      (accumulate contract).
+//
+// Zero flags contribute to no counter (KAT x=0), so ragged heads/tails and idle
+// lanes are handled by zero-filling: no host-side tail, no scalar fallback.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flagstat_kernels.h"
+
+namespace fsk {
+
+// ------------------------------------------------------------------ primitives
+__device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
+{
+    return __builtin_amdgcn_perm(hi, lo, sel);  // v_perm_b32: bytes 0-3 = lo, 4-7 = hi
+}
+
+// carry-save adder on 32 one-bit columns: 2 VALU ops on gfx950
+__device__ __forceinline__ void csa(uint32_t& carry, uint32_t& sum, uint32_t a, uint32_t b, uint32_t c)
+{
+    const uint32_t s = __builtin_amdgcn_bitop3_b32(a, b, c, 0x96);  // a ^ b ^ c
+    const uint32_t k = __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8);  // majority
+    sum = s;
+    carry = k;
+}
+
+// Front end for 4 flags held in two dwords (xa = flags 0,1; xb = flags 2,3).
+//
+// Output byte layout (one byte per flag, bit -> internal counter index):
+//   bit0 secondary            bit1 n_pair_good (proper & !unmap & pp)
+//   bit2 unmapped             bit3 supplementary & !secondary
+//   bit4 n_sgltn  (munmap & !unmap & pp)     bit5 n_pair_map (!munmap & !unmap & pp)
+//   bit6 read1 & pp           bit7 read2 & pp
+// where pp = paired & !secondary & !supplementary  (libflagstats.h:129-131).
+// selq: per byte (qcfail | dup<<1), feeds the QC/DUP LUTs.
+__device__ __forceinline__ void front4(uint32_t xa, uint32_t xb, uint32_t& T, uint32_t& selq)
+{
+    const uint32_t L = perm(xb, xa, 0x06040200u);  // FLAG bits 0..7  of 4 flags
+    const uint32_t H = perm(xb, xa, 0x07050301u);  // FLAG bits 8..15 of 4 flags
+
+    // LUT 1: idx = (proper, unmap, munmap) = L bits 1..3.  Entry = derived bits
+    // at 1/4/5, plus constant ones at bits 0 and 3 (so the AND below passes the
+    // secondary / supplementary bits that LUT 2 supplies).
+    const uint32_t sel1 = (L >> 1) & 0x07070707u;
+    const uint32_t abc = perm(0x09091B19u, 0x09092B29u, sel1);
+    // raw read1/read2 (6,7) and unmapped (2) from L, derived bits from the LUT
+    const uint32_t m = (L & 0xC4C4C4C4u) | abc;
+
+    // LUT 2: idx = (secondary, paired, supplementary).  Entry = keep-mask:
+    //   secondary         -> 0x01        supplementary only -> 0x08
+    //   primary paired    -> 0xF2        none of them       -> 0x00
+    // always | 0x04 so the unconditional UNMAP bit survives.
+    uint32_t idx = (H & 0x01010101u);
+    idx = ((H >> 1) & 0x04040404u) | idx;
+    idx = ((L << 1) & 0x02020202u) | idx;
+    const uint32_t keep = perm(0x050C050Cu, 0x05F60504u, idx);
+    T = m & keep;
+
+    selq = (H >> 1) & 0x03030303u;  // bit0 = QCFAIL, bit1 = DUP
+}
+
+// ------------------------------------------------------------------ lane state
+// Bit-sliced counters of one lane.  Streams: T (8 counters x 4 byte slots),
+// F (= T under fail-QC), S (one-hot QC/DUP, two nibble groups x 4 slots).
+template <int DEPTH>
+struct Lane {
+    uint32_t t1, t2, t4, t8;   // T planes of weight 1,2,4,8
+    uint32_t f1, f2, f4, f8;
+    uint32_t s1, s2, s4;       // S planes of weight 1,2,4 (8 inputs per step)
+    uint32_t tA[DEPTH], tB[DEPTH];  // chain level j: weight 16<<j  (accumulator, pending)
+    uint32_t fA[DEPTH], fB[DEPTH];
+    uint32_t sA[DEPTH], sB[DEPTH];  // weight 8<<j
+    uint32_t acc[kInternal];        // flushed lane counters
+};
+
+template <int DEPTH>
+__device__ __forceinline__ void lane_init(Lane<DEPTH>& s)
+{
+    s.t1 = s.t2 = s.t4 = s.t8 = 0;
+    s.f1 = s.f2 = s.f4 = s.f8 = 0;
+    s.s1 = s.s2 = s.s4 = 0;
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) s.tA[j] = s.tB[j] = s.fA[j] = s.fB[j] = s.sA[j] = s.sB[j] = 0;
+#pragma unroll
+    for (int c = 0; c < kInternal; ++c) s.acc[c] = 0;
+}
+
+// Binary-counter chain.  `blk` (steps pushed so far in this epoch) is wave-
+// uniform, so the branches are scalar.  Level j: bit j of blk clear -> park the
+// carry in the pending plane; set -> CSA(accumulator, pending, carry) and
+// ripple the new carry up.  Epochs end at 2^DEPTH-1 steps, so the top level
+// never carries out.
+template <int J, int DEPTH>
+__device__ __forceinline__ void chain_push(Lane<DEPTH>& s, uint32_t blk, uint32_t ct, uint32_t cf, uint32_t cs)
+{
+    if constexpr (J < DEPTH) {
+        if ((blk & (1u << J)) == 0) {
+            s.tB[J] = ct;
+            s.fB[J] = cf;
+            s.sB[J] = cs;
+        } else {
+            uint32_t nt, nf, ns;
+            csa(nt, s.tA[J], s.tA[J], s.tB[J], ct);
+            csa(nf, s.fA[J], s.fA[J], s.fB[J], cf);
+            csa(ns, s.sA[J], s.sA[J], s.sB[J], cs);
+            s.tB[J] = 0;
+            s.fB[J] = 0;
+            s.sB[J] = 0;
+            chain_push<J + 1, DEPTH>(s, blk, nt, nf, ns);
+        }
+    }
+}
+
+// One step: 8 vectors of 16 B per lane = 64 flags -> 16 T, 16 F, 8 S inputs.
+template <int DEPTH>
+__device__ __forceinline__ void step(Lane<DEPTH>& s, const uint4 (&v)[kUnroll], uint32_t blk)
+{
+    uint32_t t8a = 0, t8b = 0, f8a = 0, f8b = 0, s4a = 0, s4b = 0;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t t4a = 0, t4b = 0, f4a = 0, f4b = 0, s2a = 0, s2b = 0;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            // two vectors -> 4 T/F inputs, 2 S inputs
+            uint32_t T[4], F[4], S[2];
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const uint4 x = v[half * 4 + q * 2 + k];
+                uint32_t qa, qb;
+                front4(x.x, x.y, T[2 * k], qa);
+                front4(x.z, x.w, T[2 * k + 1], qb);
+                // fail-QC byte masks and one-hot (QC only, DUP only, both) nibbles
+                F[2 * k] = T[2 * k] & perm(0u, 0xFF00FF00u, qa);
+                F[2 * k + 1] = T[2 * k + 1] & perm(0u, 0xFF00FF00u, qb);
+                S[k] = perm(0u, 0x04020100u, qa) | perm(0u, 0x40201000u, qb);
+            }
+            uint32_t t2a, t2b, f2a, f2b;
+            csa(t2a, s.t1, s.t1, T[0], T[1]);
+            csa(t2b, s.t1, s.t1, T[2], T[3]);
+            csa(f2a, s.f1, s.f1, F[0], F[1]);
+            csa(f2b, s.f1, s.f1, F[2], F[3]);
+            csa(q ? t4b : t4a, s.t2, s.t2, t2a, t2b);
+            csa(q ? f4b : f4a, s.f2, s.f2, f2a, f2b);
+            csa(q ? s2b : s2a, s.s1, s.s1, S[0], S[1]);
+        }
+        csa(half ? t8b : t8a, s.t4, s.t4, t4a, t4b);
+        csa(half ? f8b : f8a, s.f4, s.f4, f4a, f4b);
+        csa(half ? s4b : s4a, s.s2, s.s2, s2a, s2b);
+    }
+    uint32_t ct, cf, cs;
+    csa(ct, s.t8, s.t8, t8a, t8b);  // weight-16 carry
+    csa(cf, s.f8, s.f8, f8a, f8b);
+    csa(cs, s.s4, s.s4, s4a, s4b);  // weight-8 carry
+    chain_push<0, DEPTH>(s, blk, ct, cf, cs);
+}
+
+// Horner over planes from the heaviest down: acc = 2*acc + popcount(plane & mask)
+__device__ __forceinline__ uint32_t hstep(uint32_t acc, uint32_t plane, uint32_t mask, bool dbl)
+{
+    return __builtin_popcount(plane & mask) + (dbl ? (acc << 1) : acc);
+}
+
+// Epoch flush: fold every plane into the 19 u32 lane counters and clear them.
+template <int DEPTH>
+__device__ __forceinline__ void flush(Lane<DEPTH>& s)
+{
+#pragma unroll
+    for (int c = 0; c < 8; ++c) {
+        const uint32_t mk = 0x01010101u << c;
+        uint32_t at = 0, af = 0;
+#pragma unroll
+        for (int j = DEPTH - 1; j >= 0; --j) {
+            at = hstep(at, s.tA[j], mk, true);
+            at = hstep(at, s.tB[j], mk, false);
+            af = hstep(af, s.fA[j], mk, true);
+            af = hstep(af, s.fB[j], mk, false);
+        }
+        at = hstep(at, s.t8, mk, true);
+        at = hstep(at, s.t4, mk, true);
+        at = hstep(at, s.t2, mk, true);
+        at = hstep(at, s.t1, mk, true);
+        af = hstep(af, s.f8, mk, true);
+        af = hstep(af, s.f4, mk, true);
+        af = hstep(af, s.f2, mk, true);
+        af = hstep(af, s.f1, mk, true);
+        s.acc[c] += at;
+        s.acc[8 + c] += af;
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t mk = 0x11111111u << c;  // both nibble groups
+        uint32_t as = 0;
+#pragma unroll
+        for (int j = DEPTH - 1; j >= 0; --j) {
+            as = hstep(as, s.sA[j], mk, true);
+            as = hstep(as, s.sB[j], mk, false);
+        }
+        as = hstep(as, s.s4, mk, true);
+        as = hstep(as, s.s2, mk, true);
+        as = hstep(as, s.s1, mk, true);
+        s.acc[16 + c] += as;
+    }
+    s.t1 = s.t2 = s.t4 = s.t8 = 0;
+    s.f1 = s.f2 = s.f4 = s.f8 = 0;
+    s.s1 = s.s2 = s.s4 = 0;
+#pragma unroll
+    for (int j = 0; j < DEPTH; ++j) s.tA[j] = s.tB[j] = s.fA[j] = s.fB[j] = s.sA[j] = s.sB[j] = 0;
+}
+
+// ------------------------------------------------------------------ loads
+// The array is addressed on the 16-byte grid of its aligned-down base `a0`:
+// vector j holds flag positions [8j, 8j+8); positions in [lo, hi) are the
+// caller's flags, everything else reads as zero (a zero flag counts nothing).
+__device__ __forceinline__ uint4 load_guarded(const uint4* __restrict__ a0, uint64_t j, uint64_t lo, uint64_t hi)
+{
+    const uint64_t f0 = j * 8;
+    uint4 r = make_uint4(0, 0, 0, 0);
+    if (f0 >= lo && f0 + 8 <= hi) return a0[j];
+    if (f0 + 8 <= lo || f0 >= hi) return r;
+    const uint16_t* p = reinterpret_cast<const uint16_t*>(a0 + j);
+    uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const uint64_t f = f0 + e;
+        if (f >= lo && f < hi) w[e >> 1] |= static_cast<uint32_t>(p[e]) << (16 * (e & 1));
+    }
+    return make_uint4(w[0], w[1], w[2], w[3]);
+}
+
+template <bool NT>
+__device__ __forceinline__ uint4 load_vec(const uint4* __restrict__ p)
+{
+    if constexpr (NT) {
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        const u32x4 t = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(p));
+        return make_uint4(t.x, t.y, t.z, t.w);
+    } else {
+        return *p;
+    }
+}
+
+// ------------------------------------------------------------------ K1
+template <int DEPTH, bool NT>
+__global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
+                                                           uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
+                                                           uint64_t* __restrict__ partials)
+{
+    Lane<DEPTH> s;
+    lane_init(s);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    // within a step each wave owns a contiguous 8 KiB: vector = wave*512 + u*64 + lane
+    const uint64_t lane_off = static_cast<uint64_t>(wave) * (64 * kUnroll) + lane;
+    uint32_t blk = 0;
+
+    for (uint64_t st = blockIdx.x; st < nsteps; st += gridDim.x) {
+        uint4 v[kUnroll];
+        const uint64_t j0 = st * kVecPerStep + lane_off;
+        if (st >= fast_begin && st < fast_end) {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<NT>(a0 + j0 + u * 64);
+        } else {
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) v[u] = load_guarded(a0, j0 + u * 64, lo, hi);
+        }
+        step(s, v, blk);
+        ++blk;
+        if (blk == (1u << DEPTH) - 1u) {
+            flush(s);
+            blk = 0;
+        }
+    }
+    flush(s);
+
+    // wave butterfly, then 4 waves through LDS
+    __shared__ uint32_t red[kThreads / 64][kInternal];
+#pragma unroll
+    for (int c = 0; c < kInternal; ++c) {
+        uint32_t x = s.acc[c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        if (lane == 0) red[wave][c] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x < kInternal) {
+        uint64_t sum = 0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) sum += red[w][threadIdx.x];
+        partials[static_cast<uint64_t>(blockIdx.x) * kInternal + threadIdx.x] = sum;
+    }
+}
+
+// ------------------------------------------------------------------ K2
+// One workgroup: sum partials[nblocks][19], map to the reference's 32 slots
+// (index = FLAGSTAT_*_OFF, libflagstats.h:69-112; +16 for fail-QC) and ADD into
+// out[32].  Slots the scalar rule never writes get nothing added.
+__global__ __launch_bounds__(kThreads) void flagstat_finalize(const uint64_t* __restrict__ partials, uint32_t nblocks,
+                                                              uint64_t* __restrict__ out)
+{
+    __shared__ uint64_t tot[kInternal];
+    __shared__ uint64_t red[kThreads / 64];
+    const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    for (int c = 0; c < kInternal; ++c) {
+        uint64_t x = 0;
+        for (uint32_t b = threadIdx.x; b < nblocks; b += kThreads) x += partials[static_cast<uint64_t>(b) * kInternal + c];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        if (lane == 0) red[wave] = x;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            uint64_t t = 0;
+            for (int w = 0; w < kThreads / 64; ++w) t += red[w];
+            tot[c] = t;
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        // internal T/F index -> reference slot
+        const int slot[8] = {8 /*secondary*/, 12 /*n_pair_good*/, 2 /*unmap*/, 11 /*supplementary*/,
+                             13 /*n_sgltn*/, 14 /*n_pair_map*/, 6 /*read1*/, 7 /*read2*/};
+        for (int c = 0; c < 8; ++c) {
+            out[slot[c]] += tot[c] - tot[8 + c];  // pass-QC = all - fail
+            out[16 + slot[c]] += tot[8 + c];
+        }
+        out[10] += tot[17];            // DUP, pass-QC
+        out[26] += tot[18];            // DUP, fail-QC
+        out[25] += tot[16] + tot[18];  // fail-QC read count
+    }
+}
+
+}  // namespace fsk
+
+// ------------------------------------------------------------------ launchers
+extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t); }
+
+template <int DEPTH, bool NT>
+static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
+{
+    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
+                       reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials);
+    return hipGetLastError();
+}
+
+// Host-side geometry: everything the kernel assumes is derived here from
+// (pointer, n) so operand shapes and the grid cannot disagree.
+extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
+                                 uint64_t* d_out32, hipStream_t stream)
+{
+    if (n == 0) return hipSuccess;
+    if (grid == 0 || d_array == nullptr || d_partials == nullptr || d_out32 == nullptr) return hipErrorInvalidValue;
+    const uintptr_t addr = reinterpret_cast<uintptr_t>(d_array);
+    if (addr & 1u) return hipErrorInvalidValue;  // uint16_t* must be 2-byte aligned
+    fsk::CountArgs a;
+    const uintptr_t base = addr & ~static_cast<uintptr_t>(15);
+    a.a0 = reinterpret_cast<const void*>(base);
+    a.lo = (addr - base) / 2;
+    a.hi = a.lo + n;
+    const uint64_t nvec = (a.hi + 7) / 8;
+    a.nsteps = (nvec + fsk::kVecPerStep - 1) / fsk::kVecPerStep;
+    // steps whose 2048 vectors are all fully inside [lo, hi)
+    a.fast_begin = (a.lo == 0) ? 0 : 1;
+    a.fast_end = (a.hi / 8) / fsk::kVecPerStep;
+    if (a.fast_end < a.fast_begin) a.fast_end = a.fast_begin;
+    if (static_cast<uint64_t>(grid) > a.nsteps) grid = static_cast<uint32_t>(a.nsteps);
+    a.grid = grid;
+    a.partials = d_partials;
+    hipError_t e;
+    switch (variant) {
+    case 1: e = launch_count_t<8, true>(a, stream); break;
+    case 2: e = launch_count_t<7, false>(a, stream); break;
+    case 3: e = launch_count_t<7, true>(a, stream); break;
+    default: e = launch_count_t<8, false>(a, stream); break;
+    }
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kThreads), 0, stream, d_partials, grid, d_out32);
+    return hipGetLastError();
+}

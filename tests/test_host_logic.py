@@ -1,0 +1,107 @@
+"""CPU: host-side logic that needs no GPU -- argument validation of the pyflagstats mirror,
+dict construction, shard arithmetic, C-ABI library surface."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden
+
+
+def test_validation_errors_match_reference_module():
+    """Same exception types and messages as python/libflagstats.pyx:9-13,21-22 (captured from the
+    reference's own module in tests/golden/pyflagstats.json).  Raised before any GPU call."""
+    import pyflagstats
+    errs = load_golden("pyflagstats.json")["errors"]
+    args = {"list": [1, 2, 3], "int32": np.zeros(4, dtype=np.int32), "empty": np.zeros(0, dtype=np.uint16),
+            "2d": np.zeros((4, 4), dtype=np.uint16)}
+    types = {"ValueError": ValueError, "IndexError": IndexError}
+    for name, arg in args.items():
+        want = errs[name]
+        with pytest.raises(types[want["type"]]) as ei:
+            pyflagstats.flagstats(arg)
+        assert str(ei.value) == want["msg"], name
+
+
+def test_dict_layout_from_counters():
+    """_as_dict restates python/libflagstats.pyx:24-35; compare with dicts the reference produced."""
+    from libflagstats_amd.pyflagstats import _as_dict
+    g = load_golden("pyflagstats.json")["dicts"]
+    for key in ("4096_100", "65536_100", "4096_1"):  # n < 256: reference ran FLAGSTAT_scalar
+        want = g[key]
+        hi, n = (int(v) for v in key.split("_"))
+        flags = np.zeros(32, dtype=np.uint32)
+        for i, name in enumerate(want["passed_keys"][:15]):
+            flags[i] = want["passed"][name]
+            flags[16 + i] = want["failed"][name]
+        got = _as_dict(flags, n)
+        assert list(got["passed"].keys()) == want["passed_keys"]
+        assert list(got["failed"].keys()) == want["failed_keys"]
+        assert {k: int(v) for k, v in got["passed"].items()} == want["passed"]
+        assert {k: int(v) for k, v in got["failed"].items()} == want["failed"]
+        assert type(got["passed"]["mapped"]).__name__ == "uint32"
+
+
+def test_shard_ranges_cover_exactly():
+    from libflagstats_amd.dist import shard_range
+    for n in (0, 1, 7, 8, 1000, 2 ** 35 + 3):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            for (b0, e0), (b1, e1) in zip(spans, spans[1:]):
+                assert e0 == b1 and b0 <= e0
+    with pytest.raises(ValueError):
+        shard_range(10, 2, 2)
+
+
+def declared_symbols():
+    text = open(os.path.join(ROOT, "include", "libflagstats_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    names = re.findall(r"\b(FLAGSTATS?_[A-Za-z0-9_]+)\s*\(", text)
+    return sorted(set(n for n in names if n != "FLAGSTATS_func"))
+
+
+def test_library_exports_every_declared_symbol():
+    """The C-ABI .so loads without a GPU and exports everything include/libflagstats_hip.h declares."""
+    from libflagstats_amd import _lib
+    lib = _lib.lib()
+    syms = declared_symbols()
+    assert len(syms) >= 20
+    for name in syms:
+        assert hasattr(lib, name), "missing export: " + name
+        assert name in _lib.SIGNATURES, "no ctypes prototype for " + name
+    assert sorted(_lib.SIGNATURES) == syms
+    # header cites the reference interface each drop-in symbol replaces
+    text = open(os.path.join(ROOT, "include", "libflagstats_hip.h")).read()
+    for cite in ("libflagstats.h:3024", "libflagstats.h:2976", "libflagstats.h:2970"):
+        assert cite in text
+
+
+def test_no_gpu_means_loud_failure_not_fallback():
+    """Without a GPU the hot path must fail loudly (non-zero + message), never compute on the CPU."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from libflagstats_amd import _lib
+    lib = _lib.lib()
+    assert lib.FLAGSTATS_hip_available() == 0
+    a = np.arange(100, dtype=np.uint16)
+    flags = np.zeros(32, dtype=np.uint32)
+    rc = lib.FLAGSTATS_u16(a.ctypes.data, a.size, flags.ctypes.data)
+    assert rc != 0 and not flags.any()
+    assert b"libflagstats_hip" in lib.FLAGSTATS_hip_last_error()
+    import pyflagstats
+    with pytest.raises(_lib.FlagstatsHipError):
+        pyflagstats.flagstats(a)
+
+
+def test_product_never_imports_oracle():
+    """Only tests/, smoke() and bench.py's cpu_baseline may touch oracle/."""
+    pkg = os.path.join(ROOT, "libflagstats_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                src = open(os.path.join(dirpath, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f
+    assert "oracle" not in open(os.path.join(ROOT, "pyflagstats.py")).read()
