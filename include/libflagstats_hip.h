@@ -58,7 +58,7 @@ int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out);
 
 /* DEVICE-resident array (any 2-byte alignment), DEVICE counters:
  * d_out[32] (uint64, device memory) += counters, asynchronously on `stream`
- * (a hipStream_t passed as void*; NULL = the library's own stream). */
+ * (a hipStream_t passed as void*; NULL = HIP's null stream, as in every HIP API). */
 int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream);
 
 /* DEVICE-resident array, HOST counters: out[32] += counters; synchronous. */
@@ -73,7 +73,7 @@ int FLAGSTATS_hip_device_id(void);          /* device the context is bound to, -
 int FLAGSTATS_hip_compute_units(void);      /* CU count of that device, -1 before init */
 
 /* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _CHUNK_FLAGS):
- * key = "blocks_per_cu" | "variant" | "chunk_flags".  Returns 0 on success. */
+ * key = "blocks_per_cu" | "variant" (0..7) | "chunk_flags".  Returns 0 on success. */
 int FLAGSTATS_hip_set(const char* key, uint64_t value);
 uint64_t FLAGSTATS_hip_get(const char* key);
 
@@ -97,6 +97,11 @@ int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t
  * the timed region; out[32] += counters of ONE pass.  Returns 0 on success. */
 int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmup, int reps, float* ms_total,
                                   uint64_t* out);
+
+/* read-only bandwidth probe with K1's load pattern and no flagstat arithmetic
+ * (the analogue of the reference's memcpy baseline, linux/instrumented_benchmark.cpp:456-544):
+ * `reps` sweeps of d_buf[0..bytes) (16-B aligned) between two hipEvents; nt = non-temporal loads. */
+int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warmup, int reps, float* ms_total);
 
 #ifdef __cplusplus
 }

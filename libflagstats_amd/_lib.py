@@ -44,6 +44,8 @@ SIGNATURES = {
                                                   ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
     "FLAGSTATS_hip_time_device_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                                      ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]),
+    "FLAGSTATS_hip_read_probe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                                ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
 }
 
 _lib = None

@@ -29,7 +29,7 @@ struct Ctx {
     int device = -1;
     int cus = 0;
     uint32_t blocks_per_cu = 0;  // 0 = auto
-    int variant = 0;
+    int variant = 1;                     // DEPTH 8, non-temporal loads, no register prefetch (tools/tune.py)
     uint64_t chunk_flags = 32ull << 20;  // host streaming chunk: 32 Mi flags = 64 MiB
     hipStream_t stream[2] = {nullptr, nullptr};
     Workspace ws[2];
@@ -75,7 +75,7 @@ uint64_t env_u64(const char* name, uint64_t dflt)
 uint32_t grid_for(uint64_t n)
 {
     (void)n;
-    uint32_t bpc = g.blocks_per_cu ? g.blocks_per_cu : 3;
+    uint32_t bpc = g.blocks_per_cu ? g.blocks_per_cu : 2;
     return (uint32_t)g.cus * bpc;
 }
 
@@ -260,7 +260,7 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         if (value > 16) return fail_msg("blocks_per_cu must be 0 (auto) .. 16");
         g.blocks_per_cu = (uint32_t)value;
     } else if (!std::strcmp(key, "variant")) {
-        if (value > 3) return fail_msg("variant must be 0..3");
+        if (value > 7) return fail_msg("variant must be 0..7");
         g.variant = (int)value;
     } else if (!std::strcmp(key, "chunk_flags")) {
         if (value < 8) return fail_msg("chunk_flags must be >= 8");
@@ -275,7 +275,7 @@ uint64_t FLAGSTATS_hip_get(const char* key)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!key) return 0;
-    if (!std::strcmp(key, "blocks_per_cu")) return g.blocks_per_cu ? g.blocks_per_cu : 3;
+    if (!std::strcmp(key, "blocks_per_cu")) return g.blocks_per_cu ? g.blocks_per_cu : 2;
     if (!std::strcmp(key, "variant")) return (uint64_t)g.variant;
     if (!std::strcmp(key, "chunk_flags")) return g.chunk_flags;
     if (!std::strcmp(key, "grid")) return g.ready ? grid_for(0) : 0;
@@ -320,7 +320,7 @@ int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_ou
     if (!d_out) return fail_msg("NULL d_out");
     int rc = bind();
     if (rc) return rc;
-    if (stream == nullptr) return count_device_async(d_array, n, d_out, g.stream[0], g.ws[0]);
+    // `stream` is used as given: NULL is HIP's null stream (what torch's default stream is)
     return count_device_async(d_array, n, d_out, (hipStream_t)stream, g.user_ws[stream]);
 }
 
@@ -408,7 +408,7 @@ int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     int rc = bind();
     if (rc) return rc;
-    HIP_TRY(fsk_generate(d_array, n, kind, seed, mask, first_index, stream ? (hipStream_t)stream : g.stream[0]));
+    HIP_TRY(fsk_generate(d_array, n, kind, seed, mask, first_index, (hipStream_t)stream));
     return 0;
 }
 
@@ -441,6 +441,30 @@ int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmu
     (void)hipEventDestroy(e1);
     if (out)
         for (int k = 0; k < 32; ++k) out[k] += g.h_out[k] / (uint64_t)reps;
+    return 0;
+}
+
+int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warmup, int reps, float* ms_total)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!ms_total || reps < 1 || warmup < 0) return fail_msg("bad timing arguments");
+    int rc = bind();
+    if (rc) return rc;
+    hipStream_t s = g.stream[0];
+    const uint32_t grid = grid_for(0);
+    rc = ensure_ws(g.ws[0], grid);  // reuse the partials buffer as the (never written) sink
+    if (rc) return rc;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < warmup; ++i) HIP_TRY(fsk_read_probe(d_buf, bytes, grid, nt, (uint32_t*)g.ws[0].partials, s));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) HIP_TRY(fsk_read_probe(d_buf, bytes, grid, nt, (uint32_t*)g.ws[0].partials, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventElapsedTime(ms_total, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
     return 0;
 }
 

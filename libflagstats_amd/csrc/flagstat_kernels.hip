@@ -277,7 +277,36 @@ __device__ __forceinline__ uint4 load_vec(const uint4* __restrict__ p)
 }
 
 // ------------------------------------------------------------------ K1
-template <int DEPTH, bool NT>
+template <bool NT>
+__device__ __forceinline__ void load_step(uint4 (&v)[kUnroll], const uint4* __restrict__ a0, uint64_t st, uint64_t lane_off,
+                                          uint64_t lo, uint64_t hi, uint64_t fast_begin, uint64_t fast_end)
+{
+    const uint64_t j0 = st * kVecPerStep + lane_off;
+    if (st >= fast_begin && st < fast_end) {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<NT>(a0 + j0 + u * 64);
+    } else {
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = load_guarded(a0, j0 + u * 64, lo, hi);
+    }
+}
+
+template <int DEPTH>
+__device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, const uint4 (&v)[kUnroll], uint32_t& blk)
+{
+    step(s, v, blk);
+    ++blk;
+    if (blk == (1u << DEPTH) - 1u) {
+        flush(s);
+        blk = 0;
+    }
+}
+
+// PREFETCH = false: load 8 x 16 B, wait, compute; latency is hidden by the other
+// waves of the SIMD only.  PREFETCH = true: two register buffers, the loads of
+// step k+1 are in flight while step k is computed (one more 8 KiB per wave in
+// flight, +32 VGPRs).
+template <int DEPTH, bool NT, bool PREFETCH>
 __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
                                                            uint64_t* __restrict__ partials)
@@ -288,23 +317,27 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
     const uint32_t wave = threadIdx.x >> 6;
     // within a step each wave owns a contiguous 8 KiB: vector = wave*512 + u*64 + lane
     const uint64_t lane_off = static_cast<uint64_t>(wave) * (64 * kUnroll) + lane;
+    const uint64_t G = gridDim.x;
     uint32_t blk = 0;
 
-    for (uint64_t st = blockIdx.x; st < nsteps; st += gridDim.x) {
-        uint4 v[kUnroll];
-        const uint64_t j0 = st * kVecPerStep + lane_off;
-        if (st >= fast_begin && st < fast_end) {
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<NT>(a0 + j0 + u * 64);
-        } else {
-#pragma unroll
-            for (int u = 0; u < kUnroll; ++u) v[u] = load_guarded(a0, j0 + u * 64, lo, hi);
+    if constexpr (!PREFETCH) {
+        for (uint64_t st = blockIdx.x; st < nsteps; st += G) {
+            uint4 v[kUnroll];
+            load_step<NT>(v, a0, st, lane_off, lo, hi, fast_begin, fast_end);
+            step_and_count(s, v, blk);
         }
-        step(s, v, blk);
-        ++blk;
-        if (blk == (1u << DEPTH) - 1u) {
-            flush(s);
-            blk = 0;
+    } else {
+        uint4 va[kUnroll], vb[kUnroll];
+        uint64_t st = blockIdx.x;
+        if (st < nsteps) load_step<NT>(va, a0, st, lane_off, lo, hi, fast_begin, fast_end);
+        while (st < nsteps) {
+            if (st + G < nsteps) load_step<NT>(vb, a0, st + G, lane_off, lo, hi, fast_begin, fast_end);
+            step_and_count(s, va, blk);
+            st += G;
+            if (st >= nsteps) break;
+            if (st + G < nsteps) load_step<NT>(va, a0, st + G, lane_off, lo, hi, fast_begin, fast_end);
+            step_and_count(s, vb, blk);
+            st += G;
         }
     }
     flush(s);
@@ -325,6 +358,30 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
         for (int w = 0; w < kThreads / 64; ++w) sum += red[w][threadIdx.x];
         partials[static_cast<uint64_t>(blockIdx.x) * kInternal + threadIdx.x] = sum;
     }
+}
+
+// ------------------------------------------------------------------ read probe
+// Measurement only ("fraction of a measured read-only probe
+// kernel", the analogue of the reference's memcpy baseline,
+// linux/instrumented_benchmark.cpp:456-544): the same load pattern as K1 with
+// the arithmetic reduced to one XOR per dword.
+template <bool NT>
+__global__ __launch_bounds__(kThreads) void flagstat_read_probe(const uint4* __restrict__ a0, uint64_t nsteps,
+                                                                uint32_t* __restrict__ sink)
+{
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t wave = threadIdx.x >> 6;
+    const uint64_t lane_off = static_cast<uint64_t>(wave) * (64 * kUnroll) + lane;
+    uint32_t acc = 0;
+    for (uint64_t st = blockIdx.x; st < nsteps; st += gridDim.x) {
+        uint4 v[kUnroll];
+        const uint64_t j0 = st * kVecPerStep + lane_off;
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<NT>(a0 + j0 + u * 64);
+#pragma unroll
+        for (int u = 0; u < kUnroll; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;  // practically never; keeps the loads alive
 }
 
 // ------------------------------------------------------------------ K2
@@ -370,10 +427,10 @@ __global__ __launch_bounds__(kThreads) void flagstat_finalize(const uint64_t* __
 // ------------------------------------------------------------------ launchers
 extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t); }
 
-template <int DEPTH, bool NT>
+template <int DEPTH, bool NT, bool PREFETCH>
 static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
+    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials);
     return hipGetLastError();
 }
@@ -403,12 +460,32 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     a.partials = d_partials;
     hipError_t e;
     switch (variant) {
-    case 1: e = launch_count_t<8, true>(a, stream); break;
-    case 2: e = launch_count_t<7, false>(a, stream); break;
-    case 3: e = launch_count_t<7, true>(a, stream); break;
-    default: e = launch_count_t<8, false>(a, stream); break;
+    case 1: e = launch_count_t<8, true, false>(a, stream); break;
+    case 2: e = launch_count_t<7, false, false>(a, stream); break;
+    case 3: e = launch_count_t<7, true, false>(a, stream); break;
+    case 4: e = launch_count_t<8, false, true>(a, stream); break;
+    case 5: e = launch_count_t<8, true, true>(a, stream); break;
+    case 6: e = launch_count_t<7, false, true>(a, stream); break;
+    case 7: e = launch_count_t<7, true, true>(a, stream); break;
+    default: e = launch_count_t<8, false, false>(a, stream); break;
     }
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kThreads), 0, stream, d_partials, grid, d_out32);
+    return hipGetLastError();
+}
+
+// read-only bandwidth probe over the first floor(bytes / 32 KiB) steps of a 16-B aligned buffer
+extern "C" hipError_t fsk_read_probe(const void* d_buf, uint64_t bytes, uint32_t grid, int nt, uint32_t* d_sink,
+                                     hipStream_t stream)
+{
+    if ((reinterpret_cast<uintptr_t>(d_buf) & 15u) || grid == 0) return hipErrorInvalidValue;
+    const uint64_t nsteps = bytes / (16ull * fsk::kVecPerStep);
+    if (nsteps == 0) return hipSuccess;
+    if (nt)
+        hipLaunchKernelGGL(fsk::flagstat_read_probe<true>, dim3(grid), dim3(fsk::kThreads), 0, stream,
+                           reinterpret_cast<const uint4*>(d_buf), nsteps, d_sink);
+    else
+        hipLaunchKernelGGL(fsk::flagstat_read_probe<false>, dim3(grid), dim3(fsk::kThreads), 0, stream,
+                           reinterpret_cast<const uint4*>(d_buf), nsteps, d_sink);
     return hipGetLastError();
 }

@@ -230,6 +230,8 @@ def load_ref():
         fn = getattr(lib, name)
         fn.argtypes = [_U16P, ctypes.c_uint64, _U64P]
         fn.restype = None
+    lib.ref_dispatch_repeat.argtypes = [_U16P, ctypes.c_uint64, ctypes.c_uint32, _U64P]
+    lib.ref_dispatch_repeat.restype = None
     for name in ("ref_has_avx512bw", "ref_has_avx2", "ref_has_sse42", "ref_cpuid"):
         getattr(lib, name).restype = ctypes.c_int
     _ref = lib

@@ -98,6 +98,12 @@ void ref_dispatch_x64(const uint16_t* a, uint64_t n, uint64_t out[32])
     }
 }
 
+/* `reps` passes inside one call, so a Python caller times the kernel, not ctypes */
+void ref_dispatch_repeat(const uint16_t* a, uint64_t n, uint32_t reps, uint64_t out[32])
+{
+    for (uint32_t r = 0; r < reps; ++r) ref_dispatch_x64(a, n, out);
+}
+
 void ref_scalar_x64(const uint16_t* a, uint64_t n, uint64_t out[32])
 {
     const uint64_t CH = 1ull << 30;

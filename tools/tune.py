@@ -1,0 +1,60 @@
+#!/usr/bin/env python3
+"""Measurement helper (GPU box): sweep K1 variants x grid sizes on the headline workload and
+measure the read-only probe ceiling.  Interleaved rounds in ONE process, median and min."""
+import argparse
+import ctypes
+import json
+import os
+import statistics
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from libflagstats_amd import _lib, device  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--flags", type=int, default=2 ** 32)
+    ap.add_argument("--variants", default="0,1,2,3,4,5,6,7")
+    ap.add_argument("--bpc", default="1,2,3,4,6,8")
+    ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--kind", type=int, default=0)
+    ap.add_argument("--probe", action="store_true")
+    args = ap.parse_args()
+    lib = _lib.lib()
+    _lib.check(lib.FLAGSTATS_hip_init(0), "init")
+    n = args.flags
+    d = device.DeviceFlags(n).generate(args.kind, seed=2026, mask=0xFFFF if args.kind == 0 else 1)
+    res = {}
+    variants = [int(v) for v in args.variants.split(",")]
+    bpcs = [int(v) for v in args.bpc.split(",")]
+    for r in range(args.rounds):
+        for v in variants:
+            for b in bpcs:
+                lib.FLAGSTATS_hip_set(b"variant", v)
+                lib.FLAGSTATS_hip_set(b"blocks_per_cu", b)
+                ms, _ = device.time_device_ptr(d.ptr, n, 1, args.reps)
+                res.setdefault((v, b), []).append(ms / args.reps)
+    print("variant bpc  median_ms  min_ms   TB/s(med)  TB/s(best)")
+    for (v, b), t in sorted(res.items()):
+        med, mn = statistics.median(t), min(t)
+        print("%7d %3d  %9.4f %8.4f  %8.3f  %8.3f" % (v, b, med, mn, 2 * n / med / 1e9, 2 * n / mn / 1e9))
+    if args.probe:
+        print("read probe: nt bpc median_ms TB/s")
+        for nt in (0, 1):
+            for b in bpcs:
+                lib.FLAGSTATS_hip_set(b"blocks_per_cu", b)
+                ts = []
+                for r in range(args.rounds):
+                    ms = ctypes.c_float(0)
+                    _lib.check(lib.FLAGSTATS_hip_read_probe(d.ptr, 2 * n, nt, 1, args.reps, ctypes.byref(ms)), "probe")
+                    ts.append(ms.value / args.reps)
+                med = statistics.median(ts)
+                print("%d %3d %9.4f %8.3f" % (nt, b, med, 2 * n / med / 1e9))
+
+
+if __name__ == "__main__":
+    main()
