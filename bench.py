@@ -141,7 +141,11 @@ def main():
     torch.cuda.synchronize()
 
     def step():
-        counters.zero_()
+        # N = 1: counters accumulate across steps (the ABI's += contract, as the reference's
+        # bench accumulates across blocks, benchmark/flagstats.cpp:304,328-329), so a step is
+        # exactly K1 + K2.  N > 1: a step is one whole query: zero, count, all-reduce.
+        if world > 1:
+            counters.zero_()
         device.count_torch(flags, counters)      # K1 + K2 on torch's current stream
         if world > 1:
             allreduce_counters(counters)          # the path's only exchange: 256 B over xGMI
@@ -153,6 +157,8 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    barrier()
+    counters.zero_()
     barrier()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
@@ -178,6 +184,9 @@ def main():
     result = None
     if rank == 0:
         got = counters.cpu().numpy().view(np.uint64)
+        passes = args.steps if world == 1 else 1   # N = 1 accumulated `steps` identical passes
+        assert not (got % np.uint64(passes)).any(), "accumulated counters are not a multiple of the step count"
+        got = got // np.uint64(passes)
         cpu = None
         parity = "not checked"
         if args.cpu_seconds > 0 and world == 1:

@@ -29,7 +29,7 @@ struct Ctx {
     int device = -1;
     int cus = 0;
     uint32_t blocks_per_cu = 0;  // 0 = auto
-    int variant = 1;                     // DEPTH 8, non-temporal loads, no register prefetch (tools/tune.py)
+    int variant = 9;                     // DEPTH 8, non-temporal loads, waves interleaved at 1 KiB (tools/tune.py)
     uint64_t chunk_flags = 32ull << 20;  // host streaming chunk: 32 Mi flags = 64 MiB
     hipStream_t stream[2] = {nullptr, nullptr};
     Workspace ws[2];
@@ -260,7 +260,7 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         if (value > 16) return fail_msg("blocks_per_cu must be 0 (auto) .. 16");
         g.blocks_per_cu = (uint32_t)value;
     } else if (!std::strcmp(key, "variant")) {
-        if (value > 7) return fail_msg("variant must be 0..7");
+        if (value > 13) return fail_msg("variant must be 0..13");
         g.variant = (int)value;
     } else if (!std::strcmp(key, "chunk_flags")) {
         if (value < 8) return fail_msg("chunk_flags must be >= 8");

@@ -277,17 +277,20 @@ __device__ __forceinline__ uint4 load_vec(const uint4* __restrict__ p)
 }
 
 // ------------------------------------------------------------------ K1
-template <bool NT>
+// USTRIDE = vectors between a lane's consecutive loads: 64 -> each wave owns a contiguous
+// 8 KiB of the step; 256 -> the 4 waves interleave at 1 KiB (each load instruction of the
+// workgroup covers a contiguous 4 KiB).
+template <bool NT, int USTRIDE>
 __device__ __forceinline__ void load_step(uint4 (&v)[kUnroll], const uint4* __restrict__ a0, uint64_t st, uint64_t lane_off,
                                           uint64_t lo, uint64_t hi, uint64_t fast_begin, uint64_t fast_end)
 {
     const uint64_t j0 = st * kVecPerStep + lane_off;
     if (st >= fast_begin && st < fast_end) {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<NT>(a0 + j0 + u * 64);
+        for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<NT>(a0 + j0 + u * USTRIDE);
     } else {
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = load_guarded(a0, j0 + u * 64, lo, hi);
+        for (int u = 0; u < kUnroll; ++u) v[u] = load_guarded(a0, j0 + u * USTRIDE, lo, hi);
     }
 }
 
@@ -306,7 +309,7 @@ __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, const uint4 (&v)[
 // waves of the SIMD only.  PREFETCH = true: two register buffers, the loads of
 // step k+1 are in flight while step k is computed (one more 8 KiB per wave in
 // flight, +32 VGPRs).
-template <int DEPTH, bool NT, bool PREFETCH>
+template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE>
 __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
                                                            uint64_t* __restrict__ partials)
@@ -315,27 +318,29 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
     lane_init(s);
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
-    // within a step each wave owns a contiguous 8 KiB: vector = wave*512 + u*64 + lane
-    const uint64_t lane_off = static_cast<uint64_t>(wave) * (64 * kUnroll) + lane;
+    // vector of (wave, u, lane) within a step: wave*512 + u*64 + lane, or u*256 + wave*64 + lane
+    constexpr int US = INTERLEAVE ? kThreads : 64;
+    const uint64_t lane_off = INTERLEAVE ? static_cast<uint64_t>(threadIdx.x)
+                                         : static_cast<uint64_t>(wave) * (64 * kUnroll) + lane;
     const uint64_t G = gridDim.x;
     uint32_t blk = 0;
 
     if constexpr (!PREFETCH) {
         for (uint64_t st = blockIdx.x; st < nsteps; st += G) {
             uint4 v[kUnroll];
-            load_step<NT>(v, a0, st, lane_off, lo, hi, fast_begin, fast_end);
+            load_step<NT, US>(v, a0, st, lane_off, lo, hi, fast_begin, fast_end);
             step_and_count(s, v, blk);
         }
     } else {
         uint4 va[kUnroll], vb[kUnroll];
         uint64_t st = blockIdx.x;
-        if (st < nsteps) load_step<NT>(va, a0, st, lane_off, lo, hi, fast_begin, fast_end);
+        if (st < nsteps) load_step<NT, US>(va, a0, st, lane_off, lo, hi, fast_begin, fast_end);
         while (st < nsteps) {
-            if (st + G < nsteps) load_step<NT>(vb, a0, st + G, lane_off, lo, hi, fast_begin, fast_end);
+            if (st + G < nsteps) load_step<NT, US>(vb, a0, st + G, lane_off, lo, hi, fast_begin, fast_end);
             step_and_count(s, va, blk);
             st += G;
             if (st >= nsteps) break;
-            if (st + G < nsteps) load_step<NT>(va, a0, st + G, lane_off, lo, hi, fast_begin, fast_end);
+            if (st + G < nsteps) load_step<NT, US>(va, a0, st + G, lane_off, lo, hi, fast_begin, fast_end);
             step_and_count(s, vb, blk);
             st += G;
         }
@@ -356,7 +361,7 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
         uint64_t sum = 0;
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) sum += red[w][threadIdx.x];
-        partials[static_cast<uint64_t>(blockIdx.x) * kInternal + threadIdx.x] = sum;
+        partials[static_cast<uint64_t>(threadIdx.x) * gridDim.x + blockIdx.x] = sum;  // [counter][block]
     }
 }
 
@@ -385,40 +390,37 @@ __global__ __launch_bounds__(kThreads) void flagstat_read_probe(const uint4* __r
 }
 
 // ------------------------------------------------------------------ K2
-// One workgroup: sum partials[nblocks][19], map to the reference's 32 slots
-// (index = FLAGSTAT_*_OFF, libflagstats.h:69-112; +16 for fail-QC) and ADD into
-// out[32].  Slots the scalar rule never writes get nothing added.
-__global__ __launch_bounds__(kThreads) void flagstat_finalize(const uint64_t* __restrict__ partials, uint32_t nblocks,
-                                                              uint64_t* __restrict__ out)
+// One workgroup of 16 waves: wave w sums column w (and w+16) of partials[19][nblocks]
+// with coalesced 8-byte loads, then 32 threads map the 19 internal counters to the
+// reference's 32 slots (index = FLAGSTAT_*_OFF, libflagstats.h:69-112; +16 for fail-QC)
+// and ADD into out[32].  Slots the scalar rule never writes get nothing added.
+constexpr int kFinalizeThreads = 1024;
+
+__global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint64_t* __restrict__ partials,
+                                                                      uint32_t nblocks, uint64_t* __restrict__ out)
 {
-    __shared__ uint64_t tot[kInternal];
-    __shared__ uint64_t red[kThreads / 64];
+    __shared__ uint64_t tot[32];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    for (int c = 0; c < kInternal; ++c) {
+    for (uint32_t c = wave; c < kInternal; c += kFinalizeThreads / 64) {
         uint64_t x = 0;
-        for (uint32_t b = threadIdx.x; b < nblocks; b += kThreads) x += partials[static_cast<uint64_t>(b) * kInternal + c];
+        for (uint32_t b = lane; b < nblocks; b += 64) x += partials[static_cast<uint64_t>(c) * nblocks + b];
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-        if (lane == 0) red[wave] = x;
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            uint64_t t = 0;
-            for (int w = 0; w < kThreads / 64; ++w) t += red[w];
-            tot[c] = t;
-        }
-        __syncthreads();
+        if (lane == 0) tot[c] = x;
     }
-    if (threadIdx.x == 0) {
-        // internal T/F index -> reference slot
-        const int slot[8] = {8 /*secondary*/, 12 /*n_pair_good*/, 2 /*unmap*/, 11 /*supplementary*/,
-                             13 /*n_sgltn*/, 14 /*n_pair_map*/, 6 /*read1*/, 7 /*read2*/};
-        for (int c = 0; c < 8; ++c) {
-            out[slot[c]] += tot[c] - tot[8 + c];  // pass-QC = all - fail
-            out[16 + slot[c]] += tot[8 + c];
-        }
-        out[10] += tot[17];            // DUP, pass-QC
-        out[26] += tot[18];            // DUP, fail-QC
-        out[25] += tot[16] + tot[18];  // fail-QC read count
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        // reference slot -> internal T index (secondary, n_pair_good, unmap, supplementary,
+        // n_sgltn, n_pair_map, read1, read2), -1 = slot has no T/F counter
+        const int t_of_slot[16] = {-1, -1, 2, -1, -1, -1, 6, 7, 0, -1, -1, 3, 1, 4, 5, -1};
+        const uint32_t slot = threadIdx.x & 15u;
+        const bool fail = threadIdx.x >= 16;
+        uint64_t add = 0;
+        const int t = t_of_slot[slot];
+        if (t >= 0) add = fail ? tot[8 + t] : tot[t] - tot[8 + t];  // pass-QC = all - fail
+        if (slot == 10) add = fail ? tot[18] : tot[17];              // DUP: fail / pass
+        if (slot == 9 && fail) add = tot[16] + tot[18];              // fail-QC read count (slot 25)
+        if (add) out[threadIdx.x] += add;
     }
 }
 
@@ -427,10 +429,10 @@ __global__ __launch_bounds__(kThreads) void flagstat_finalize(const uint64_t* __
 // ------------------------------------------------------------------ launchers
 extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t); }
 
-template <int DEPTH, bool NT, bool PREFETCH>
+template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE>
 static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
+    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials);
     return hipGetLastError();
 }
@@ -459,18 +461,24 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     a.grid = grid;
     a.partials = d_partials;
     hipError_t e;
-    switch (variant) {
-    case 1: e = launch_count_t<8, true, false>(a, stream); break;
-    case 2: e = launch_count_t<7, false, false>(a, stream); break;
-    case 3: e = launch_count_t<7, true, false>(a, stream); break;
-    case 4: e = launch_count_t<8, false, true>(a, stream); break;
-    case 5: e = launch_count_t<8, true, true>(a, stream); break;
-    case 6: e = launch_count_t<7, false, true>(a, stream); break;
-    case 7: e = launch_count_t<7, true, true>(a, stream); break;
-    default: e = launch_count_t<8, false, false>(a, stream); break;
+    // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
+    // 8 = waves interleaved at 1 KiB within a step
+    switch (variant & 15) {
+    case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
+    case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
+    case 2: e = launch_count_t<7, false, false, false>(a, stream); break;
+    case 3: e = launch_count_t<7, true, false, false>(a, stream); break;
+    case 4: e = launch_count_t<8, false, true, false>(a, stream); break;
+    case 5: e = launch_count_t<8, true, true, false>(a, stream); break;
+    case 6: e = launch_count_t<7, false, true, false>(a, stream); break;
+    case 7: e = launch_count_t<7, true, true, false>(a, stream); break;
+    case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
+    case 11: e = launch_count_t<7, true, false, true>(a, stream); break;
+    case 13: e = launch_count_t<8, true, true, true>(a, stream); break;
+    default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kThreads), 0, stream, d_partials, grid, d_out32);
+    hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kFinalizeThreads), 0, stream, d_partials, grid, d_out32);
     return hipGetLastError();
 }
 

@@ -78,6 +78,22 @@ def test_library_exports_every_declared_symbol():
         assert cite in text
 
 
+def test_header_shim_consumer_compiles_and_links(tmp_path):
+    """include/libflagstats.h lets an unmodified consumer of the reference API build against the .so."""
+    import subprocess
+    import torch
+    exe = str(tmp_path / "consumer")
+    libdir = os.path.join(ROOT, "libflagstats_amd")
+    cmd = ["gcc", "-O1", "-std=c11", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "consumer_shim.c"),
+           "-L", libdir, "-lflagstats_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe]
+    subprocess.run(cmd, check=True)
+    r = subprocess.run([exe, "5000"], capture_output=True, text=True)
+    if torch.cuda.is_available():
+        assert r.returncode == 0, r.stdout + r.stderr
+    else:  # no GPU here: the call must fail loudly, not compute
+        assert r.returncode == 3 and "libflagstats_hip" in r.stderr
+
+
 def test_no_gpu_means_loud_failure_not_fallback():
     """Without a GPU the hot path must fail loudly (non-zero + message), never compute on the CPU."""
     import torch
