@@ -102,8 +102,8 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=500)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--flags-per-gpu", type=int, default=2 ** 32, help="default 2^32 flags = 8 GiB uint16")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 27)

@@ -29,7 +29,7 @@ struct Ctx {
     int device = -1;
     int cus = 0;
     uint32_t blocks_per_cu = 0;  // 0 = auto
-    int variant = 9;                     // DEPTH 8, non-temporal loads, waves interleaved at 1 KiB (tools/tune.py)
+    int variant = 25;                    // DEPTH 8, nt loads, interleaved waves, rolling re-issue (tools/tune.py)
     uint64_t chunk_flags = 32ull << 20;  // host streaming chunk: 32 Mi flags = 64 MiB
     hipStream_t stream[2] = {nullptr, nullptr};
     Workspace ws[2];
@@ -75,7 +75,7 @@ uint64_t env_u64(const char* name, uint64_t dflt)
 uint32_t grid_for(uint64_t n)
 {
     (void)n;
-    uint32_t bpc = g.blocks_per_cu ? g.blocks_per_cu : 2;
+    uint32_t bpc = g.blocks_per_cu ? g.blocks_per_cu : 1;
     return (uint32_t)g.cus * bpc;
 }
 
@@ -260,7 +260,7 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         if (value > 16) return fail_msg("blocks_per_cu must be 0 (auto) .. 16");
         g.blocks_per_cu = (uint32_t)value;
     } else if (!std::strcmp(key, "variant")) {
-        if (value > 13) return fail_msg("variant must be 0..13");
+        if (value > 31) return fail_msg("variant must be 0..31");
         g.variant = (int)value;
     } else if (!std::strcmp(key, "chunk_flags")) {
         if (value < 8) return fail_msg("chunk_flags must be >= 8");
@@ -275,7 +275,7 @@ uint64_t FLAGSTATS_hip_get(const char* key)
 {
     std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!key) return 0;
-    if (!std::strcmp(key, "blocks_per_cu")) return g.blocks_per_cu ? g.blocks_per_cu : 2;
+    if (!std::strcmp(key, "blocks_per_cu")) return g.blocks_per_cu ? g.blocks_per_cu : 1;
     if (!std::strcmp(key, "variant")) return (uint64_t)g.variant;
     if (!std::strcmp(key, "chunk_flags")) return g.chunk_flags;
     if (!std::strcmp(key, "grid")) return g.ready ? grid_for(0) : 0;

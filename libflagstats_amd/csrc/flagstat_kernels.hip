@@ -148,9 +148,15 @@ __device__ __forceinline__ void chain_push(Lane<DEPTH>& s, uint32_t blk, uint32_
     }
 }
 
+template <bool NT>
+__device__ __forceinline__ uint4 load_vec(const uint4* __restrict__ p);
+
 // One step: 8 vectors of 16 B per lane = 64 flags -> 16 T, 16 F, 8 S inputs.
-template <int DEPTH>
-__device__ __forceinline__ void step(Lane<DEPTH>& s, const uint4 (&v)[kUnroll], uint32_t blk)
+// ROLL: as soon as vector u has been copied out of its registers, the same registers are
+// re-issued for vector u of the lane's NEXT step (`next`, stride USTRIDE vectors), so a wave
+// keeps ~8 loads in flight through the whole step without a second register buffer.
+template <int DEPTH, bool ROLL, bool NT, int USTRIDE>
+__device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t blk, const uint4* __restrict__ next)
 {
     uint32_t t8a = 0, t8b = 0, f8a = 0, f8b = 0, s4a = 0, s4b = 0;
 #pragma unroll
@@ -162,7 +168,20 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, const uint4 (&v)[kUnroll], 
             uint32_t T[4], F[4], S[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                const uint4 x = v[half * 4 + q * 2 + k];
+                uint4 x = v[half * 4 + q * 2 + k];
+                if constexpr (ROLL) {
+                    // Copy the vector out with real v_movs HERE (a load may land at any time, so the
+                    // registers it targets must be dead first), then re-issue into the same registers.
+                    // The asm keeps hipcc from turning the copies into loop-top PHI moves (which wait
+                    // for all 8 loads), the sched_barriers from sinking the loads below the arithmetic.
+                    const uint4 o = x;
+                    __builtin_amdgcn_sched_barrier(0);
+                    asm volatile("v_mov_b32 %0, %4\n\tv_mov_b32 %1, %5\n\tv_mov_b32 %2, %6\n\tv_mov_b32 %3, %7"
+                                 : "=&v"(x.x), "=&v"(x.y), "=&v"(x.z), "=&v"(x.w)
+                                 : "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w));
+                    v[half * 4 + q * 2 + k] = load_vec<NT>(next + (half * 4 + q * 2 + k) * USTRIDE);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
                 uint32_t qa, qb;
                 front4(x.x, x.y, T[2 * k], qa);
                 front4(x.z, x.w, T[2 * k + 1], qb);
@@ -294,10 +313,11 @@ __device__ __forceinline__ void load_step(uint4 (&v)[kUnroll], const uint4* __re
     }
 }
 
-template <int DEPTH>
-__device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, const uint4 (&v)[kUnroll], uint32_t& blk)
+template <int DEPTH, bool ROLL = false, bool NT = false, int USTRIDE = 64>
+__device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t& blk,
+                                               const uint4* __restrict__ next = nullptr)
 {
-    step(s, v, blk);
+    step<DEPTH, ROLL, NT, USTRIDE>(s, v, blk, next);
     ++blk;
     if (blk == (1u << DEPTH) - 1u) {
         flush(s);
@@ -309,7 +329,7 @@ __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, const uint4 (&v)[
 // waves of the SIMD only.  PREFETCH = true: two register buffers, the loads of
 // step k+1 are in flight while step k is computed (one more 8 KiB per wave in
 // flight, +32 VGPRs).
-template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE>
+template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, bool ROLL>
 __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
                                                            uint64_t* __restrict__ partials)
@@ -325,7 +345,38 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
     const uint64_t G = gridDim.x;
     uint32_t blk = 0;
 
-    if constexpr (!PREFETCH) {
+    if constexpr (ROLL) {
+        // ragged edge steps (at most the first and the last of the whole array) go through the
+        // guarded loader, outside the pipelined loop
+        if (fast_begin != 0 && blockIdx.x == 0) {
+            uint4 v[kUnroll];
+            load_step<NT, US>(v, a0, 0, lane_off, lo, hi, fast_begin, fast_end);
+            step_and_count(s, v, blk);
+        }
+        if (nsteps > fast_end && nsteps - 1 >= fast_begin && (nsteps - 1) % G == blockIdx.x) {
+            uint4 v[kUnroll];
+            load_step<NT, US>(v, a0, nsteps - 1, lane_off, lo, hi, fast_begin, fast_end);
+            step_and_count(s, v, blk);
+        }
+        // first fully in-range step of this workgroup
+        uint64_t st = blockIdx.x;
+        if (st < fast_begin) st += G;  // fast_begin is 0 or 1
+        if (st < fast_end) {
+            uint4 v[kUnroll];
+            const uint4* p = a0 + st * kVecPerStep + lane_off;
+            // issue order = consumption order, so the loop-top wait can be vmcnt(7), not vmcnt(0)
+#pragma unroll
+            for (int u = 0; u < kUnroll; ++u) {
+                v[u] = load_vec<NT>(p + u * US);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            for (; st + G < fast_end; st += G) {
+                p += G * kVecPerStep;
+                step_and_count<DEPTH, true, NT, US>(s, v, blk, p);
+            }
+            step_and_count(s, v, blk);
+        }
+    } else if constexpr (!PREFETCH) {
         for (uint64_t st = blockIdx.x; st < nsteps; st += G) {
             uint4 v[kUnroll];
             load_step<NT, US>(v, a0, st, lane_off, lo, hi, fast_begin, fast_end);
@@ -429,10 +480,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
 // ------------------------------------------------------------------ launchers
 extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t); }
 
-template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE>
+template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, bool ROLL = false>
 static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
+    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, ROLL>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials);
     return hipGetLastError();
 }
@@ -462,8 +513,8 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     a.partials = d_partials;
     hipError_t e;
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
-    // 8 = waves interleaved at 1 KiB within a step
-    switch (variant & 15) {
+    // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers
+    switch (variant & 31) {
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
     case 2: e = launch_count_t<7, false, false, false>(a, stream); break;
@@ -475,6 +526,9 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
     case 11: e = launch_count_t<7, true, false, true>(a, stream); break;
     case 13: e = launch_count_t<8, true, true, true>(a, stream); break;
+    case 17: e = launch_count_t<8, true, false, false, true>(a, stream); break;
+    case 25: e = launch_count_t<8, true, false, true, true>(a, stream); break;
+    case 27: e = launch_count_t<7, true, false, true, true>(a, stream); break;
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
