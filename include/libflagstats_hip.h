@@ -98,6 +98,26 @@ int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t
 int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmup, int reps, float* ms_total,
                                   uint64_t* out);
 
+/* ---- block files: the reference's `bench decompress -d` / `-D` callers ----
+ * File format written by benchmark/flagstats.cpp:119-138 and read at :311-316: a sequence of
+ *   int32 uncompressed_size, int32 compressed_size, <raw LZ4 block>   (little-endian; not LZ4 frames).
+ * The LZ4 path decodes blocks on `threads` host threads (<= 0: up to 24) into pinned chunk buffers,
+ * overlapped with the H2D copy and K1/K2 of earlier chunks; out[32] += counters of every flag
+ * (a block contributes uncompressed_size >> 1 flags, as benchmark/flagstats.cpp:323). */
+typedef struct FLAGSTATS_blockfile_stats {
+    uint64_t n_flags, n_blocks, compressed_bytes, uncompressed_bytes;
+    double wall_s, index_s, setup_s, decode_cpu_s; /* setup_s: index + buffers; decode_cpu_s: sum over threads */
+    int32_t threads, chunks;
+} FLAGSTATS_blockfile_stats;
+int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
+int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads, uint64_t* out,
+                                 FLAGSTATS_blockfile_stats* stats); /* same, file already in memory */
+/* raw uint16 file (benchmark/flagstats.cpp:415-468, `-D`): mmap + FLAGSTATS_u16_x64 */
+int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
+/* the host LZ4 *block* decoder used above (replaces the reference's call to liblz4's
+ * LZ4_decompress_safe, benchmark/flagstats.cpp:316): returns decoded bytes, < 0 on malformed input */
+int64_t FLAGSTATS_lz4_block_decode(const void* src, uint64_t srclen, void* dst, uint64_t dstcap);
+
 /* read-only bandwidth probe with K1's load pattern and no flagstat arithmetic
  * (the analogue of the reference's memcpy baseline, linux/instrumented_benchmark.cpp:456-544):
  * `reps` sweeps of d_buf[0..bytes) (16-B aligned) between two hipEvents; nt = non-temporal loads. */

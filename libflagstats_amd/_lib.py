@@ -17,6 +17,13 @@ _U32P = ctypes.POINTER(ctypes.c_uint32)
 _U64P = ctypes.POINTER(ctypes.c_uint64)
 FLAGSTATS_func = ctypes.CFUNCTYPE(ctypes.c_int, _U16P, ctypes.c_uint32, _U32P)
 
+class BlockfileStats(ctypes.Structure):
+    """FLAGSTATS_blockfile_stats of include/libflagstats_hip.h."""
+    _fields_ = [("n_flags", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("compressed_bytes", ctypes.c_uint64),
+                ("uncompressed_bytes", ctypes.c_uint64), ("wall_s", ctypes.c_double), ("index_s", ctypes.c_double),
+                ("setup_s", ctypes.c_double), ("decode_cpu_s", ctypes.c_double), ("threads", ctypes.c_int32), ("chunks", ctypes.c_int32)]
+
+
 # name -> (restype, argtypes); mirrors include/libflagstats_hip.h one to one
 SIGNATURES = {
     "FLAGSTATS_u16": (ctypes.c_uint64, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
@@ -44,6 +51,12 @@ SIGNATURES = {
                                                   ctypes.c_uint32, ctypes.c_uint64, ctypes.c_void_p]),
     "FLAGSTATS_hip_time_device_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                                      ctypes.POINTER(ctypes.c_float), ctypes.c_void_p]),
+    "FLAGSTATS_hip_blockfile_lz4": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p,
+                                                   ctypes.POINTER(BlockfileStats)]),
+    "FLAGSTATS_hip_blockimage_lz4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
+                                                    ctypes.POINTER(BlockfileStats)]),
+    "FLAGSTATS_hip_file_raw": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
+    "FLAGSTATS_lz4_block_decode": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]),
     "FLAGSTATS_hip_read_probe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
 }

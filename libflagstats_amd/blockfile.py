@@ -1,0 +1,50 @@
+"""Block files of the reference's bench programs, counted on the MI355X engine (row f1).
+
+``flagstat_lz4_file`` is the counterpart of ``bench decompress -i X.lz4 -d``
+(``benchmark/flagstats.cpp:288-358``): threaded host LZ4 block decode overlapped with the H2D
+copy and K1/K2.  ``flagstat_raw_file`` is ``-D`` (``:415-468``).  Both return
+``(uint64[32] counters, stats dict)``.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+
+def _stats(st: _lib.BlockfileStats) -> dict:
+    return {name: getattr(st, name) for name, _ in st._fields_}
+
+
+def flagstat_lz4_file(path: str, threads: int = 0):
+    out = np.zeros(32, dtype=np.uint64)
+    st = _lib.BlockfileStats()
+    _lib.check(_lib.lib().FLAGSTATS_hip_blockfile_lz4(str(path).encode(), threads, out.ctypes.data, ctypes.byref(st)),
+               "FLAGSTATS_hip_blockfile_lz4")
+    return out, _stats(st)
+
+
+def flagstat_lz4_image(image: bytes, threads: int = 0):
+    out = np.zeros(32, dtype=np.uint64)
+    st = _lib.BlockfileStats()
+    buf = (ctypes.c_char * len(image)).from_buffer_copy(image) if image else None
+    _lib.check(_lib.lib().FLAGSTATS_hip_blockimage_lz4(buf, len(image), threads, out.ctypes.data, ctypes.byref(st)),
+               "FLAGSTATS_hip_blockimage_lz4")
+    return out, _stats(st)
+
+
+def flagstat_raw_file(path: str):
+    out = np.zeros(32, dtype=np.uint64)
+    st = _lib.BlockfileStats()
+    _lib.check(_lib.lib().FLAGSTATS_hip_file_raw(str(path).encode(), out.ctypes.data, ctypes.byref(st)),
+               "FLAGSTATS_hip_file_raw")
+    return out, _stats(st)
+
+
+def lz4_block_decode(src: bytes, dstcap: int):
+    """The product's host LZ4 block decoder; returns bytes or None on malformed input."""
+    dst = ctypes.create_string_buffer(max(dstcap, 1))
+    n = _lib.lib().FLAGSTATS_lz4_block_decode(src, len(src), dst, dstcap)
+    return None if n < 0 else dst.raw[:n]

@@ -1,0 +1,433 @@
+// flagstat_blocks.hip -- SURVEY.md section 8 row f1: the caller-side step BEFORE the hot path.
+//
+// Reads the reference's block files and feeds the decoded FLAG stream to K1/K2:
+//   * format (benchmark/flagstats.cpp:119-138 writer, :288-332 reader): a sequence of
+//       int32 uncompressed_size, int32 compressed_size, <raw LZ4 block>      (native little-endian)
+//     -- NOT the LZ4 frame format.  The reference writes 1,024,000-byte blocks
+//     (512,000 flags) and, when the input size is a multiple of that, a trailing empty block.
+//   * reference pipeline (:311-332): read -> LZ4_decompress_safe -> FLAGSTATS_get_function(N)(...)
+//     strictly serially, one thread, ~80 % of the time in I/O + decode (README.md:27-29).
+//   * here: index pass over the headers, then N host threads decode blocks straight into their
+//     final place of a pinned chunk buffer (block sizes are known from the headers, so there is
+//     no ordering between threads), while the previous chunk is on its way over PCIe
+//     (hipMemcpyAsync) and the one before is being counted by K1/K2.  3 pinned chunk buffers,
+//     2 device buffers, 2 streams.
+//
+// LZ4 itself is a third-party dependency of the reference's bench (liblz4, found at build time
+// via LZ4_PATH, Makefile:28-39; not vendored).  The decoder below is written from the published
+// LZ4 *block* format (token = 4 bits literal length | 4 bits match length - 4, 255-continued
+// length bytes, 2-byte little-endian offset, last sequence literals-only) and is checked in
+// tests/ against the image's liblz4.so.1 (1.9.3) acting as oracle.
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../../include/libflagstats_hip.h"
+#include "flagstat_ctx.h"
+
+namespace {
+
+// ---------------------------------------------------------------- LZ4 block decoder (safe)
+// Returns decoded byte count, or -1 on malformed input / output overflow.  Never reads outside
+// [src, src+n) nor writes outside [dst, dst+cap).
+int64_t lz4_block_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap)
+{
+    const uint8_t* ip = src;
+    const uint8_t* const iend = src + n;
+    uint8_t* op = dst;
+    uint8_t* const oend = dst + cap;
+    if (n == 0) return -1;
+    for (;;) {
+        if (ip >= iend) return -1;
+        const unsigned token = *ip++;
+        size_t lit = token >> 4;
+        // Shortcut for the common sequence (<= 14 literals, match of <= 18 bytes at distance >= 8)
+        // while far from both buffer ends: fixed-size copies, one bounds check.  With >= 18 input
+        // bytes left and <= 14 literals this cannot be the literals-only last sequence.
+        if (lit < 15 && static_cast<size_t>(iend - ip) >= 18 && static_cast<size_t>(oend - op) >= 36) {
+            std::memcpy(op, ip, 16);
+            ip += lit;
+            op += lit;
+            const size_t soff = static_cast<size_t>(ip[0]) | (static_cast<size_t>(ip[1]) << 8);
+            const size_t sml = token & 15u;
+            if (sml < 15 && soff >= 8 && soff <= static_cast<size_t>(op - dst)) {
+                const uint8_t* m = op - soff;
+                std::memcpy(op, m, 8);
+                std::memcpy(op + 8, m + 8, 8);
+                std::memcpy(op + 16, m + 16, 2);
+                ip += 2;
+                op += sml + 4;
+                continue;
+            }
+            // not a shortcut match: undo and take the general path below
+            ip -= lit;
+            op -= lit;
+        }
+        if (lit == 15) {
+            unsigned b;
+            do {
+                if (ip >= iend) return -1;
+                b = *ip++;
+                lit += b;
+            } while (b == 255);
+        }
+        if (lit > static_cast<size_t>(iend - ip) || lit > static_cast<size_t>(oend - op)) return -1;
+        if (lit <= 32 && static_cast<size_t>(iend - ip) >= 32 && static_cast<size_t>(oend - op) >= 32) {
+            std::memcpy(op, ip, 32);  // short literal run: one fixed-size copy, tail bytes are overwritten later
+        } else {
+            std::memcpy(op, ip, lit);
+        }
+        ip += lit;
+        op += lit;
+        if (ip == iend) break;  // last sequence carries literals only
+        if (iend - ip < 2) return -1;
+        const size_t off = static_cast<size_t>(ip[0]) | (static_cast<size_t>(ip[1]) << 8);
+        ip += 2;
+        if (off == 0 || off > static_cast<size_t>(op - dst)) return -1;
+        size_t ml = token & 15u;
+        if (ml == 15) {
+            unsigned b;
+            do {
+                if (ip >= iend) return -1;
+                b = *ip++;
+                ml += b;
+            } while (b == 255);
+        }
+        ml += 4;
+        if (ml > static_cast<size_t>(oend - op)) return -1;
+        const uint8_t* m = op - off;
+        if (off >= 16 && static_cast<size_t>(oend - op) >= ml + 16) {
+            // non-overlapping at 16-byte granularity: wild copy in 16-byte steps
+            uint8_t* d = op;
+            const uint8_t* const dend = op + ml;
+            do {
+                std::memcpy(d, m, 16);
+                d += 16;
+                m += 16;
+            } while (d < dend);
+        } else if (off >= ml) {
+            std::memcpy(op, m, ml);
+        } else {
+            for (size_t i = 0; i < ml; ++i) op[i] = m[i];  // overlapping run (RLE-like)
+        }
+        op += ml;
+    }
+    return op - dst;
+}
+
+struct BlockRef {
+    const uint8_t* src;
+    uint32_t csize, usize;
+    uint64_t dst_off;  // byte offset inside its chunk buffer (16-byte aligned)
+    uint32_t chunk;
+};
+
+struct ChunkRef {
+    size_t b0, b1;      // blocks [b0, b1)
+    uint64_t bytes;     // padded bytes used in the chunk buffer (multiple of 16)
+};
+
+double now_s()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+// Parse the block headers of a file image.  Every block's decoded bytes get a 16-byte aligned
+// slot in a chunk buffer; the gap up to the next slot is zero-filled, and a zero flag counts
+// nothing, so a whole chunk is counted as ONE array.
+int index_blocks(const uint8_t* img, uint64_t bytes, uint64_t chunk_cap, std::vector<BlockRef>& blocks,
+                 std::vector<ChunkRef>& chunks, uint64_t& uncompressed)
+{
+    uint64_t pos = 0;
+    uncompressed = 0;
+    ChunkRef cur{0, 0, 0};
+    while (pos < bytes) {
+        if (bytes - pos < 8) return fsint::fail_text("block file: truncated block header");
+        int32_t us, cs;
+        std::memcpy(&us, img + pos, 4);
+        std::memcpy(&cs, img + pos + 4, 4);
+        pos += 8;
+        if (us < 0 || cs < 0) return fsint::fail_text("block file: negative size in block header");
+        if (static_cast<uint64_t>(cs) > bytes - pos) return fsint::fail_text("block file: block payload runs past end of file");
+        const uint64_t padded = (static_cast<uint64_t>(us) + 15) & ~15ull;
+        if (padded > chunk_cap) return fsint::fail_text("block file: block larger than the chunk buffer");
+        if (cur.bytes + padded > chunk_cap) {
+            cur.b1 = blocks.size();
+            chunks.push_back(cur);
+            cur = ChunkRef{blocks.size(), 0, 0};
+        }
+        blocks.push_back(BlockRef{img + pos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us), cur.bytes,
+                                  static_cast<uint32_t>(chunks.size())});
+        cur.bytes += padded;
+        uncompressed += static_cast<uint64_t>(us);
+        pos += static_cast<uint64_t>(cs);
+    }
+    cur.b1 = blocks.size();
+    if (cur.b1 > cur.b0) chunks.push_back(cur);
+    return 0;
+}
+
+struct Pipe {
+    std::mutex m;
+    std::condition_variable cv;
+    size_t released = 0;                 // chunks [0, released) may be decoded
+    std::vector<size_t> done;            // blocks decoded per chunk
+    std::vector<std::atomic<size_t>> next;  // next block to grab per chunk
+    bool failed = false;
+    double decode_cpu_s = 0;
+    explicit Pipe(size_t nchunks) : done(nchunks, 0), next(nchunks) {}
+};
+
+constexpr int kPinned = 3;
+
+int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* st)
+{
+    const double t0 = now_s();
+    uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
+    if (chunk_cap < (4ull << 20)) chunk_cap = 4ull << 20;
+    std::vector<BlockRef> blocks;
+    std::vector<ChunkRef> chunks;
+    uint64_t uncompressed = 0;
+    int rc = index_blocks(img, bytes, chunk_cap, blocks, chunks, uncompressed);
+    if (rc) return rc;
+    const double t_index = now_s() - t0;
+    uint64_t n_flags = 0;
+    for (const BlockRef& b : blocks) n_flags += b.usize >> 1;  // as benchmark/flagstats.cpp:323
+    if (threads <= 0) {
+        threads = static_cast<int>(std::thread::hardware_concurrency());
+        if (threads > 24) threads = 24;  // measured optimum on 2x EPYC 9575F; more threads contend (profiles/r01)
+        if (threads < 1) threads = 1;
+    }
+    if (static_cast<size_t>(threads) > blocks.size() && !blocks.empty()) threads = static_cast<int>(blocks.size());
+
+    std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
+    rc = fsint::bind_ctx();
+    if (rc) return rc;
+    if (!chunks.empty()) {
+        rc = fsint::stage_reserve(chunk_cap / 2);
+        if (rc) return rc;
+    }
+    uint8_t* pinned[kPinned] = {nullptr, nullptr, nullptr};
+    hipEvent_t copied[kPinned];
+    const int npin = chunks.size() < static_cast<size_t>(kPinned) ? static_cast<int>(chunks.size()) : kPinned;
+    if (npin) {
+        void* bufs[3];
+        rc = fsint::pinned_reserve(chunk_cap, bufs);  // allocated once per process: hipHostMalloc costs ~10 ms / 64 MiB
+        if (rc) return rc;
+        for (int i = 0; i < kPinned; ++i) pinned[i] = static_cast<uint8_t*>(bufs[i]);
+    }
+    for (int i = 0; i < npin; ++i) {
+        hipError_t e = hipEventCreateWithFlags(&copied[i], hipEventDisableTiming);
+        if (e != hipSuccess) return fsint::fail_hip("hipEventCreate", e);
+    }
+    const double t_setup = now_s() - t0;
+    for (int s = 0; s < 2; ++s) {
+        hipError_t e = hipMemsetAsync(fsint::dev_out(s), 0, 32 * sizeof(uint64_t), fsint::stream(s));
+        if (e != hipSuccess) return fsint::fail_hip("hipMemsetAsync", e);
+    }
+
+    Pipe pipe(chunks.size());
+    for (auto& a : pipe.next) a.store(0);
+    auto worker = [&]() {
+        double busy = 0;
+        for (size_t c = 0; c < chunks.size(); ++c) {
+            {
+                std::unique_lock<std::mutex> ul(pipe.m);
+                pipe.cv.wait(ul, [&] { return pipe.released > c || pipe.failed; });
+                if (pipe.failed) break;
+            }
+            uint8_t* base = pinned[c % kPinned];
+            size_t mine = 0;
+            bool bad = false;
+            const double w0 = now_s();
+            for (;;) {
+                const size_t b = chunks[c].b0 + pipe.next[c].fetch_add(1);
+                if (b >= chunks[c].b1) break;
+                const BlockRef& br = blocks[b];
+                uint8_t* dst = base + br.dst_off;
+                const uint64_t padded = (static_cast<uint64_t>(br.usize) + 15) & ~15ull;
+                const int64_t got = lz4_block_decode(br.src, br.csize, dst, br.usize);
+                if (got != static_cast<int64_t>(br.usize)) {
+                    bad = true;
+                    break;
+                }
+                // an odd trailing byte is dropped like the reference's N = size >> 1; pad with zero flags
+                uint64_t keep = br.usize & ~1ull;
+                std::memset(dst + keep, 0, padded - keep);
+                ++mine;
+            }
+            busy += now_s() - w0;
+            std::lock_guard<std::mutex> g(pipe.m);
+            pipe.done[c] += mine;
+            if (bad) pipe.failed = true;
+            pipe.cv.notify_all();
+            if (bad) break;
+        }
+        std::lock_guard<std::mutex> g(pipe.m);
+        pipe.decode_cpu_s += busy;
+    };
+    std::vector<std::thread> pool;
+    for (int t = 0; t < threads && !chunks.empty(); ++t) pool.emplace_back(worker);
+
+    auto release = [&](size_t upto) {
+        std::lock_guard<std::mutex> g(pipe.m);
+        if (upto > pipe.released) pipe.released = upto;
+        pipe.cv.notify_all();
+    };
+    release(static_cast<size_t>(npin));
+    int err = 0;
+    for (size_t c = 0; c < chunks.size() && !err; ++c) {
+        {
+            std::unique_lock<std::mutex> ul(pipe.m);
+            pipe.cv.wait(ul, [&] { return pipe.done[c] == chunks[c].b1 - chunks[c].b0 || pipe.failed; });
+            if (pipe.failed) {
+                err = fsint::fail_text("block file: LZ4 block failed to decode to its declared size");
+                break;
+            }
+        }
+        const int sl = static_cast<int>(c & 1);
+        const int pb = static_cast<int>(c % kPinned);
+        hipError_t e = hipMemcpyAsync(fsint::stage_buf(sl), pinned[pb], chunks[c].bytes, hipMemcpyHostToDevice, fsint::stream(sl));
+        if (e == hipSuccess) e = hipEventRecord(copied[pb], fsint::stream(sl));
+        if (e != hipSuccess) {
+            err = fsint::fail_hip("hipMemcpyAsync(chunk)", e);
+            break;
+        }
+        err = fsint::count_async(fsint::stage_buf(sl), chunks[c].bytes / 2, sl);
+        if (err) break;
+        if (c + kPinned < chunks.size()) {
+            // the pinned buffer of chunk c is reusable once its copy has left the host
+            e = hipEventSynchronize(copied[pb]);
+            if (e != hipSuccess) {
+                err = fsint::fail_hip("hipEventSynchronize", e);
+                break;
+            }
+            release(c + kPinned + 1);
+        }
+    }
+    if (err) {
+        std::lock_guard<std::mutex> g(pipe.m);
+        pipe.failed = true;
+        pipe.cv.notify_all();
+    }
+    for (auto& t : pool) t.join();
+    if (!err) {
+        for (int s = 0; s < 2 && !err; ++s) {
+            hipError_t e = hipMemcpyAsync(fsint::host_out() + 32 * s, fsint::dev_out(s), 32 * sizeof(uint64_t),
+                                          hipMemcpyDeviceToHost, fsint::stream(s));
+            if (e != hipSuccess) err = fsint::fail_hip("hipMemcpyAsync(counters)", e);
+        }
+    }
+    for (int s = 0; s < 2; ++s) {
+        hipError_t e = hipStreamSynchronize(fsint::stream(s));
+        if (e != hipSuccess && !err) err = fsint::fail_hip("hipStreamSynchronize", e);
+    }
+    for (int i = 0; i < npin; ++i) (void)hipEventDestroy(copied[i]);
+    if (err) return err;
+    for (int s = 0; s < 2; ++s)
+        for (int k = 0; k < 32; ++k) out[k] += fsint::host_out()[32 * s + k];
+    if (st) {
+        st->n_flags = n_flags;
+        st->n_blocks = blocks.size();
+        st->compressed_bytes = bytes;
+        st->uncompressed_bytes = uncompressed;
+        st->wall_s = now_s() - t0;
+        st->index_s = t_index;
+        st->setup_s = t_setup;
+        st->decode_cpu_s = pipe.decode_cpu_s;
+        st->threads = threads;
+        st->chunks = static_cast<int32_t>(chunks.size());
+    }
+    return 0;
+}
+
+struct Mapped {
+    const uint8_t* p = nullptr;
+    uint64_t bytes = 0;
+    int fd = -1;
+    ~Mapped()
+    {
+        if (p && bytes) munmap(const_cast<uint8_t*>(p), bytes);
+        if (fd >= 0) close(fd);
+    }
+};
+
+int map_file(const char* path, Mapped& m)
+{
+    if (!path) return fsint::fail_text("NULL path");
+    m.fd = open(path, O_RDONLY);
+    if (m.fd < 0) return fsint::fail_text("cannot open file");
+    struct stat sb;
+    if (fstat(m.fd, &sb) != 0) return fsint::fail_text("cannot stat file");
+    m.bytes = static_cast<uint64_t>(sb.st_size);
+    if (m.bytes == 0) return 0;
+    void* p = mmap(nullptr, m.bytes, PROT_READ, MAP_PRIVATE, m.fd, 0);
+    if (p == MAP_FAILED) {
+        m.bytes = 0;
+        return fsint::fail_text("cannot mmap file");
+    }
+    (void)madvise(p, m.bytes, MADV_SEQUENTIAL);
+    m.p = static_cast<const uint8_t*>(p);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t FLAGSTATS_lz4_block_decode(const void* src, uint64_t srclen, void* dst, uint64_t dstcap)
+{
+    if (!src || (!dst && dstcap)) return -1;
+    return lz4_block_decode(static_cast<const uint8_t*>(src), srclen, static_cast<uint8_t*>(dst), dstcap);
+}
+
+int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads, uint64_t* out,
+                                 FLAGSTATS_blockfile_stats* stats)
+{
+    if (!out) return fsint::fail_text("NULL out");
+    if (!image && bytes) return fsint::fail_text("NULL image");
+    return run_pipeline(static_cast<const uint8_t*>(image), bytes, threads, out, stats);
+}
+
+int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    if (!out) return fsint::fail_text("NULL out");
+    Mapped m;
+    int rc = map_file(path, m);
+    if (rc) return rc;
+    return run_pipeline(m.p, m.bytes, threads, out, stats);
+}
+
+int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    if (!out) return fsint::fail_text("NULL out");
+    const double t0 = now_s();
+    Mapped m;
+    int rc = map_file(path, m);
+    if (rc) return rc;
+    const uint64_t n = m.bytes / 2;  // a trailing odd byte is dropped, as `read >> 1` at benchmark/flagstats.cpp:450
+    {
+        std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
+        rc = fsint::bind_ctx();
+        if (rc) return rc;
+        rc = fsint::count_host_array(reinterpret_cast<const uint16_t*>(m.p), n, out);
+        if (rc) return rc;
+    }
+    if (stats) {
+        std::memset(stats, 0, sizeof *stats);
+        stats->n_flags = n;
+        stats->compressed_bytes = stats->uncompressed_bytes = m.bytes;
+        stats->wall_s = now_s() - t0;
+    }
+    return 0;
+}
+
+}  // extern "C"

@@ -38,6 +38,8 @@ struct Ctx {
     uint64_t stage_flags = 0;
     uint64_t* h_out = nullptr;                 // pinned 2 x 32
     std::map<void*, Workspace> user_ws;        // workspaces for caller-owned streams
+    void* pinned[3] = {nullptr, nullptr, nullptr};  // block-file chunk buffers (flagstat_blocks.hip), kept across calls
+    uint64_t pinned_bytes = 0;
 };
 
 Ctx g;
@@ -194,6 +196,40 @@ int count_host(const uint16_t* h, uint64_t n, uint64_t out[32])
 
 }  // namespace
 
+// internal surface for flagstat_blocks.hip (block-file pipeline), declared in flagstat_ctx.h
+namespace fsint {
+std::recursive_mutex& mutex() { return g_mu; }
+int bind_ctx() { return bind(); }
+int fail_text(const char* msg) { return fail_msg(msg); }
+int fail_hip(const char* what, hipError_t e) { return fail(what, e); }
+int stage_reserve(uint64_t flags) { return ensure_stage(flags); }
+uint16_t* stage_buf(int slot) { return g.stage[slot]; }
+hipStream_t stream(int slot) { return g.stream[slot]; }
+uint64_t* dev_out(int slot) { return g.d_out[slot]; }
+uint64_t* host_out() { return g.h_out; }
+int count_async(const uint16_t* d, uint64_t n, int slot) { return count_device_async(d, n, g.d_out[slot], g.stream[slot], g.ws[slot]); }
+int count_host_array(const uint16_t* h, uint64_t n, uint64_t* out) { return count_host(h, n, out); }
+uint64_t chunk_bytes() { return g.chunk_flags * 2; }
+// three pinned host buffers of >= bytes each, allocated once and reused by later calls
+int pinned_reserve(uint64_t bytes, void* bufs[3])
+{
+    if (g.pinned_bytes < bytes) {
+        for (int i = 0; i < 3; ++i) {
+            if (g.pinned[i]) (void)hipHostFree(g.pinned[i]);
+            g.pinned[i] = nullptr;
+        }
+        g.pinned_bytes = 0;
+        for (int i = 0; i < 3; ++i) {
+            hipError_t e = hipHostMalloc(&g.pinned[i], bytes, hipHostMallocDefault);
+            if (e != hipSuccess) return fail("hipHostMalloc(chunk buffer)", e);
+        }
+        g.pinned_bytes = bytes;
+    }
+    for (int i = 0; i < 3; ++i) bufs[i] = g.pinned[i];
+    return 0;
+}
+}  // namespace fsint
+
 extern "C" {
 
 int FLAGSTATS_hip_available(void)
@@ -229,6 +265,8 @@ void FLAGSTATS_hip_shutdown(void)
     for (auto& kv : g.user_ws)
         if (kv.second.partials) (void)hipFree(kv.second.partials);
     if (g.h_out) (void)hipHostFree(g.h_out);
+    for (int i = 0; i < 3; ++i)
+        if (g.pinned[i]) (void)hipHostFree(g.pinned[i]);
     const uint32_t bpc = g.blocks_per_cu;
     const int variant = g.variant;
     const uint64_t chunk = g.chunk_flags;

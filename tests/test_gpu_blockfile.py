@@ -1,0 +1,97 @@
+"""GPU: block-file reader + threaded LZ4 decode pipeline (row f1) vs the oracle on the raw flags.
+Files are produced by the real liblz4 in the reference's block format (tools/blockfile_tool.py)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import blockfile_tool as bt  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def expect(flags, block_bytes):
+    """Reference semantics (benchmark/flagstats.cpp:323): each block contributes size >> 1 flags."""
+    import oracle
+    raw = np.ascontiguousarray(flags, dtype=np.uint16).tobytes()
+    out = np.zeros(32, dtype=np.uint64)
+    n = 0
+    for pos in range(0, len(raw), block_bytes):
+        chunk = raw[pos:pos + block_bytes]
+        k = len(chunk) >> 1
+        out += oracle.flagstat_hist(np.frombuffer(chunk[:2 * k], dtype=np.uint16))
+        n += k
+    return out, n
+
+
+@pytest.mark.parametrize("case", ["na_ragged", "exact_multiple", "uniform_incompressible", "hc9", "tiny_odd_blocks",
+                                  "three_chunks"])
+def test_lz4_block_files(hip, tmp_path, case):
+    import oracle
+    from libflagstats_amd import blockfile
+    kw = dict(block_bytes=bt.BLOCK_BYTES, mode="fast", level=2)
+    if case == "na_ragged":
+        flags = oracle.generate(oracle.GEN_NA12878, 1, 1, 0, 512000 * 3 + 12345)
+    elif case == "exact_multiple":      # reference writer appends an empty block here
+        flags = oracle.generate(oracle.GEN_NA12878, 2, 0, 0, 512000 * 2)
+    elif case == "uniform_incompressible":
+        flags = oracle.generate(oracle.GEN_UNIFORM, 3, 0xFFFF, 0, 512000 * 2 + 77)
+    elif case == "hc9":
+        flags = oracle.generate(oracle.GEN_NA12878, 4, 1, 0, 512000 + 999)
+        kw.update(mode="hc", level=9)
+    elif case == "tiny_odd_blocks":     # odd block size: the last byte of every block is dropped (N = size >> 1)
+        flags = oracle.generate(oracle.GEN_UNIFORM, 5, 0x0FFF, 0, 200000)
+        kw.update(block_bytes=9999)
+    else:                               # > 2 chunk buffers of 64 MiB: exercises buffer recycling
+        flags = oracle.generate(oracle.GEN_NA12878, 6, 1, 0, 512000 * 150 + 5)
+    path = tmp_path / (case + ".lz4")
+    size = bt.write_block_file(path, flags, **kw)
+    want, n = expect(flags, kw["block_bytes"])
+    for threads in (1, 3, 0):
+        got, st = blockfile.flagstat_lz4_file(str(path), threads)
+        assert np.array_equal(got, want), (case, threads)
+        assert st["n_flags"] == n and st["compressed_bytes"] == size
+    img = open(path, "rb").read()
+    got, st = blockfile.flagstat_lz4_image(img, 2)
+    assert np.array_equal(got, want)
+    if case == "exact_multiple":
+        assert st["n_blocks"] == 3      # 2 data blocks + the reference writer's trailing empty block
+    if case == "three_chunks":
+        assert st["chunks"] >= 3
+
+
+def test_empty_and_damaged_files(hip, tmp_path):
+    import oracle
+    from libflagstats_amd import _lib, blockfile
+    p = tmp_path / "empty.lz4"
+    p.write_bytes(b"")
+    got, st = blockfile.flagstat_lz4_file(str(p), 2)
+    assert not got.any() and st["n_blocks"] == 0
+    flags = oracle.generate(oracle.GEN_NA12878, 8, 1, 0, 512000 + 100)
+    img = bt.block_file_image(flags)
+    for cut in (3, 8 + 10, len(img) - 1):          # truncated header / payload / last byte
+        with pytest.raises(_lib.FlagstatsHipError):
+            blockfile.flagstat_lz4_image(img[:cut], 2)
+    bad = bytearray(img)
+    bad[0:4] = (512000 * 2 + 1000).to_bytes(4, "little")   # header claims more bytes than the block holds
+    with pytest.raises(_lib.FlagstatsHipError):
+        blockfile.flagstat_lz4_image(bytes(bad), 2)
+    with pytest.raises(_lib.FlagstatsHipError):
+        blockfile.flagstat_lz4_file(str(tmp_path / "missing.lz4"), 1)
+    # the library is still usable after failures
+    got, _ = blockfile.flagstat_lz4_image(img, 2)
+    assert np.array_equal(got, expect(flags, bt.BLOCK_BYTES)[0])
+
+
+def test_raw_file(hip, tmp_path):
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_UNIFORM, 12, 0xFFFF, 0, 3_000_001)
+    p = tmp_path / "flags.bin"
+    p.write_bytes(flags.tobytes() + b"\x7f")        # trailing odd byte is ignored (read >> 1)
+    got, st = blockfile.flagstat_raw_file(str(p))
+    assert np.array_equal(got, oracle.flagstat_hist(flags)) and st["n_flags"] == flags.size
