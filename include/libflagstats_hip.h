@@ -118,6 +118,15 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
  * LZ4_decompress_safe, benchmark/flagstats.cpp:316): returns decoded bytes, < 0 on malformed input */
 int64_t FLAGSTATS_lz4_block_decode(const void* src, uint64_t srclen, void* dst, uint64_t dstcap);
 
+/* ---- plain 16-bit positional popcount ----
+ * replaces: `static int STORM_pospopcnt_u16(const uint16_t* data, size_t len, uint32_t* out)`
+ * python/libalgebra.h:3496-3551 -- out[16] is ZEROED first (:3497), then out[j] = number of words
+ * with bit j set.  HOST pointer.  Returns 0 on success. */
+int STORM_pospopcnt_u16(const uint16_t* data, size_t len, uint32_t* out);
+/* 64-bit forms in this library's convention: out[16] += bit counts (host array / device array) */
+int FLAGSTATS_hip_pospopcnt_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out);
+int FLAGSTATS_hip_device_pospopcnt_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream);
+
 /* read-only bandwidth probe with K1's load pattern and no flagstat arithmetic
  * (the analogue of the reference's memcpy baseline, linux/instrumented_benchmark.cpp:456-544):
  * `reps` sweeps of d_buf[0..bytes) (16-B aligned) between two hipEvents; nt = non-temporal loads. */

@@ -140,7 +140,10 @@ int bind()
     return 0;
 }
 
-int count_device_async(const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w)
+enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1 };
+
+int count_device_async(const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w,
+                       int op = OP_FLAGSTAT)
 {
     if (n == 0) return 0;
     if (!d_array) return fail_msg("NULL array with n > 0");
@@ -148,7 +151,10 @@ int count_device_async(const uint16_t* d_array, uint64_t n, uint64_t* d_out, hip
     const uint32_t grid = grid_for(n);
     int rc = ensure_ws(w, grid);
     if (rc) return rc;
-    HIP_TRY(fsk_launch(d_array, n, grid, g.variant, w.partials, d_out, s));
+    if (op == OP_POSPOPCNT)
+        HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s));
+    else
+        HIP_TRY(fsk_launch(d_array, n, grid, g.variant, w.partials, d_out, s));
     return 0;
 }
 
@@ -166,8 +172,9 @@ int ensure_stage(uint64_t flags)
 }
 
 // host array -> counters: double-buffered H2D + K1/K2 per chunk on two streams
-int count_host(const uint16_t* h, uint64_t n, uint64_t out[32])
+int count_host(const uint16_t* h, uint64_t n, uint64_t* out, int op = OP_FLAGSTAT)
 {
+    const int nout = (op == OP_POSPOPCNT) ? 16 : 32;
     if (n == 0) return 0;
     if (!h) return fail_msg("NULL array with n > 0");
     const uint64_t chunk = g.chunk_flags < 8 ? 8 : g.chunk_flags;
@@ -182,7 +189,7 @@ int count_host(const uint16_t* h, uint64_t n, uint64_t out[32])
         // same stream per slot: the copy into stage[sl] is ordered after the
         // kernel that last read it
         HIP_TRY(hipMemcpyAsync(g.stage[sl], h + done, c * sizeof(uint16_t), hipMemcpyHostToDevice, g.stream[sl]));
-        rc = count_device_async(g.stage[sl], c, g.d_out[sl], g.stream[sl], g.ws[sl]);
+        rc = count_device_async(g.stage[sl], c, g.d_out[sl], g.stream[sl], g.ws[sl], op);
         if (rc) return rc;
         done += c;
     }
@@ -190,7 +197,7 @@ int count_host(const uint16_t* h, uint64_t n, uint64_t out[32])
         HIP_TRY(hipMemcpyAsync(g.h_out + 32 * i, g.d_out[i], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream[i]));
     for (int i = 0; i < slots; ++i) HIP_TRY(hipStreamSynchronize(g.stream[i]));
     for (int i = 0; i < slots; ++i)
-        for (int s = 0; s < 32; ++s) out[s] += g.h_out[32 * i + s];
+        for (int s = 0; s < nout; ++s) out[s] += g.h_out[32 * i + s];
     return 0;
 }
 
@@ -480,6 +487,37 @@ int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmu
     if (out)
         for (int k = 0; k < 32; ++k) out[k] += g.h_out[k] / (uint64_t)reps;
     return 0;
+}
+
+/* ---- row f4: plain positional popcount (python/libalgebra.h:3496-3551) ---- */
+int FLAGSTATS_hip_pospopcnt_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!out) return fail_msg("NULL out");
+    int rc = bind();
+    if (rc) return rc;
+    return count_host(array, n, out, OP_POSPOPCNT);
+}
+
+int STORM_pospopcnt_u16(const uint16_t* data, size_t len, uint32_t* out)
+{
+    if (!out) return fail_msg("NULL out");
+    std::memset(out, 0, 16 * sizeof(uint32_t));  // the reference zeroes out[] first (:3497)
+    uint64_t wide[16];
+    std::memset(wide, 0, sizeof wide);
+    const int rc = FLAGSTATS_hip_pospopcnt_u16_x64(data, len, wide);
+    if (rc) return rc;
+    for (int i = 0; i < 16; ++i) out[i] = (uint32_t)wide[i];
+    return 0;
+}
+
+int FLAGSTATS_hip_device_pospopcnt_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!d_out) return fail_msg("NULL d_out");
+    int rc = bind();
+    if (rc) return rc;
+    return count_device_async(d_array, n, d_out, (hipStream_t)stream, g.user_ws[stream], OP_POSPOPCNT);
 }
 
 int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warmup, int reps, float* ms_total)

@@ -31,6 +31,9 @@ size_t fsk_partials_bytes(uint32_t grid);
 // K1 + K2 on `stream`: d_out32[32] += counters of d_array[0..n).  Asynchronous.
 hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
                       uint64_t* d_out32, hipStream_t stream);
+// positional popcount (flagstat_pospopcnt.hip): d_out16[16] += bit counts.  d_partials as for fsk_launch.
+hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, uint32_t grid, uint64_t* d_partials,
+                                uint64_t* d_out16, hipStream_t stream);
 // read-only bandwidth probe (measurement only)
 hipError_t fsk_read_probe(const void* d_buf, uint64_t bytes, uint32_t grid, int nt, uint32_t* d_sink, hipStream_t stream);
 // on-device input makers (flagstat_generate.hip)

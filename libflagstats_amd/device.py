@@ -67,6 +67,28 @@ class DeviceFlags:
         return count_device_ptr(self.ptr + 2 * offset, n)
 
 
+def pospopcnt_host(values: np.ndarray) -> np.ndarray:
+    """``STORM_pospopcnt_u16`` (python/libalgebra.h:3496-3551) of a host array: uint32[16], zeroed first."""
+    v = np.ascontiguousarray(values, dtype=np.uint16)
+    out = np.full(16, 0xDEADBEEF, dtype=np.uint32)  # the callee zeroes it, like the reference
+    _lib.check(_lib.lib().STORM_pospopcnt_u16(v.ctypes.data if v.size else None, v.size, out.ctypes.data),
+               "STORM_pospopcnt_u16")
+    return out
+
+
+def pospopcnt_torch(t, out=None):
+    """int64[16] += positional popcount of a 16-bit CUDA tensor, on torch's current stream."""
+    import torch
+
+    assert t.is_cuda and t.is_contiguous() and t.element_size() == 2
+    if out is None:
+        out = torch.zeros(16, dtype=torch.int64, device=t.device)
+    stream = torch.cuda.current_stream(t.device).cuda_stream
+    _lib.check(_lib.lib().FLAGSTATS_hip_device_pospopcnt_u16(t.data_ptr(), t.numel(), out.data_ptr(),
+                                                             ctypes.c_void_p(stream)), "FLAGSTATS_hip_device_pospopcnt_u16")
+    return out
+
+
 def count_device_ptr(ptr: int, n: int) -> np.ndarray:
     """uint64[32] counters of a device ``uint16`` array given as a raw pointer."""
     out = np.zeros(32, dtype=np.uint64)

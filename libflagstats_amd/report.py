@@ -1,0 +1,70 @@
+"""Report layer: the step AFTER the hot path.
+
+``samtools_counts`` / ``samtools_flagstat_text`` turn the 32 counters into the samtools-flagstat
+fields and text the reference's bench prints (``benchmark/flagstats.cpp:577-588``, struct
+``bam_flagstat_t`` ``:42-48``, ``percent`` ``:73-78``).  Mapping of counter slots to samtools fields
+(w = 0 pass-QC / 1 fail-QC, slot = 16*w + k):
+
+    n_reads[1]  = slot 25;  n_reads[0] = n_values - slot 25
+    n_secondary = 8   n_supp = 11   n_dup = 10   n_read1 = 6   n_read2 = 7
+    n_pair_good = 12  n_sgltn = 13  n_pair_map = 14
+    n_mapped[w] = n_reads[w] - slot 2          (libflagstats counts UNMAP, pyx:34)
+    n_pair_all[w] = n_read1[w] + n_read2[w]    (not among the 19 scalar counters; the reference's
+                                                Python module derives "paired_in_seq" the same way,
+                                                python/libflagstats.pyx:35 -- exact whenever every
+                                                primary paired read is exactly one of read1/read2)
+
+The two "mate mapped to a different chr" lines of samtools need RNAME/MAPQ, not FLAG, and are
+commented out in the reference as well (``:589-590``).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def samtools_counts(counters, n_values: int) -> dict:
+    c = [int(v) for v in np.asarray(counters).ravel()]
+    assert len(c) == 32
+    n_reads = [int(n_values) - c[25], c[25]]
+    out = {"n_reads": n_reads}
+    for name, k in (("n_secondary", 8), ("n_supp", 11), ("n_dup", 10), ("n_read1", 6), ("n_read2", 7),
+                    ("n_pair_good", 12), ("n_sgltn", 13), ("n_pair_map", 14)):
+        out[name] = [c[k], c[16 + k]]
+    out["n_mapped"] = [n_reads[0] - c[2], n_reads[1] - c[18]]
+    out["n_pair_all"] = [c[6] + c[7], c[22] + c[23]]
+    return out
+
+
+def _percent(n: int, total: int) -> str:
+    # benchmark/flagstats.cpp:73-78: "%.2f%%" of (float)n / total * 100.0, "N/A" for an empty class
+    if total == 0:
+        return "N/A"
+    return "%.2f%%" % (float(np.float32(n) / np.float32(total)) * 100.0)
+
+
+def samtools_flagstat_text(counters, n_values: int) -> str:
+    s = samtools_counts(counters, n_values)
+    two = lambda k: "%d + %d" % (s[k][0], s[k][1])  # noqa: E731
+    pct = lambda a, b: "(%s : %s)" % (_percent(s[a][0], s[b][0]), _percent(s[a][1], s[b][1]))  # noqa: E731
+    lines = [
+        two("n_reads") + " in total (QC-passed reads + QC-failed reads)",
+        two("n_secondary") + " secondary",
+        two("n_supp") + " supplementary",
+        two("n_dup") + " duplicates",
+        two("n_mapped") + " mapped " + pct("n_mapped", "n_reads"),
+        two("n_pair_all") + " paired in sequencing",
+        two("n_read1") + " read1",
+        two("n_read2") + " read2",
+        two("n_pair_good") + " properly paired " + pct("n_pair_good", "n_pair_all"),
+        two("n_pair_map") + " with itself and mate mapped",
+        two("n_sgltn") + " singletons " + pct("n_sgltn", "n_pair_all"),
+    ]
+    return "\n".join(lines) + "\n"
+
+
+def counter_table_text(counters) -> str:
+    """The 15-row name / pass / fail table the reference's bench writes to stderr
+    (benchmark/flagstats.cpp:340-342, names :100)."""
+    from .pyflagstats import SAM_FLAG_NAMES
+    c = np.asarray(counters).ravel()
+    return "".join("%s\t%d\t%d\n" % (SAM_FLAG_NAMES[i], int(c[i]), int(c[16 + i])) for i in range(15))

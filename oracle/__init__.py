@@ -28,6 +28,9 @@ from .pyoracle import (  # noqa: F401
     generate,
     load_c,
     load_ref,
+    pospopcnt,
+    pospopcnt_numpy,
+    ref_pospopcnt,
     pyflagstats_dict,
     ref_call,
 )

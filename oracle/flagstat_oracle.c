@@ -148,6 +148,18 @@ void oracle_flagstat_mt_u16(const uint16_t* array, uint64_t n, int threads, uint
     free(tid);
 }
 
+/* python/libalgebra.h:566-574 (scalar naive pospopcnt), through a 65536-bin histogram */
+void oracle_pospopcnt_u16(const uint16_t* array, uint64_t n, uint64_t out[16])
+{
+    uint64_t* hist = (uint64_t*)calloc(65536, sizeof(uint64_t));
+    hist_accumulate(array, n, hist);
+    for (int v = 0; v < 65536; ++v)
+        if (hist[v])
+            for (int j = 0; j < 16; ++j)
+                if (v & (1 << j)) out[j] += hist[v];
+    free(hist);
+}
+
 /* ---- synthetic input makers (host twins) --------------------------------- */
 
 static inline uint64_t mix64(uint64_t seed, uint64_t ctr)

@@ -47,6 +47,10 @@ void oracle_flagstat_mt_u16(const uint16_t* array, uint64_t n, int threads, uint
 /* uint32 ABI twin of the reference signature (accumulates, returns 0). */
 int oracle_FLAGSTAT_scalar(const uint16_t* array, uint32_t len, uint32_t* flags);
 
+/* Plain 16-bit positional popcount, restating STORM_pospopcnt_u16_scalar_naive
+ * (python/libalgebra.h:566-574): out[j] += number of words with bit j set (row f4). */
+void oracle_pospopcnt_u16(const uint16_t* array, uint64_t n, uint64_t out[16]);
+
 /* ---- host twins of the product's on-device input makers ------------------
  * (libflagstats_amd/csrc/flagstat_generate.hip).  Counter-based, so any
  * sub-range can be regenerated independently.  kind:

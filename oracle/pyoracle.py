@@ -142,6 +142,8 @@ def load_c():
     lib.oracle_flagstat_mt_u16.restype = None
     lib.oracle_FLAGSTAT_scalar.argtypes = [_U16P, ctypes.c_uint32, _U32P]
     lib.oracle_FLAGSTAT_scalar.restype = ctypes.c_int
+    lib.oracle_pospopcnt_u16.argtypes = [_U16P, ctypes.c_uint64, _U64P]
+    lib.oracle_pospopcnt_u16.restype = None
     lib.oracle_generate_u16.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32,
                                         ctypes.c_uint64, ctypes.c_uint64, _U16P]
     lib.oracle_generate_u16.restype = None
@@ -185,6 +187,34 @@ def flagstat_hist(values) -> np.ndarray:
 def flagstat_mt(values, threads: int | None = None) -> np.ndarray:
     threads = threads or (os.cpu_count() or 1)
     return _run(load_c().oracle_flagstat_mt_u16, values, ctypes.c_int(threads))
+
+
+def pospopcnt(values) -> np.ndarray:
+    """uint64[16] positional popcount (flagstat_oracle.c: oracle_pospopcnt_u16)."""
+    a = _as_u16(values)
+    out = np.zeros(16, dtype=np.uint64)
+    load_c().oracle_pospopcnt_u16(_ptr16(a), a.size, out.ctypes.data_as(_U64P))
+    return out
+
+
+def pospopcnt_numpy(values) -> np.ndarray:
+    x = np.ascontiguousarray(values, dtype=np.uint16).ravel()
+    return np.array([np.count_nonzero(x & np.uint16(1 << j)) for j in range(16)], dtype=np.uint64)
+
+
+def ref_pospopcnt(values, naive: bool = False):
+    """The reference's STORM_pospopcnt_u16 (or its scalar_naive form) from oracle/_ref, or None."""
+    lib = load_ref()
+    name = "ref_STORM_pospopcnt_u16_scalar_naive" if naive else "ref_STORM_pospopcnt_u16"
+    if lib is None or not hasattr(lib, name):
+        return None
+    a = _as_u16(values)
+    out = np.zeros(16, dtype=np.uint32)
+    fn = getattr(lib, name)
+    fn.argtypes = [_U16P, ctypes.c_size_t, _U32P]
+    fn.restype = ctypes.c_int
+    fn(_ptr16(a), a.size, out.ctypes.data_as(_U32P))
+    return out
 
 
 def generate(kind: int, seed: int, mask: int, first_index: int, n: int) -> np.ndarray:

@@ -80,6 +80,14 @@ int ref_FLAGSTAT_avx512_improved3(const uint16_t* a, uint32_t n, uint32_t* f)
 }
 #endif
 
+/* libalgebra's positional popcount entry (python/libalgebra.h:3496-3551; zeroes out[16] first)
+ * and its scalar statement (:566-574; accumulates) */
+int ref_STORM_pospopcnt_u16(const uint16_t* a, size_t n, uint32_t* out) { return STORM_pospopcnt_u16(a, n, out); }
+int ref_STORM_pospopcnt_u16_scalar_naive(const uint16_t* a, size_t n, uint32_t* out)
+{
+    return STORM_pospopcnt_u16_scalar_naive(a, n, out);
+}
+
 /* 64-bit convenience for the CPU baseline: chunk into <= 2^30-flag calls of
  * the dispatcher's choice, private uint32[32] per chunk, summed to uint64
  * (BASELINE.md section 4 step 2/3). */

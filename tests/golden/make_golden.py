@@ -228,8 +228,23 @@ print(json.dumps(res))
     dump("pyflagstats.json", res)
 
 
+def make_pospopcnt():
+    """Row f4: STORM_pospopcnt_u16 (python/libalgebra.h:3496-3551) on seeded inputs."""
+    cases = []
+    for seed, hi, n in ((1, 65536, 0), (2, 65536, 1), (3, 65536, 31), (4, 65536, 255), (5, 65536, 513), (6, 4096, 4097),
+                        (7, 65536, 100003), (8, 65536, 1048577)):
+        a = np.random.RandomState(seed).randint(0, hi, n).astype(np.uint16)
+        d = oracle.ref_pospopcnt(a)
+        nv = oracle.ref_pospopcnt(a, naive=True)
+        assert [int(v) for v in d] == [int(v) for v in nv]
+        cases.append({"seed": seed, "hi": hi, "n": n, "counts": [int(v) for v in d]})
+    dump("pospopcnt.json", {"source": "STORM_pospopcnt_u16 python/libalgebra.h:3496-3551 via oracle/_ref",
+                            "recipe": "numpy.random.RandomState(seed).randint(0, hi, n).astype(uint16)", "cases": cases})
+
+
 if __name__ == "__main__":
     oracle.build(ref=True)
+    make_pospopcnt()
     make_kat()
     make_random()
     make_accumulate()

@@ -58,7 +58,7 @@ def test_shard_ranges_cover_exactly():
 def declared_symbols():
     text = open(os.path.join(ROOT, "include", "libflagstats_hip.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    names = re.findall(r"\b(FLAGSTATS?_[A-Za-z0-9_]+)\s*\(", text)
+    names = re.findall(r"\b((?:FLAGSTATS?|STORM)_[A-Za-z0-9_]+)\s*\(", text)
     return sorted(set(n for n in names if n != "FLAGSTATS_func"))
 
 
