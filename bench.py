@@ -39,6 +39,7 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
 
     a = oracle.generate(oracle.GEN_UNIFORM, seed, 0xFFFF, 0, sample_flags)
     ref = oracle.load_ref()
+    lib = oracle.load_c()
     if ref is not None:
         kind = "reference"
         name = ref.ref_dispatch_name(min(sample_flags, 2 ** 30)).decode()
@@ -70,24 +71,44 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
             break
     one = sample_flags * passes / dt / 1e9
 
-    # all cores: contiguous shards, private counters per thread (ctypes drops the GIL)
+    # all cores: a larger sample (beyond the host's last-level caches), one contiguous shard and
+    # private counters per thread; the pass loop runs inside C (ref_dispatch_repeat), ctypes drops
+    # the GIL, so Python is not what is being timed
     cores = os.cpu_count() or 1
-    per = sample_flags // cores
-    addr = a.ctypes.data
+    big_flags = max(sample_flags, min(2 ** 30, 4 * 2 ** 20 * cores))
+    per = big_flags // cores
+    big = np.empty(per * cores, dtype=np.uint16)
 
-    def worker(k, reps):
-        ptr = ctypes.cast(addr + 2 * per * k, ctypes.POINTER(ctypes.c_uint16))
-        for _ in range(reps):
-            run(ptr, per)
+    def fill(k):
+        oracle.load_c().oracle_generate_u16(oracle.GEN_UNIFORM, seed, 0xFFFF, per * k, per,
+                                            ctypes.cast(big.ctypes.data + 2 * per * k, ctypes.POINTER(ctypes.c_uint16)))
 
-    reps = max(1, int(passes * min(1.0, 5.0 / max(dt, 1e-9))))
-    ths = [threading.Thread(target=worker, args=(k, reps)) for k in range(cores)]
-    t0 = time.perf_counter()
+    def timed(reps):
+        def worker(k):
+            ptr = ctypes.cast(big.ctypes.data + 2 * per * k, ctypes.POINTER(ctypes.c_uint16))
+            out = np.zeros(32, dtype=np.uint64)
+            p64 = out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
+            if ref is not None:
+                ref.ref_dispatch_repeat(ptr, per, reps, p64)
+            else:
+                for _ in range(reps):
+                    lib.oracle_flagstat_hist_u16(ptr, per, p64)
+        ths = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
+        t0 = time.perf_counter()
+        for t in ths:
+            t.start()
+        for t in ths:
+            t.join()
+        return time.perf_counter() - t0
+
+    ths = [threading.Thread(target=fill, args=(k,)) for k in range(cores)]
     for t in ths:
         t.start()
     for t in ths:
         t.join()
-    dt_all = time.perf_counter() - t0
+    probe = timed(2)
+    reps = max(2, min(100000, int(2 * 5.0 / max(probe, 1e-6))))   # aim at ~5 s
+    dt_all = timed(reps)
     allc = per * cores * reps / dt_all / 1e9
 
     return {
@@ -95,7 +116,8 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
         "sample": "first %d flags (%.0f MiB) of the rank-0 workload, %d passes in %.1f s, 1 thread"
                   % (sample_flags, sample_flags * 2 / 2 ** 20, passes, dt),
         "all_cores": {"value": round(allc, 4), "unit": "Gflags/s", "cores": cores,
-                      "sample": "%d contiguous shards x %d passes in %.1f s" % (cores, reps, dt_all)},
+                      "sample": "%d flags (%.0f MiB) in %d contiguous shards x %d passes in %.1f s"
+                                % (per * cores, per * cores * 2 / 2 ** 20, cores, reps, dt_all)},
     }, a
 
 
