@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 27)
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--force-dist", action="store_true",
+                    help="run the N>1 step (store + RCCL all-reduce) even at world size 1: exercises the multi-GPU "
+                         "code path on a single-GPU box")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -152,8 +155,10 @@ def main():
     dev = torch.device("cuda", local_rank)
     lib = _lib.lib()
     _lib.check(lib.FLAGSTATS_hip_init(local_rank), "FLAGSTATS_hip_init")
-    if world > 1:
+    multi = world > 1 or args.force_dist
+    if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.flags_per_gpu
@@ -165,15 +170,13 @@ def main():
     def step():
         # N = 1: counters accumulate across steps (the ABI's += contract, as the reference's
         # bench accumulates across blocks, benchmark/flagstats.cpp:304,328-329), so a step is
-        # exactly K1 + K2.  N > 1: a step is one whole query: zero, count, all-reduce.
-        if world > 1:
-            counters.zero_()
-        device.count_torch(flags, counters)      # K1 + K2 on torch's current stream
-        if world > 1:
+        # exactly K1 + K2.  N > 1: a step is one whole query: count (K2 stores), all-reduce.
+        device.count_torch(flags, counters, store=multi)   # K1 + K2 on torch's current stream
+        if multi:
             allreduce_counters(counters)          # the path's only exchange: 256 B over xGMI
 
     def barrier():
-        if world > 1:
+        if multi:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -193,7 +196,7 @@ def main():
     wall = time.perf_counter() - t0
     ev_ms = e0.elapsed_time(e1)
 
-    if world > 1:
+    if multi:
         tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tmax[0]), float(tmax[1])
@@ -206,7 +209,7 @@ def main():
     result = None
     if rank == 0:
         got = counters.cpu().numpy().view(np.uint64)
-        passes = args.steps if world == 1 else 1   # N = 1 accumulated `steps` identical passes
+        passes = 1 if multi else args.steps   # N = 1 accumulated `steps` identical passes
         assert not (got % np.uint64(passes)).any(), "accumulated counters are not a multiple of the step count"
         got = got // np.uint64(passes)
         cpu = None
@@ -254,7 +257,7 @@ def main():
             result["gpu_over_cpu_1thread"] = round(value / cpu["value"], 1) if cpu["value"] else None
         print(json.dumps(result), flush=True)
 
-    if world > 1:
+    if multi:
         dist.barrier()
         dist.destroy_process_group()
     return result

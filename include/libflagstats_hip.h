@@ -61,6 +61,10 @@ int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out);
  * (a hipStream_t passed as void*; NULL = HIP's null stream, as in every HIP API). */
 int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream);
 
+/* same, but d_out[32] = counters (all 32 slots written, never-written slots as 0): one query per
+ * call with no zeroing launch in front; used by the multi-GPU step before its all-reduce. */
+int FLAGSTATS_hip_device_u16_store(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream);
+
 /* DEVICE-resident array, HOST counters: out[32] += counters; synchronous. */
 int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t* out);
 

@@ -31,6 +31,7 @@ SIGNATURES = {
     "FLAGSTAT_hip": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "FLAGSTATS_u16_x64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
     "FLAGSTATS_hip_device_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
+    "FLAGSTATS_hip_device_u16_store": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
     "FLAGSTATS_hip_device_u16_sync": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
     "FLAGSTATS_hip_available": (ctypes.c_int, []),
     "FLAGSTATS_hip_init": (ctypes.c_int, [ctypes.c_int]),

@@ -140,12 +140,15 @@ int bind()
     return 0;
 }
 
-enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1 };
+enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2 };
 
 int count_device_async(const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w,
                        int op = OP_FLAGSTAT)
 {
-    if (n == 0) return 0;
+    if (n == 0) {
+        if (op == OP_FLAGSTAT_STORE) HIP_TRY(hipMemsetAsync(d_out, 0, 32 * sizeof(uint64_t), s));
+        return 0;
+    }
     if (!d_array) return fail_msg("NULL array with n > 0");
     if (reinterpret_cast<uintptr_t>(d_array) & 1u) return fail_msg("array must be 2-byte aligned");
     const uint32_t grid = grid_for(n);
@@ -154,7 +157,7 @@ int count_device_async(const uint16_t* d_array, uint64_t n, uint64_t* d_out, hip
     if (op == OP_POSPOPCNT)
         HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s));
     else
-        HIP_TRY(fsk_launch(d_array, n, grid, g.variant, w.partials, d_out, s));
+        HIP_TRY(fsk_launch(d_array, n, grid, g.variant | (op == OP_FLAGSTAT_STORE ? 256 : 0), w.partials, d_out, s));
     return 0;
 }
 
@@ -367,6 +370,15 @@ int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_ou
     if (rc) return rc;
     // `stream` is used as given: NULL is HIP's null stream (what torch's default stream is)
     return count_device_async(d_array, n, d_out, (hipStream_t)stream, g.user_ws[stream]);
+}
+
+int FLAGSTATS_hip_device_u16_store(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!d_out) return fail_msg("NULL d_out");
+    int rc = bind();
+    if (rc) return rc;
+    return count_device_async(d_array, n, d_out, (hipStream_t)stream, g.user_ws[stream], OP_FLAGSTAT_STORE);
 }
 
 int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t* out)

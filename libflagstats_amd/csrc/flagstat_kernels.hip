@@ -390,7 +390,8 @@ __global__ __launch_bounds__(kThreads) void flagstat_read_probe(const uint4* __r
 constexpr int kFinalizeThreads = 1024;
 
 __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint64_t* __restrict__ partials,
-                                                                      uint32_t nblocks, uint64_t* __restrict__ out)
+                                                                      uint32_t nblocks, uint64_t* __restrict__ out,
+                                                                      int store)
 {
     __shared__ uint64_t tot[32];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -413,7 +414,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
         if (t >= 0) add = fail ? tot[8 + t] : tot[t] - tot[8 + t];  // pass-QC = all - fail
         if (slot == 10) add = fail ? tot[18] : tot[17];              // DUP: fail / pass
         if (slot == 9 && fail) add = tot[16] + tot[18];              // fail-QC read count (slot 25)
-        if (add) out[threadIdx.x] += add;
+        if (store)
+            out[threadIdx.x] = add;        // "=" form: all 32 slots written, dead slots as 0
+        else if (add)
+            out[threadIdx.x] += add;       // reference contract: accumulate, never touch dead slots
     }
 }
 
@@ -474,7 +478,8 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kFinalizeThreads), 0, stream, d_partials, grid, d_out32);
+    hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kFinalizeThreads), 0, stream, d_partials, grid, d_out32,
+                       (variant >> 8) & 1);  // bit 8 of `variant`: store instead of accumulate
     return hipGetLastError();
 }
 

@@ -101,10 +101,11 @@ def count_device_async(ptr: int, n: int, d_out_ptr: int, stream: int | None) -> 
     _lib.check(_lib.lib().FLAGSTATS_hip_device_u16(ptr, n, d_out_ptr, stream), "FLAGSTATS_hip_device_u16")
 
 
-def count_torch(t, out=None):
+def count_torch(t, out=None, store: bool = False):
     """Counters of a CUDA torch tensor of 16-bit elements, on torch's current stream.
 
     Returns (or adds into) an ``int64[32]`` CUDA tensor; nothing is synchronised.
+    ``store=True`` overwrites ``out`` instead of accumulating (no zeroing launch needed).
     """
     import torch
 
@@ -112,8 +113,12 @@ def count_torch(t, out=None):
     if out is None:
         out = torch.zeros(32, dtype=torch.int64, device=t.device)
     assert out.is_cuda and out.dtype == torch.int64 and out.numel() == 32 and out.is_contiguous()
-    stream = torch.cuda.current_stream(t.device).cuda_stream
-    count_device_async(t.data_ptr(), t.numel(), out.data_ptr(), ctypes.c_void_p(stream))
+    stream = ctypes.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+    if store:
+        _lib.check(_lib.lib().FLAGSTATS_hip_device_u16_store(t.data_ptr(), t.numel(), out.data_ptr(), stream),
+                   "FLAGSTATS_hip_device_u16_store")
+    else:
+        count_device_async(t.data_ptr(), t.numel(), out.data_ptr(), stream)
     return out
 
 

@@ -35,7 +35,7 @@ def allreduce_counters(counters, group=None):
     import torch.distributed as dist
 
     assert counters.dtype == torch.int64 and counters.numel() == 32
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized():
         dist.all_reduce(counters, op=dist.ReduceOp.SUM, group=group)
     return counters
 

@@ -248,3 +248,10 @@ def test_torch_stream_entry(hip):
     torch.cuda.synchronize()
     want = oracle.flagstat_generated(oracle.GEN_UNIFORM, 31, 0xFFFF, 0, n)
     assert np.array_equal(out.cpu().numpy().view(np.uint64), want * U64(2))
+    # store form: overwrites whatever is there, writes every slot (dead ones as 0)
+    junk = torch.full((32,), 12345, dtype=torch.int64, device="cuda:0")
+    device.count_torch(t, junk, store=True)
+    device.count_torch(t[:0], out, store=True)       # n == 0 stores zeros
+    torch.cuda.synchronize()
+    assert np.array_equal(junk.cpu().numpy().view(np.uint64), want)
+    assert not out.cpu().numpy().any()
