@@ -111,6 +111,7 @@ int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmu
 typedef struct FLAGSTATS_blockfile_stats {
     uint64_t n_flags, n_blocks, compressed_bytes, uncompressed_bytes;
     double wall_s, index_s, setup_s, decode_cpu_s; /* setup_s: index + buffers; decode_cpu_s: sum over threads */
+    double wait_decode_s, wait_copy_s;             /* orchestrator: waiting for decoders / for H2D copies */
     int32_t threads, chunks;
 } FLAGSTATS_blockfile_stats;
 int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);

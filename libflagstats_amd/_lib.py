@@ -21,7 +21,8 @@ class BlockfileStats(ctypes.Structure):
     """FLAGSTATS_blockfile_stats of include/libflagstats_hip.h."""
     _fields_ = [("n_flags", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("compressed_bytes", ctypes.c_uint64),
                 ("uncompressed_bytes", ctypes.c_uint64), ("wall_s", ctypes.c_double), ("index_s", ctypes.c_double),
-                ("setup_s", ctypes.c_double), ("decode_cpu_s", ctypes.c_double), ("threads", ctypes.c_int32), ("chunks", ctypes.c_int32)]
+                ("setup_s", ctypes.c_double), ("decode_cpu_s", ctypes.c_double),
+                ("wait_decode_s", ctypes.c_double), ("wait_copy_s", ctypes.c_double), ("threads", ctypes.c_int32), ("chunks", ctypes.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/libflagstats_hip.h one to one

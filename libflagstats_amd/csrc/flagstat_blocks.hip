@@ -26,6 +26,8 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 #include <vector>
@@ -124,7 +126,8 @@ int64_t lz4_block_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap)
 }
 
 struct BlockRef {
-    const uint8_t* src;
+    const uint8_t* src;   // payload in memory (image mode) or nullptr (file mode: pread at file_off)
+    uint64_t file_off;
     uint32_t csize, usize;
     uint64_t dst_off;  // byte offset inside its chunk buffer (16-byte aligned)
     uint32_t chunk;
@@ -143,7 +146,7 @@ double now_s()
 // Parse the block headers of a file image.  Every block's decoded bytes get a 16-byte aligned
 // slot in a chunk buffer; the gap up to the next slot is zero-filled, and a zero flag counts
 // nothing, so a whole chunk is counted as ONE array.
-int index_blocks(const uint8_t* img, uint64_t bytes, uint64_t chunk_cap, std::vector<BlockRef>& blocks,
+int index_blocks(const uint8_t* img, int fd, uint64_t bytes, uint64_t chunk_cap, std::vector<BlockRef>& blocks,
                  std::vector<ChunkRef>& chunks, uint64_t& uncompressed)
 {
     uint64_t pos = 0;
@@ -152,8 +155,14 @@ int index_blocks(const uint8_t* img, uint64_t bytes, uint64_t chunk_cap, std::ve
     while (pos < bytes) {
         if (bytes - pos < 8) return fsint::fail_text("block file: truncated block header");
         int32_t us, cs;
-        std::memcpy(&us, img + pos, 4);
-        std::memcpy(&cs, img + pos + 4, 4);
+        uint8_t hdr[8];
+        if (img) {
+            std::memcpy(hdr, img + pos, 8);
+        } else if (pread(fd, hdr, 8, static_cast<off_t>(pos)) != 8) {
+            return fsint::fail_text("block file: cannot read block header");
+        }
+        std::memcpy(&us, hdr, 4);
+        std::memcpy(&cs, hdr + 4, 4);
         pos += 8;
         if (us < 0 || cs < 0) return fsint::fail_text("block file: negative size in block header");
         if (static_cast<uint64_t>(cs) > bytes - pos) return fsint::fail_text("block file: block payload runs past end of file");
@@ -164,8 +173,8 @@ int index_blocks(const uint8_t* img, uint64_t bytes, uint64_t chunk_cap, std::ve
             chunks.push_back(cur);
             cur = ChunkRef{blocks.size(), 0, 0};
         }
-        blocks.push_back(BlockRef{img + pos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us), cur.bytes,
-                                  static_cast<uint32_t>(chunks.size())});
+        blocks.push_back(BlockRef{img ? img + pos : nullptr, pos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us),
+                                  cur.bytes, static_cast<uint32_t>(chunks.size())});
         cur.bytes += padded;
         uncompressed += static_cast<uint64_t>(us);
         pos += static_cast<uint64_t>(cs);
@@ -177,7 +186,8 @@ int index_blocks(const uint8_t* img, uint64_t bytes, uint64_t chunk_cap, std::ve
 
 struct Pipe {
     std::mutex m;
-    std::condition_variable cv;
+    std::condition_variable cv_workers;  // "a chunk buffer was released" (orchestrator -> decoders)
+    std::condition_variable cv_main;     // "a chunk is fully decoded" (last decoder of the chunk -> orchestrator)
     size_t released = 0;                 // chunks [0, released) may be decoded
     std::vector<size_t> done;            // blocks decoded per chunk
     std::vector<std::atomic<size_t>> next;  // next block to grab per chunk
@@ -188,7 +198,11 @@ struct Pipe {
 
 constexpr int kPinned = 3;
 
-int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* st)
+// img != nullptr: the whole file image is in memory.  img == nullptr: file mode -- every worker
+// preads the compressed payload of its block into a private buffer.  (mmap-ing the file instead
+// makes all decode threads fault on one address space; the contention grows with the thread
+// count and was measured to cost more than the extra copy.)
+int run_pipeline(const uint8_t* img, int fd, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* st)
 {
     const double t0 = now_s();
     uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
@@ -196,14 +210,14 @@ int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out,
     std::vector<BlockRef> blocks;
     std::vector<ChunkRef> chunks;
     uint64_t uncompressed = 0;
-    int rc = index_blocks(img, bytes, chunk_cap, blocks, chunks, uncompressed);
+    int rc = index_blocks(img, fd, bytes, chunk_cap, blocks, chunks, uncompressed);
     if (rc) return rc;
     const double t_index = now_s() - t0;
     uint64_t n_flags = 0;
     for (const BlockRef& b : blocks) n_flags += b.usize >> 1;  // as benchmark/flagstats.cpp:323
     if (threads <= 0) {
         threads = static_cast<int>(std::thread::hardware_concurrency());
-        if (threads > 24) threads = 24;  // measured optimum on 2x EPYC 9575F; more threads contend (profiles/r01)
+        if (threads > 24) threads = 24;  // ~PCIe-bound from 16-24 decoders on 2x EPYC 9575F (profiles/r01)
         if (threads < 1) threads = 1;
     }
     if (static_cast<size_t>(threads) > blocks.size() && !blocks.empty()) threads = static_cast<int>(blocks.size());
@@ -238,10 +252,11 @@ int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out,
     for (auto& a : pipe.next) a.store(0);
     auto worker = [&]() {
         double busy = 0;
+        std::vector<uint8_t> local;  // file mode: this thread's copy of the compressed payload
         for (size_t c = 0; c < chunks.size(); ++c) {
             {
                 std::unique_lock<std::mutex> ul(pipe.m);
-                pipe.cv.wait(ul, [&] { return pipe.released > c || pipe.failed; });
+                pipe.cv_workers.wait(ul, [&] { return pipe.released > c || pipe.failed; });
                 if (pipe.failed) break;
             }
             uint8_t* base = pinned[c % kPinned];
@@ -254,7 +269,22 @@ int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out,
                 const BlockRef& br = blocks[b];
                 uint8_t* dst = base + br.dst_off;
                 const uint64_t padded = (static_cast<uint64_t>(br.usize) + 15) & ~15ull;
-                const int64_t got = lz4_block_decode(br.src, br.csize, dst, br.usize);
+                const uint8_t* src = br.src;
+                if (!src) {
+                    if (local.size() < br.csize) local.resize(br.csize + (br.csize >> 2) + 64);
+                    size_t have = 0;
+                    while (have < br.csize) {
+                        const ssize_t r = pread(fd, local.data() + have, br.csize - have, static_cast<off_t>(br.file_off + have));
+                        if (r <= 0) break;
+                        have += static_cast<size_t>(r);
+                    }
+                    if (have != br.csize) {
+                        bad = true;
+                        break;
+                    }
+                    src = local.data();
+                }
+                const int64_t got = lz4_block_decode(src, br.csize, dst, br.usize);
                 if (got != static_cast<int64_t>(br.usize)) {
                     bad = true;
                     break;
@@ -267,31 +297,40 @@ int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out,
             busy += now_s() - w0;
             std::lock_guard<std::mutex> g(pipe.m);
             pipe.done[c] += mine;
-            if (bad) pipe.failed = true;
-            pipe.cv.notify_all();
+            if (bad) {
+                pipe.failed = true;
+                pipe.cv_workers.notify_all();
+            }
+            // one wake-up per chunk, not one per decoder (a shared condvar made this O(threads^2))
+            if (bad || pipe.done[c] == chunks[c].b1 - chunks[c].b0) pipe.cv_main.notify_one();
             if (bad) break;
         }
         std::lock_guard<std::mutex> g(pipe.m);
         pipe.decode_cpu_s += busy;
     };
+    const double t_a = now_s();
     std::vector<std::thread> pool;
     for (int t = 0; t < threads && !chunks.empty(); ++t) pool.emplace_back(worker);
+    const double t_b = now_s();
 
     auto release = [&](size_t upto) {
         std::lock_guard<std::mutex> g(pipe.m);
         if (upto > pipe.released) pipe.released = upto;
-        pipe.cv.notify_all();
+        pipe.cv_workers.notify_all();
     };
     release(static_cast<size_t>(npin));
     int err = 0;
+    double wait_decode = 0, wait_copy = 0;
     for (size_t c = 0; c < chunks.size() && !err; ++c) {
         {
+            const double w0 = now_s();
             std::unique_lock<std::mutex> ul(pipe.m);
-            pipe.cv.wait(ul, [&] { return pipe.done[c] == chunks[c].b1 - chunks[c].b0 || pipe.failed; });
+            pipe.cv_main.wait(ul, [&] { return pipe.done[c] == chunks[c].b1 - chunks[c].b0 || pipe.failed; });
             if (pipe.failed) {
                 err = fsint::fail_text("block file: LZ4 block failed to decode to its declared size");
                 break;
             }
+            wait_decode += now_s() - w0;
         }
         const int sl = static_cast<int>(c & 1);
         const int pb = static_cast<int>(c % kPinned);
@@ -303,22 +342,28 @@ int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out,
         }
         err = fsint::count_async(fsint::stage_buf(sl), chunks[c].bytes / 2, sl);
         if (err) break;
-        if (c + kPinned < chunks.size()) {
-            // the pinned buffer of chunk c is reusable once its copy has left the host
-            e = hipEventSynchronize(copied[pb]);
+        if (c >= 1 && (c - 1) + kPinned < chunks.size()) {
+            // The pinned buffer of chunk c-1 is reusable once ITS copy has left the host.  Waiting for
+            // it only now -- with copy(c) already queued behind it -- keeps the copy engine busy
+            // back to back; waiting for copy(c) itself here left it idle between chunks.
+            const double w1 = now_s();
+            e = hipEventSynchronize(copied[(c - 1) % kPinned]);
+            wait_copy += now_s() - w1;
             if (e != hipSuccess) {
                 err = fsint::fail_hip("hipEventSynchronize", e);
                 break;
             }
-            release(c + kPinned + 1);
+            release((c - 1) + kPinned + 1);
         }
     }
     if (err) {
         std::lock_guard<std::mutex> g(pipe.m);
         pipe.failed = true;
-        pipe.cv.notify_all();
+        pipe.cv_workers.notify_all();
     }
+    const double t_c = now_s();
     for (auto& t : pool) t.join();
+    const double t_d = now_s();
     if (!err) {
         for (int s = 0; s < 2 && !err; ++s) {
             hipError_t e = hipMemcpyAsync(fsint::host_out() + 32 * s, fsint::dev_out(s), 32 * sizeof(uint64_t),
@@ -331,6 +376,8 @@ int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out,
         if (e != hipSuccess && !err) err = fsint::fail_hip("hipStreamSynchronize", e);
     }
     for (int i = 0; i < npin; ++i) (void)hipEventDestroy(copied[i]);
+    if (getenv("FLAGSTATS_HIP_TRACE"))
+        fprintf(stderr, "blocks: spawn %.4f loop %.4f join %.4f sync %.4f\n", t_b - t_a, t_c - t_b, t_d - t_c, now_s() - t_d);
     if (err) return err;
     for (int s = 0; s < 2; ++s)
         for (int k = 0; k < 32; ++k) out[k] += fsint::host_out()[32 * s + k];
@@ -342,6 +389,8 @@ int run_pipeline(const uint8_t* img, uint64_t bytes, int threads, uint64_t* out,
         st->wall_s = now_s() - t0;
         st->index_s = t_index;
         st->setup_s = t_setup;
+        st->wait_decode_s = wait_decode;
+        st->wait_copy_s = wait_copy;
         st->decode_cpu_s = pipe.decode_cpu_s;
         st->threads = threads;
         st->chunks = static_cast<int32_t>(chunks.size());
@@ -394,16 +443,25 @@ int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads,
 {
     if (!out) return fsint::fail_text("NULL out");
     if (!image && bytes) return fsint::fail_text("NULL image");
-    return run_pipeline(static_cast<const uint8_t*>(image), bytes, threads, out, stats);
+    static const uint8_t empty = 0;
+    return run_pipeline(image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, out, stats);
 }
 
 int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
 {
     if (!out) return fsint::fail_text("NULL out");
-    Mapped m;
-    int rc = map_file(path, m);
-    if (rc) return rc;
-    return run_pipeline(m.p, m.bytes, threads, out, stats);
+    if (!path) return fsint::fail_text("NULL path");
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fsint::fail_text("cannot open file");
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        return fsint::fail_text("cannot stat file");
+    }
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    const int rc = run_pipeline(nullptr, fd, static_cast<uint64_t>(sb.st_size), threads, out, stats);
+    close(fd);
+    return rc;
 }
 
 int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats)

@@ -76,7 +76,7 @@ def main():
                 best = (dt, st)
         dt, st = best
         rows.append({"chunk_MiB": cm, "threads": st["threads"], "wall_s": round(dt, 4), "Gflags_s": round(n / dt / 1e9, 2),
-                     "compressed_GB_s": round(size / dt / 1e9, 2), "decode_cpu_s": round(st["decode_cpu_s"], 3), "setup_s": round(st["setup_s"], 4),
+                     "compressed_GB_s": round(size / dt / 1e9, 2), "decode_cpu_s": round(st["decode_cpu_s"], 3), "setup_s": round(st["setup_s"], 4), "wait_decode_s": round(st["wait_decode_s"], 4), "wait_copy_s": round(st["wait_copy_s"], 4),
                      "decode_GB_s_per_thread": round(2 * n / max(st["decode_cpu_s"], 1e-9) / 1e9, 2)})
         print(rows[-1], flush=True)
 
