@@ -130,6 +130,9 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 27)
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--strong", action="store_true",
+                    help="strong scaling: --flags-per-gpu is the TOTAL array, split into contiguous shards over the ranks "
+                         "(default is weak scaling: every rank holds its own --flags-per-gpu shard)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 step (store + RCCL all-reduce) even at world size 1: exercises the multi-GPU "
                          "code path on a single-GPU box")
@@ -162,6 +165,10 @@ def main():
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     n = args.flags_per_gpu
+    if args.strong:
+        from libflagstats_amd.dist import shard_range
+        b, e = shard_range(args.flags_per_gpu, rank, world)
+        n = e - b
     flags = torch.empty(n, dtype=torch.int16, device=dev)           # this rank's shard, resident in HBM
     device.generate_torch(flags, device.GEN_UNIFORM, seed=args.seed + rank, mask=0xFFFF)
     counters = torch.zeros(32, dtype=torch.int64, device=dev)
@@ -202,7 +209,8 @@ def main():
         wall, ev_ms = float(tmax[0]), float(tmax[1])
 
     ms_per_step = wall * 1e3 / args.steps
-    value = n * world * args.steps / wall / 1e9            # whole-job Gflags/s
+    total_flags = args.flags_per_gpu if args.strong else n * world
+    value = total_flags * args.steps / wall / 1e9          # whole-job Gflags/s
     ev_ms_per_step = ev_ms / args.steps
     achieved = 2.0 * n / (ev_ms_per_step * 1e-3) / 1e9     # GB/s per GPU, algorithmic bytes
 
@@ -238,11 +246,11 @@ def main():
         result = {
             "metric": METRIC, "value": round(value, 3), "unit": "Gflags/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
+            "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": "%.3g GiB uniform-random uint16 FLAG array (%d flags) per GPU, device-resident, "
                                    "K1 flagstat_count + K2 flagstat_finalize%s"
                                    % (n * 2 / 2 ** 30, n, " + RCCL all-reduce int64[32]" if world > 1 else ""),
-                       "flags_per_gpu": n, "global_flags": n * world, "parallelism": "shard%d" % world,
+                       "flags_per_gpu": n, "global_flags": total_flags, "parallelism": "shard%d" % world,
                        "kernel_variant": int(lib.FLAGSTATS_hip_get(b"variant")),
                        "grid_blocks": int(lib.FLAGSTATS_hip_get(b"grid"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",

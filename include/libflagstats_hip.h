@@ -137,6 +137,11 @@ int FLAGSTATS_hip_device_pospopcnt_u16(const uint16_t* d_array, uint64_t n, uint
  * `reps` sweeps of d_buf[0..bytes) (16-B aligned) between two hipEvents; nt = non-temporal loads. */
 int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warmup, int reps, float* ms_total);
 
+/* parameterised variant for access-pattern sweeps (tools/probe_sweep.py): mode 0 grid-stride /
+ * 1 block-contiguous; unroll 2|4|8|16 vectors of 16 B per lane per step; threads per workgroup. */
+int FLAGSTATS_hip_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads, uint32_t grid,
+                              int nt, int warmup, int reps, float* ms_total);
+
 #ifdef __cplusplus
 }
 #endif

@@ -556,4 +556,32 @@ int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warm
     return 0;
 }
 
+extern "C" hipError_t fsk_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads,
+                                      uint32_t grid, int nt, uint32_t* d_sink, hipStream_t stream);
+
+int FLAGSTATS_hip_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads, uint32_t grid,
+                              int nt, int warmup, int reps, float* ms_total)
+{
+    std::lock_guard<std::recursive_mutex> lk(g_mu);
+    if (!ms_total || reps < 1 || warmup < 0) return fail_msg("bad timing arguments");
+    int rc = bind();
+    if (rc) return rc;
+    hipStream_t s = g.stream[0];
+    rc = ensure_ws(g.ws[0], grid_for(0));
+    if (rc) return rc;
+    uint32_t* sink = (uint32_t*)g.ws[0].partials;
+    hipEvent_t e0, e1;
+    HIP_TRY(hipEventCreate(&e0));
+    HIP_TRY(hipEventCreate(&e1));
+    for (int i = 0; i < warmup; ++i) HIP_TRY(fsk_read_probe2(d_buf, bytes, mode, unroll, threads, grid, nt, sink, s));
+    HIP_TRY(hipEventRecord(e0, s));
+    for (int i = 0; i < reps; ++i) HIP_TRY(fsk_read_probe2(d_buf, bytes, mode, unroll, threads, grid, nt, sink, s));
+    HIP_TRY(hipEventRecord(e1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventElapsedTime(ms_total, e0, e1));
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return 0;
+}
+
 }  // extern "C"

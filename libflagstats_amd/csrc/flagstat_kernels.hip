@@ -459,20 +459,14 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     a.partials = d_partials;
     hipError_t e;
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
-    // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers
+    // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers.
+    // Only the combinations that mattered in the r01 sweeps are instantiated (profiles/r01/tune_*.log
+    // also list 2-7, 11, 17, which lost and were dropped).
     switch (variant & 31) {
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
-    case 2: e = launch_count_t<7, false, false, false>(a, stream); break;
-    case 3: e = launch_count_t<7, true, false, false>(a, stream); break;
-    case 4: e = launch_count_t<8, false, true, false>(a, stream); break;
-    case 5: e = launch_count_t<8, true, true, false>(a, stream); break;
-    case 6: e = launch_count_t<7, false, true, false>(a, stream); break;
-    case 7: e = launch_count_t<7, true, true, false>(a, stream); break;
     case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
-    case 11: e = launch_count_t<7, true, false, true>(a, stream); break;
     case 13: e = launch_count_t<8, true, true, true>(a, stream); break;
-    case 17: e = launch_count_t<8, true, false, false, true>(a, stream); break;
     case 25: e = launch_count_t<8, true, false, true, true>(a, stream); break;
     case 27: e = launch_count_t<7, true, false, true, true>(a, stream); break;
     default: return hipErrorInvalidValue;

@@ -1,0 +1,68 @@
+// flagstat_probe.hip -- measurement only: a parameterised read-only kernel used to map out which
+// access pattern the chip reads fastest (tools/probe_sweep.py).  Not on any product path.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "flagstat_device.h"
+
+namespace fsk {
+
+// MODE 0: grid-stride over steps of blockDim*UNROLL vectors, threads interleaved (u*blockDim + tid)
+// MODE 1: every workgroup streams its own contiguous region of nvec/gridDim vectors
+template <int UNROLL, bool NT, int MODE>
+__global__ void read_probe2(const uint4* __restrict__ a0, uint64_t nvec, uint32_t* __restrict__ sink)
+{
+    const uint64_t step = static_cast<uint64_t>(blockDim.x) * UNROLL;
+    uint64_t begin, end, stride;
+    if (MODE == 0) {
+        begin = blockIdx.x * step;
+        end = nvec - (nvec % step);
+        stride = gridDim.x * step;
+    } else {
+        const uint64_t per = (nvec / gridDim.x) - ((nvec / gridDim.x) % step);
+        begin = blockIdx.x * per;
+        end = begin + per;
+        stride = step;
+    }
+    uint32_t acc = 0;
+    for (uint64_t j = begin; j < end; j += stride) {
+        uint4 v[UNROLL];
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) v[u] = load_vec<NT>(a0 + j + static_cast<uint64_t>(u) * blockDim.x + threadIdx.x);
+#pragma unroll
+        for (int u = 0; u < UNROLL; ++u) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+    }
+    if (acc == 0x9E3779B9u) sink[0] = acc;
+}
+
+}  // namespace fsk
+
+template <int UNROLL>
+static void launch_u(int mode, int nt, uint32_t grid, uint32_t threads, const uint4* p, uint64_t nvec, uint32_t* sink,
+                     hipStream_t s)
+{
+    if (mode == 0) {
+        if (nt) hipLaunchKernelGGL((fsk::read_probe2<UNROLL, true, 0>), dim3(grid), dim3(threads), 0, s, p, nvec, sink);
+        else hipLaunchKernelGGL((fsk::read_probe2<UNROLL, false, 0>), dim3(grid), dim3(threads), 0, s, p, nvec, sink);
+    } else {
+        if (nt) hipLaunchKernelGGL((fsk::read_probe2<UNROLL, true, 1>), dim3(grid), dim3(threads), 0, s, p, nvec, sink);
+        else hipLaunchKernelGGL((fsk::read_probe2<UNROLL, false, 1>), dim3(grid), dim3(threads), 0, s, p, nvec, sink);
+    }
+}
+
+extern "C" hipError_t fsk_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads,
+                                      uint32_t grid, int nt, uint32_t* d_sink, hipStream_t stream)
+{
+    if ((reinterpret_cast<uintptr_t>(d_buf) & 15u) || grid == 0 || threads == 0 || threads > 1024 || (threads & 63u))
+        return hipErrorInvalidValue;
+    const uint4* p = reinterpret_cast<const uint4*>(d_buf);
+    const uint64_t nvec = bytes / 16;
+    switch (unroll) {
+    case 2: launch_u<2>(mode, nt, grid, threads, p, nvec, d_sink, stream); break;
+    case 4: launch_u<4>(mode, nt, grid, threads, p, nvec, d_sink, stream); break;
+    case 8: launch_u<8>(mode, nt, grid, threads, p, nvec, d_sink, stream); break;
+    case 16: launch_u<16>(mode, nt, grid, threads, p, nvec, d_sink, stream); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}

@@ -1,0 +1,62 @@
+"""GPU: randomized parity sweep -- random lengths, 2-byte offsets, input makers and launch
+geometries through the device entry, each checked bit-exactly against the oracle."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_random_lengths_offsets_geometries(hip):
+    import oracle
+    from libflagstats_amd import _lib, device
+    rs = np.random.RandomState(20261003)
+    cap = 3_000_000
+    buf = device.DeviceFlags(cap + 64)
+    old_v, old_b = hip.FLAGSTATS_hip_get(b"variant"), hip.FLAGSTATS_hip_get(b"blocks_per_cu")
+    try:
+        for it in range(150):
+            kind = int(rs.randint(0, 3))
+            mask = [0xFFFF, 0x0FFF, 0x00FF][rs.randint(0, 3)] if kind == 0 else int(rs.randint(0, 2))
+            seed = int(rs.randint(0, 2 ** 31))
+            first = int(rs.randint(0, 2 ** 40))
+            # lengths cluster around step (16384) and vector (8) boundaries as well as anywhere
+            pick = rs.randint(0, 4)
+            if pick == 0:
+                n = int(rs.randint(0, 64))
+            elif pick == 1:
+                n = int(16384 * rs.randint(0, 40) + rs.randint(-9, 10))
+            elif pick == 2:
+                n = int(8 * rs.randint(0, 5000) + rs.randint(-1, 2))
+            else:
+                n = int(rs.randint(0, cap))
+            n = max(0, min(n, cap))
+            off = int(rs.randint(0, 32))
+            _lib.check(hip.FLAGSTATS_hip_set(b"variant", int(rs.choice([1, 9, 25, 27, 13, 0]))), "variant")
+            _lib.check(hip.FLAGSTATS_hip_set(b"blocks_per_cu", int(rs.choice([1, 2, 3]))), "bpc")
+            buf.generate(kind, seed=seed, mask=mask, first_index=first, offset=off, n=n)
+            got = buf.count(offset=off, n=n)
+            want = oracle.flagstat_generated(kind, seed, mask, first, n, threads=4)
+            assert np.array_equal(got, want), (it, kind, mask, seed, first, n, off)
+    finally:
+        hip.FLAGSTATS_hip_set(b"variant", old_v)
+        hip.FLAGSTATS_hip_set(b"blocks_per_cu", old_b)
+        buf.free()
+
+
+def test_values_concentrated_on_single_categories(hip):
+    """Arrays made of ONE value each: every LUT entry of the front end is hit in isolation, for every
+    value of the 10 FLAG bits the rule reads (bits 4,5,12-15 are ignored, libflagstats.h:118-142)."""
+    import oracle
+    from libflagstats_amd import device
+    rel = [0, 1, 2, 3, 6, 7, 8, 9, 10, 11]
+    n = 4099
+    buf = device.DeviceFlags(n)
+    rs = np.random.RandomState(1)
+    for code in range(1024):
+        v = sum(((code >> i) & 1) << b for i, b in enumerate(rel)) | (int(rs.randint(0, 4)) << 4) | (int(rs.randint(0, 16)) << 12)
+        a = np.full(n, v, dtype=np.uint16)
+        buf.upload(a)
+        got = buf.count()
+        one = oracle.flagstat_c(a[:1])
+        assert np.array_equal(got, one * np.uint64(n)), hex(v)
+    buf.free()

@@ -5,8 +5,8 @@ mkdir -p gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 timeout 900 python bench.py > gpurun_out/bench.log 2>&1; echo "bench rc=$?" >> gpurun_out/bench.log
 tail -3 gpurun_out/bench.log
-# kernel trace + stats of the same command (CPU leg off: it adds nothing to the trace)
-timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 bench.py --steps 200 --warmup 20 --cpu-seconds 0 > gpurun_out/prof_trace.log 2>&1
+# kernel trace + stats of the SAME command (default arguments)
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_trace -- python3 bench.py > gpurun_out/prof_trace.log 2>&1
 echo "trace rc=$?"
 find gpurun_out/prof_trace -name "*kernel_stats.csv" | head -1 | xargs cat | head -20
 # PMC passes, each on its own (no trace domains combined with --pmc)
