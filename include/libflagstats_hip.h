@@ -77,6 +77,7 @@ int FLAGSTATS_hip_device_id(void);          /* device the context is bound to, -
 int FLAGSTATS_hip_compute_units(void);      /* CU count of that device, -1 before init */
 
 /* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _CHUNK_FLAGS):
+ * "fuse" (0 = K1 + K2, default; 1 = K1 finalises itself, one kernel per call),
  * key = "blocks_per_cu" | "variant" (bit0 non-temporal loads, bit1 chain depth 7, bit2 register prefetch, bit3 interleaved waves) | "chunk_flags".  Returns 0 on success. */
 int FLAGSTATS_hip_set(const char* key, uint64_t value);
 uint64_t FLAGSTATS_hip_get(const char* key);

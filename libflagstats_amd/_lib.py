@@ -77,11 +77,36 @@ class FlagstatsHipError(RuntimeError):
     """The GPU path failed; there is no CPU fallback to hide it."""
 
 
+def _share_hip_runtime_with_torch() -> None:
+    """PyTorch-ROCm wheels bundle their own libamdhip64; a process must not end up with torch
+    bound to a different HIP runtime than the one that is already loaded.  If torch is installed
+    but not imported yet, load ITS runtime first (by SONAME both then resolve to the same copy);
+    importing torch later then works in either order.  No torch: the system runtime is used."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules or os.environ.get("FLAGSTATS_HIP_SYSTEM_RUNTIME"):
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        return
+    if not spec or not spec.submodule_search_locations:
+        return
+    cand = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            ctypes.CDLL(cand, mode=ctypes.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib() -> ctypes.CDLL:
     """Load libflagstats_hip.so (once) and attach the prototypes."""
     global _lib
     if _lib is not None:
         return _lib
+    _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):
         raise ImportError(
             f"{LIB_PATH} is missing: the HIP extension has not been built. Run "

@@ -30,6 +30,7 @@ struct Ctx {
     int cus = 0;
     uint32_t blocks_per_cu = 0;  // 0 = auto
     int variant = 25;                    // DEPTH 8, nt loads, interleaved waves, rolling re-issue (tools/tune.py)
+    int fuse = 0;                        // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
     uint64_t chunk_flags = 32ull << 20;  // host streaming chunk: 32 Mi flags = 64 MiB
     hipStream_t stream[2] = {nullptr, nullptr};
     Workspace ws[2];
@@ -88,6 +89,7 @@ int ensure_ws(Workspace& w, uint32_t grid)
     w.partials = nullptr;
     w.grid_cap = 0;
     HIP_TRY(hipMalloc(&w.partials, fsk_partials_bytes(grid)));
+    HIP_TRY(hipMemset(w.partials, 0, fsk_partials_bytes(grid)));  // the ticket word must start at 0
     w.grid_cap = grid;
     return 0;
 }
@@ -117,6 +119,7 @@ int init_locked(int device)
     g.blocks_per_cu = (uint32_t)env_u64("FLAGSTATS_HIP_BLOCKS_PER_CU", g.blocks_per_cu);
     g.variant = (int)env_u64("FLAGSTATS_HIP_VARIANT", (uint64_t)g.variant);
     g.chunk_flags = env_u64("FLAGSTATS_HIP_CHUNK_FLAGS", g.chunk_flags);
+    g.fuse = (int)env_u64("FLAGSTATS_HIP_FUSE", (uint64_t)g.fuse);
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&g.stream[i], hipStreamNonBlocking));
         HIP_TRY(hipMalloc(&g.d_out[i], 32 * sizeof(uint64_t)));
@@ -157,7 +160,8 @@ int count_device_async(const uint16_t* d_array, uint64_t n, uint64_t* d_out, hip
     if (op == OP_POSPOPCNT)
         HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s));
     else
-        HIP_TRY(fsk_launch(d_array, n, grid, g.variant | (op == OP_FLAGSTAT_STORE ? 256 : 0), w.partials, d_out, s));
+        HIP_TRY(fsk_launch(d_array, n, grid, g.variant | (op == OP_FLAGSTAT_STORE ? 256 : 0) | (g.fuse ? 512 : 0), w.partials,
+                           reinterpret_cast<uint32_t*>(w.partials + (size_t)w.grid_cap * fsk::kInternal), d_out, s));
     return 0;
 }
 
@@ -279,10 +283,12 @@ void FLAGSTATS_hip_shutdown(void)
         if (g.pinned[i]) (void)hipHostFree(g.pinned[i]);
     const uint32_t bpc = g.blocks_per_cu;
     const int variant = g.variant;
+    const int fuse = g.fuse;
     const uint64_t chunk = g.chunk_flags;
     g = Ctx();
     g.blocks_per_cu = bpc;
     g.variant = variant;
+    g.fuse = fuse;
     g.chunk_flags = chunk;
 }
 
@@ -310,6 +316,9 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
     } else if (!std::strcmp(key, "variant")) {
         if (value > 31) return fail_msg("variant must be 0..31");
         g.variant = (int)value;
+    } else if (!std::strcmp(key, "fuse")) {
+        if (value > 1) return fail_msg("fuse must be 0 or 1");
+        g.fuse = (int)value;
     } else if (!std::strcmp(key, "chunk_flags")) {
         if (value < 8) return fail_msg("chunk_flags must be >= 8");
         g.chunk_flags = value;
@@ -326,6 +335,7 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "blocks_per_cu")) return g.blocks_per_cu ? g.blocks_per_cu : 1;
     if (!std::strcmp(key, "variant")) return (uint64_t)g.variant;
     if (!std::strcmp(key, "chunk_flags")) return g.chunk_flags;
+    if (!std::strcmp(key, "fuse")) return (uint64_t)g.fuse;
     if (!std::strcmp(key, "grid")) return g.ready ? grid_for(0) : 0;
     return 0;
 }

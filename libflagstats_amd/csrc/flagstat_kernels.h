@@ -20,7 +20,10 @@ struct CountArgs {
     uint64_t fast_begin;   // steps in [fast_begin, fast_end) are fully in range
     uint64_t fast_end;
     uint32_t grid;
-    uint64_t* partials;    // [grid][kInternal]
+    uint64_t* partials;    // [kInternal][grid]
+    uint32_t* ticket;      // non-null: fused finalise by the last-arriving workgroup (must be 0 at launch)
+    uint64_t* out;         // device uint64[32]
+    int store;             // 0: out += counters, 1: out = counters
 };
 
 }  // namespace fsk
@@ -29,8 +32,9 @@ extern "C" {
 // bytes of workspace K1 needs for `grid` workgroups
 size_t fsk_partials_bytes(uint32_t grid);
 // K1 + K2 on `stream`: d_out32[32] += counters of d_array[0..n).  Asynchronous.
+// variant bits 0-4: K1 schedule; bit 8: store instead of accumulate; bit 9: fused finalise (needs d_ticket)
 hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
-                      uint64_t* d_out32, hipStream_t stream);
+                      uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream);
 // positional popcount (flagstat_pospopcnt.hip): d_out16[16] += bit counts.  d_partials as for fsk_launch.
 hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, uint32_t grid, uint64_t* d_partials,
                                 uint64_t* d_out16, hipStream_t stream);

@@ -237,6 +237,29 @@ __device__ __forceinline__ void flush(Lane<DEPTH>& s)
     for (int j = 0; j < DEPTH; ++j) s.tA[j] = s.tB[j] = s.fA[j] = s.fB[j] = s.sA[j] = s.sB[j] = 0;
 }
 
+// Map the 19 internal totals to the reference's 32 slots (index = FLAGSTAT_*_OFF,
+// libflagstats.h:69-112; +16 for fail-QC) and add them to / store them in out[32].
+// Called by the first 32 threads of a workgroup after tot[] is complete.
+__device__ __forceinline__ void finalize_slots(const uint64_t* tot, uint64_t* __restrict__ out, int store)
+{
+    if (threadIdx.x < 32) {
+        // reference slot -> internal T index (secondary, n_pair_good, unmap, supplementary,
+        // n_sgltn, n_pair_map, read1, read2), -1 = slot has no T/F counter
+        const int t_of_slot[16] = {-1, -1, 2, -1, -1, -1, 6, 7, 0, -1, -1, 3, 1, 4, 5, -1};
+        const uint32_t slot = threadIdx.x & 15u;
+        const bool fail = threadIdx.x >= 16;
+        uint64_t add = 0;
+        const int t = t_of_slot[slot];
+        if (t >= 0) add = fail ? tot[8 + t] : tot[t] - tot[8 + t];  // pass-QC = all - fail
+        if (slot == 10) add = fail ? tot[18] : tot[17];              // DUP: fail / pass
+        if (slot == 9 && fail) add = tot[16] + tot[18];              // fail-QC read count (slot 25)
+        if (store)
+            out[threadIdx.x] = add;        // "=" form: all 32 slots written, dead slots as 0
+        else if (add)
+            out[threadIdx.x] += add;       // reference contract: accumulate, never touch dead slots
+    }
+}
+
 // ------------------------------------------------------------------ K1
 // USTRIDE = vectors between a lane's consecutive loads: 64 -> each wave owns a contiguous
 // 8 KiB of the step; 256 -> the 4 waves interleave at 1 KiB (each load instruction of the
@@ -274,7 +297,8 @@ __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnrol
 template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, bool ROLL>
 __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
-                                                           uint64_t* __restrict__ partials)
+                                                           uint64_t* __restrict__ partials, uint32_t* ticket,
+                                                           uint64_t* out, int store)
 {
     Lane<DEPTH> s;
     lane_init(s);
@@ -354,8 +378,46 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
         uint64_t sum = 0;
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) sum += red[w][threadIdx.x];
-        partials[static_cast<uint64_t>(threadIdx.x) * gridDim.x + blockIdx.x] = sum;  // [counter][block]
+        // [counter][block]; write-through (sc1) so the finalising workgroup -- on whichever XCD -- sees it
+        __hip_atomic_store(&partials[static_cast<uint64_t>(threadIdx.x) * gridDim.x + blockIdx.x], sum, __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
     }
+    if (ticket == nullptr) return;  // two-kernel form: K2 (flagstat_finalize) sums the partials
+
+    // Fused form ("one HIP kernel", BASELINE config 1): the workgroup that draws the last ticket
+    // finalises.  Hand-off per the CDNA guide's counter recipe: every storing wave drains its
+    // stores, workgroup barrier, ONE lane: agent-scope release -> drain -> relaxed agent ticket add;
+    // the last arriver: agent-scope acquire -> drain -> barrier -> sc1 (atomic) loads of the partials.
+    // Correct for any placement of workgroups on XCDs; `ticket` is zero before the first launch
+    // and reset here for the next one (launches sharing a workspace are stream-ordered).
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __shared__ uint32_t is_last;
+    __shared__ uint64_t tot[32];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const uint32_t t = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t last = (t == gridDim.x - 1) ? 1u : 0u;
+        if (last) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        is_last = last;
+    }
+    __syncthreads();
+    if (!is_last) return;
+    for (uint32_t c = wave; c < kInternal; c += kThreads / 64) {
+        uint64_t x = 0;
+        for (uint32_t b = lane; b < gridDim.x; b += 64)
+            x += __hip_atomic_load(&partials[static_cast<uint64_t>(c) * gridDim.x + b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+        if (lane == 0) tot[c] = x;
+    }
+    __syncthreads();
+    finalize_slots(tot, out, store);
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------ read probe
@@ -403,41 +465,28 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
         if (lane == 0) tot[c] = x;
     }
     __syncthreads();
-    if (threadIdx.x < 32) {
-        // reference slot -> internal T index (secondary, n_pair_good, unmap, supplementary,
-        // n_sgltn, n_pair_map, read1, read2), -1 = slot has no T/F counter
-        const int t_of_slot[16] = {-1, -1, 2, -1, -1, -1, 6, 7, 0, -1, -1, 3, 1, 4, 5, -1};
-        const uint32_t slot = threadIdx.x & 15u;
-        const bool fail = threadIdx.x >= 16;
-        uint64_t add = 0;
-        const int t = t_of_slot[slot];
-        if (t >= 0) add = fail ? tot[8 + t] : tot[t] - tot[8 + t];  // pass-QC = all - fail
-        if (slot == 10) add = fail ? tot[18] : tot[17];              // DUP: fail / pass
-        if (slot == 9 && fail) add = tot[16] + tot[18];              // fail-QC read count (slot 25)
-        if (store)
-            out[threadIdx.x] = add;        // "=" form: all 32 slots written, dead slots as 0
-        else if (add)
-            out[threadIdx.x] += add;       // reference contract: accumulate, never touch dead slots
-    }
+    finalize_slots(tot, out, store);
 }
 
 }  // namespace fsk
 
 // ------------------------------------------------------------------ launchers
-extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t); }
+// partials[19][grid] followed by a 256-byte block holding the hand-off ticket
+extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 256; }
 
 template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, bool ROLL = false>
 static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
     hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, ROLL>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
-                       reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials);
+                       reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials,
+                       a.ticket, a.out, a.store);
     return hipGetLastError();
 }
 
 // Host-side geometry: everything the kernel assumes is derived here from
 // (pointer, n) so operand shapes and the grid cannot disagree.
 extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
-                                 uint64_t* d_out32, hipStream_t stream)
+                                 uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream)
 {
     if (n == 0) return hipSuccess;
     if (grid == 0 || d_array == nullptr || d_partials == nullptr || d_out32 == nullptr) return hipErrorInvalidValue;
@@ -457,6 +506,10 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     if (static_cast<uint64_t>(grid) > a.nsteps) grid = static_cast<uint32_t>(a.nsteps);
     a.grid = grid;
     a.partials = d_partials;
+    a.store = (variant >> 8) & 1;                        // bit 8 of `variant`: store instead of accumulate
+    a.ticket = ((variant >> 9) & 1) ? d_ticket : nullptr;  // bit 9: fused finalise inside K1
+    a.out = d_out32;
+    if (((variant >> 9) & 1) && d_ticket == nullptr) return hipErrorInvalidValue;
     hipError_t e;
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
     // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers.
@@ -472,8 +525,9 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
+    if (a.ticket) return hipSuccess;  // K1 finalised by itself
     hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kFinalizeThreads), 0, stream, d_partials, grid, d_out32,
-                       (variant >> 8) & 1);  // bit 8 of `variant`: store instead of accumulate
+                       a.store);
     return hipGetLastError();
 }
 

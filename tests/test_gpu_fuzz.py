@@ -13,6 +13,7 @@ def test_random_lengths_offsets_geometries(hip):
     cap = 3_000_000
     buf = device.DeviceFlags(cap + 64)
     old_v, old_b = hip.FLAGSTATS_hip_get(b"variant"), hip.FLAGSTATS_hip_get(b"blocks_per_cu")
+    old_f = hip.FLAGSTATS_hip_get(b"fuse")
     try:
         for it in range(150):
             kind = int(rs.randint(0, 3))
@@ -33,6 +34,7 @@ def test_random_lengths_offsets_geometries(hip):
             off = int(rs.randint(0, 32))
             _lib.check(hip.FLAGSTATS_hip_set(b"variant", int(rs.choice([1, 9, 25, 27, 13, 0]))), "variant")
             _lib.check(hip.FLAGSTATS_hip_set(b"blocks_per_cu", int(rs.choice([1, 2, 3]))), "bpc")
+            _lib.check(hip.FLAGSTATS_hip_set(b"fuse", int(rs.randint(0, 2))), "fuse")  # K1+K2 or K1 finalising itself
             buf.generate(kind, seed=seed, mask=mask, first_index=first, offset=off, n=n)
             got = buf.count(offset=off, n=n)
             want = oracle.flagstat_generated(kind, seed, mask, first, n, threads=4)
@@ -40,6 +42,7 @@ def test_random_lengths_offsets_geometries(hip):
     finally:
         hip.FLAGSTATS_hip_set(b"variant", old_v)
         hip.FLAGSTATS_hip_set(b"blocks_per_cu", old_b)
+        hip.FLAGSTATS_hip_set(b"fuse", old_f)
         buf.free()
 
 
@@ -60,3 +63,37 @@ def test_values_concentrated_on_single_categories(hip):
         one = oracle.flagstat_c(a[:1])
         assert np.array_equal(got, one * np.uint64(n)), hex(v)
     buf.free()
+
+
+@pytest.mark.parametrize("fuse", [0, 1])
+def test_back_to_back_launches_same_workspace(hip, fuse):
+    """Many launches of very different sizes on one stream and one workspace: with fuse=1 the
+    last-arriving workgroup finalises and re-arms the ticket for the next launch; the accumulated
+    device counters must equal the sum of the oracle's, and a final store-form call must overwrite."""
+    import torch
+
+    import oracle
+    from libflagstats_amd import _lib, device
+    old = hip.FLAGSTATS_hip_get(b"fuse")
+    _lib.check(hip.FLAGSTATS_hip_set(b"fuse", fuse), "fuse")
+    try:
+        n = 50_000_000
+        t = torch.empty(n, dtype=torch.int16, device="cuda:0")
+        device.generate_torch(t, device.GEN_UNIFORM, seed=4242, mask=0xFFFF)
+        host = oracle.generate(oracle.GEN_UNIFORM, 4242, 0xFFFF, 0, n)
+        rs = np.random.RandomState(9)
+        out = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+        want = np.zeros(32, dtype=np.uint64)
+        for i in range(300):                      # no host sync between launches
+            a = int(rs.randint(0, n - 1))
+            m = int(rs.choice([1, 7, 300, 16384, 70000, 3_000_000, 20_000_000]))
+            m = min(m, n - a)
+            device.count_torch(t[a:a + m], out)
+            want += oracle.flagstat_hist(host[a:a + m])
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+        device.count_torch(t[5:1005], out, store=True)
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), oracle.flagstat_hist(host[5:1005]))
+    finally:
+        hip.FLAGSTATS_hip_set(b"fuse", old)

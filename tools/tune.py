@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--kind", type=int, default=0)
     ap.add_argument("--probe", action="store_true")
+    ap.add_argument("--fuse", default="0", help="comma list of fuse modes to compare (0 = K1+K2, 1 = K1 finalises)")
     args = ap.parse_args()
     lib = _lib.lib()
     _lib.check(lib.FLAGSTATS_hip_init(0), "init")
@@ -31,10 +32,14 @@ def main():
     res = {}
     variants = [int(v) for v in args.variants.split(",")]
     bpcs = [int(v) for v in args.bpc.split(",")]
+    fuses = [int(f) for f in args.fuse.split(",")]
     for r in range(args.rounds):
+      for fz in fuses:
+        lib.FLAGSTATS_hip_set(b"fuse", fz)
         for v in variants:
             for b in bpcs:
-                lib.FLAGSTATS_hip_set(b"variant", v)
+                v = v % 1000 + 1000 * fz
+                lib.FLAGSTATS_hip_set(b"variant", v % 1000)
                 lib.FLAGSTATS_hip_set(b"blocks_per_cu", b)
                 ms, _ = device.time_device_ptr(d.ptr, n, 1, args.reps)
                 res.setdefault((v, b), []).append(ms / args.reps)
