@@ -76,9 +76,14 @@ const char* FLAGSTATS_hip_last_error(void); /* text of the last failure on this 
 int FLAGSTATS_hip_device_id(void);          /* device the context is bound to, -1 before init */
 int FLAGSTATS_hip_compute_units(void);      /* CU count of that device, -1 before init */
 
-/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _CHUNK_FLAGS):
- * "fuse" (0 = K1 + K2, default; 1 = K1 finalises itself, one kernel per call),
- * key = "blocks_per_cu" | "variant" (bit0 non-temporal loads, bit1 chain depth 7, bit2 register prefetch, bit3 interleaved waves) | "chunk_flags".  Returns 0 on success. */
+/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _CHUNK_FLAGS).  key =
+ *   "blocks_per_cu"  workgroups per CU of K1's grid (default 1)
+ *   "variant"        K1 schedule: bit0 non-temporal loads, bit1 chain depth 7, bit2 register
+ *                    prefetch, bit3 interleaved waves, bit4 rolling re-issue (default 25;
+ *                    instantiated: 0, 1, 9, 13, 25, 27)
+ *   "fuse"           0 = K1 + K2 (default); 1 = K1 finalises itself, one kernel per call
+ *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB)
+ * Returns 0 on success. */
 int FLAGSTATS_hip_set(const char* key, uint64_t value);
 uint64_t FLAGSTATS_hip_get(const char* key);
 

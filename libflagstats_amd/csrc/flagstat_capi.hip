@@ -188,6 +188,19 @@ int count_host(const uint16_t* h, uint64_t n, uint64_t* out, int op = OP_FLAGSTA
     int rc = ensure_stage(n < chunk ? n : chunk);
     if (rc) return rc;
     const int slots = (n > chunk) ? 2 : 1;
+    if (slots == 1 && op == OP_FLAGSTAT) {
+        // latency path (what an unmodified per-block caller of the reference hits, e.g. 512,000 flags
+        // per call, benchmark/flagstats.cpp:328-329): one copy, K1, and K2 STORING straight into the
+        // pinned host result buffer -- no counter memset, no D2H copy
+        uint64_t* h_out_dev = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_out_dev), g.h_out, 0));
+        HIP_TRY(hipMemcpyAsync(g.stage[0], h, n * sizeof(uint16_t), hipMemcpyHostToDevice, g.stream[0]));
+        rc = count_device_async(g.stage[0], n, h_out_dev, g.stream[0], g.ws[0], OP_FLAGSTAT_STORE);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(g.stream[0]));
+        for (int s = 0; s < 32; ++s) out[s] += g.h_out[s];
+        return 0;
+    }
     for (int i = 0; i < slots; ++i) HIP_TRY(hipMemsetAsync(g.d_out[i], 0, 32 * sizeof(uint64_t), g.stream[i]));
     uint64_t done = 0;
     for (uint64_t k = 0; done < n; ++k) {
