@@ -138,9 +138,36 @@ __device__ __forceinline__ void chain_push(Lane<DEPTH>& s, uint32_t blk, uint32_
 // ROLL: as soon as vector u has been copied out of its registers, the same registers are
 // re-issued for vector u of the lane's NEXT step (`next`, stride USTRIDE vectors), so a wave
 // keeps ~8 loads in flight through the whole step without a second register buffer.
-template <int DEPTH, bool ROLL, bool NT, int USTRIDE>
-__device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t blk, const uint4* __restrict__ next)
+// LDS staging (STAGE == 2): where a wave's ring of 16 x 1 KiB slots lives
+struct LdsStage {
+    const uint4* lane;   // this lane's 16 bytes of slot 0 of the wave's ring (slot i: lane + i*64)
+    uint32_t slot0;      // LDS byte address of the first slot this step reads (wave-uniform)
+    uint32_t first;      // index of that slot in the ring (0 or 8)
+};
+
+// one 1 KiB LDS-DMA piece: 64 lanes x 16 B from per-lane global addresses to LDS [m0, m0 + 1 KiB)
+template <bool NT>
+__device__ __forceinline__ void lds_dma16(const uint4* gsrc, uint32_t lds_dst)
 {
+    uint32_t keep;
+    const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    if constexpr (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+
+// STAGE 0: vectors are in v[].  1 (rolling registers): see below.  2 (LDS ring, north_star's
+// "stage into LDS"): the vector is read from the wave's LDS slot (ds_read_b128) once the LDS-DMA
+// that filled it has landed -- 15 younger DMAs are always in flight behind it, hence vmcnt(15) --
+// and the slot is immediately re-targeted by the DMA for the lane's step after next.
+template <int DEPTH, int STAGE, bool NT, int USTRIDE>
+__device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t blk, const uint4* __restrict__ next,
+                                     LdsStage lds = LdsStage{nullptr, 0, 0})
+{
+    constexpr bool ROLL = (STAGE == 1);
     uint32_t t8a = 0, t8b = 0, f8a = 0, f8b = 0, s4a = 0, s4b = 0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -151,7 +178,16 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
             uint32_t T[4], F[4], S[2];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                uint4 x = v[half * 4 + q * 2 + k];
+                uint4 x;
+                if constexpr (STAGE == 2) {
+                    const int u = half * 4 + q * 2 + k;  // a constant after unrolling
+                    asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
+                    x = lds.lane[(lds.first + u) * 64];
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot has been read: it may be refilled
+                    lds_dma16<NT>(next + u * USTRIDE, lds.slot0 + u * 1024);
+                } else {
+                    x = v[half * 4 + q * 2 + k];
+                }
                 if constexpr (ROLL) {
                     // Copy the vector out with real v_movs HERE (a load may land at any time, so the
                     // registers it targets must be dead first), then re-issue into the same registers.
@@ -278,11 +314,11 @@ __device__ __forceinline__ void load_step(uint4 (&v)[kUnroll], const uint4* __re
     }
 }
 
-template <int DEPTH, bool ROLL = false, bool NT = false, int USTRIDE = 64>
+template <int DEPTH, int STAGE = 0, bool NT = false, int USTRIDE = 64>
 __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t& blk,
-                                               const uint4* __restrict__ next = nullptr)
+                                               const uint4* __restrict__ next = nullptr, LdsStage lds = LdsStage{nullptr, 0, 0})
 {
-    step<DEPTH, ROLL, NT, USTRIDE>(s, v, blk, next);
+    step<DEPTH, STAGE, NT, USTRIDE>(s, v, blk, next, lds);
     ++blk;
     if (blk == (1u << DEPTH) - 1u) {
         flush(s);
@@ -294,7 +330,7 @@ __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnrol
 // waves of the SIMD only.  PREFETCH = true: two register buffers, the loads of
 // step k+1 are in flight while step k is computed (one more 8 KiB per wave in
 // flight, +32 VGPRs).
-template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, bool ROLL>
+template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE>
 __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
                                                            uint64_t* __restrict__ partials, uint32_t* ticket,
@@ -311,6 +347,7 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
     const uint64_t G = gridDim.x;
     uint32_t blk = 0;
 
+    constexpr bool ROLL = (STAGE != 0);
     if constexpr (ROLL) {
         // ragged edge steps (at most the first and the last of the whole array) go through the
         // guarded loader, outside the pipelined loop
@@ -327,20 +364,44 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
         // first fully in-range step of this workgroup
         uint64_t st = blockIdx.x;
         if (st < fast_begin) st += G;  // fast_begin is 0 or 1
-        if (st < fast_end) {
-            uint4 v[kUnroll];
-            const uint4* p = a0 + st * kVecPerStep + lane_off;
-            // issue order = consumption order, so the loop-top wait can be vmcnt(7), not vmcnt(0)
+        if constexpr (STAGE == 1) {
+            if (st < fast_end) {
+                uint4 v[kUnroll];
+                const uint4* p = a0 + st * kVecPerStep + lane_off;
+                // issue order = consumption order, so the loop-top wait can be vmcnt(7), not vmcnt(0)
 #pragma unroll
-            for (int u = 0; u < kUnroll; ++u) {
-                v[u] = load_vec<NT>(p + u * US);
-                __builtin_amdgcn_sched_barrier(0);
+                for (int u = 0; u < kUnroll; ++u) {
+                    v[u] = load_vec<NT>(p + u * US);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                for (; st + G < fast_end; st += G) {
+                    p += G * kVecPerStep;
+                    step_and_count<DEPTH, 1, NT, US>(s, v, blk, p);
+                }
+                step_and_count(s, v, blk);
             }
-            for (; st + G < fast_end; st += G) {
-                p += G * kVecPerStep;
-                step_and_count<DEPTH, true, NT, US>(s, v, blk, p);
+        } else {
+            // LDS ring: 16 slots of 1 KiB per wave (two steps); slot (k & 1) * 8 + u holds vector u of
+            // the wave's k-th step.  DMAs for steps that do not exist re-read the current step (their
+            // data is never consumed) so that exactly 15 DMAs are younger than the one being waited for.
+            __shared__ uint4 ring[kThreads / 64][16][64];
+            if (st < fast_end) {
+                const uint4* lane_ptr = &ring[wave][0][lane];
+                const uint32_t wave_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>(&ring[wave][0][0]));
+                auto ptr = [&](uint64_t sx) { return a0 + (sx < fast_end ? sx : st) * kVecPerStep + lane_off; };
+                uint4 dummy[kUnroll];
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) lds_dma16<NT>(ptr(st) + u * US, wave_base + u * 1024);
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) lds_dma16<NT>(ptr(st + G) + u * US, wave_base + (8 + u) * 1024);
+                uint32_t par = 0;
+                for (; st < fast_end; st += G) {
+                    const uint4* p2 = ptr(st + 2 * G);
+                    step_and_count<DEPTH, 2, NT, US>(s, dummy, blk, p2, LdsStage{lane_ptr, wave_base + par * 8192, par * 8});
+                    par ^= 1u;
+                }
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // drain the DMAs nobody consumes
             }
-            step_and_count(s, v, blk);
         }
     } else if constexpr (!PREFETCH) {
         for (uint64_t st = blockIdx.x; st < nsteps; st += G) {
@@ -474,10 +535,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
 // partials[19][grid] followed by a 256-byte block holding the hand-off ticket
 extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 256; }
 
-template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, bool ROLL = false>
+template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE = 0>
 static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, ROLL>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
+    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, STAGE>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials,
                        a.ticket, a.out, a.store);
     return hipGetLastError();
@@ -512,16 +573,18 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     if (((variant >> 9) & 1) && d_ticket == nullptr) return hipErrorInvalidValue;
     hipError_t e;
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
-    // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers.
+    // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers,
+    // 32 = staging through a per-wave LDS ring filled by LDS-DMA.
     // Only the combinations that mattered in the r01 sweeps are instantiated (profiles/r01/tune_*.log
     // also list 2-7, 11, 17, which lost and were dropped).
-    switch (variant & 31) {
+    switch (variant & 63) {
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
     case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
     case 13: e = launch_count_t<8, true, true, true>(a, stream); break;
-    case 25: e = launch_count_t<8, true, false, true, true>(a, stream); break;
-    case 27: e = launch_count_t<7, true, false, true, true>(a, stream); break;
+    case 25: e = launch_count_t<8, true, false, true, 1>(a, stream); break;
+    case 27: e = launch_count_t<7, true, false, true, 1>(a, stream); break;
+    case 41: e = launch_count_t<8, true, false, true, 2>(a, stream); break;  // bit 5: LDS-DMA ring instead of registers
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
