@@ -133,6 +133,10 @@ def main():
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --flags-per-gpu is the TOTAL array, split into contiguous shards over the ranks "
                          "(default is weak scaling: every rank holds its own --flags-per-gpu shard)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl = RCCL over xGMI (default)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="TEST ONLY: put every rank on GPU 0 (use with --backend gloo) to exercise the multi-rank "
+                         "launch contract on a single-GPU box; the number it prints is not a scaling result")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 step (store + RCCL all-reduce) even at world size 1: exercises the multi-GPU "
                          "code path on a single-GPU box")
@@ -154,6 +158,8 @@ def main():
     from libflagstats_amd import _lib, device
     from libflagstats_amd.dist import allreduce_counters
 
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = _lib.lib()
@@ -162,7 +168,10 @@ def main():
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
 
     n = args.flags_per_gpu
     if args.strong:

@@ -4,7 +4,7 @@
  *
  * Plain C, plain pointers and sizes; no HIP or torch types in any signature
  * (streams travel as void*).  Every symbol below is exported by
- * libflagstats_amd/libflagstats_hip.so (tests/test_capi_symbols.py checks that).
+ * libflagstats_amd/libflagstats_hip.so (tests/test_host_logic.py checks that).
  *
  * Semantics (all entry points): counters follow the reference's FLAGSTAT_scalar
  * exactly (libflagstats.h:118-142, :170-176): 32 slots, [0..15] pass-QC,
