@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--kind", type=int, default=0)
     ap.add_argument("--probe", action="store_true")
+    ap.add_argument("--pospopcnt", action="store_true", help="also time the positional-popcount op (row f4)")
     ap.add_argument("--fuse", default="0", help="comma list of fuse modes to compare (0 = K1+K2, 1 = K1 finalises)")
     args = ap.parse_args()
     lib = _lib.lib()
@@ -47,6 +48,21 @@ def main():
     for (v, b), t in sorted(res.items()):
         med, mn = statistics.median(t), min(t)
         print("%7d %3d  %9.4f %8.4f  %8.3f  %8.3f" % (v, b, med, mn, 2 * n / med / 1e9, 2 * n / mn / 1e9))
+    if args.pospopcnt:
+        import torch
+        t = torch.empty(0)  # noqa: F841  (torch only for the stream-ordered device entry below)
+        out = device.DeviceFlags(64)
+        ts = []
+        import time
+        for r in range(args.rounds):
+            _lib.check(lib.FLAGSTATS_hip_synchronize(), "sync")
+            t0 = time.perf_counter()
+            for _ in range(args.reps):
+                _lib.check(lib.FLAGSTATS_hip_device_pospopcnt_u16(d.ptr, n, out.ptr, None), "pospopcnt")
+            _lib.check(lib.FLAGSTATS_hip_synchronize(), "sync")
+            ts.append((time.perf_counter() - t0) * 1e3 / args.reps)
+        med = statistics.median(ts)
+        print("pospopcnt_u16: median %.4f ms  %.3f TB/s" % (med, 2 * n / med / 1e9))
     if args.probe:
         print("read probe: nt bpc median_ms TB/s")
         for nt in (0, 1):
