@@ -129,6 +129,25 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
  * LZ4_decompress_safe, benchmark/flagstats.cpp:316): returns decoded bytes, < 0 on malformed input */
 int64_t FLAGSTATS_lz4_block_decode(const void* src, uint64_t srclen, void* dst, uint64_t dstcap);
 
+/* ---- streaming sessions: for callers that keep their own per-block loop and accumulate into one
+ * counter array read after the loop, as benchmark/flagstats.cpp:304,311-342 does.  The caller decodes
+ * straight into pinned memory handed out by `acquire` (zero copy) and `commit`s; copies and kernels
+ * run behind it; `finish` waits and adds the counters of everything committed since the last finish.
+ *   FLAGSTATS_hip_stream* s = FLAGSTATS_hip_stream_open();
+ *   for each block: uint16_t* p = FLAGSTATS_hip_stream_acquire(s, N);  decode N flags into p;
+ *                   FLAGSTATS_hip_stream_commit(s, N);
+ *   FLAGSTATS_hip_stream_finish(s, counters);  FLAGSTATS_hip_stream_close(s);
+ * `push` = acquire + memcpy + commit for callers that cannot decode in place.  A block may not
+ * exceed the chunk size (knob "chunk_flags").  The pointer from `acquire` is valid until `commit`. */
+typedef struct FLAGSTATS_hip_stream FLAGSTATS_hip_stream;
+FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void);                       /* NULL on failure */
+uint16_t* FLAGSTATS_hip_stream_acquire(FLAGSTATS_hip_stream* s, uint64_t n); /* room for n flags; NULL on failure */
+int FLAGSTATS_hip_stream_commit(FLAGSTATS_hip_stream* s, uint64_t n);        /* n <= the acquired size */
+int FLAGSTATS_hip_stream_push(FLAGSTATS_hip_stream* s, const uint16_t* array, uint64_t n);
+int FLAGSTATS_hip_stream_finish(FLAGSTATS_hip_stream* s, uint64_t* out);     /* out[32] += counters; session reusable */
+uint64_t FLAGSTATS_hip_stream_flags(const FLAGSTATS_hip_stream* s);          /* flags committed since the last finish */
+void FLAGSTATS_hip_stream_close(FLAGSTATS_hip_stream* s);
+
 /* ---- plain 16-bit positional popcount ----
  * replaces: `static int STORM_pospopcnt_u16(const uint16_t* data, size_t len, uint32_t* out)`
  * python/libalgebra.h:3496-3551 -- out[16] is ZEROED first (:3497), then out[j] = number of words

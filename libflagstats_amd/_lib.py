@@ -59,6 +59,13 @@ SIGNATURES = {
                                                     ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_file_raw": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_lz4_block_decode": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]),
+    "FLAGSTATS_hip_stream_open": (ctypes.c_void_p, []),
+    "FLAGSTATS_hip_stream_acquire": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_uint64]),
+    "FLAGSTATS_hip_stream_commit": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64]),
+    "FLAGSTATS_hip_stream_push": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64]),
+    "FLAGSTATS_hip_stream_finish": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p]),
+    "FLAGSTATS_hip_stream_flags": (ctypes.c_uint64, [ctypes.c_void_p]),
+    "FLAGSTATS_hip_stream_close": (None, [ctypes.c_void_p]),
     "STORM_pospopcnt_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]),
     "FLAGSTATS_hip_pospopcnt_u16_x64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
     "FLAGSTATS_hip_device_pospopcnt_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p,

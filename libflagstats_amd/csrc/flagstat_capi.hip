@@ -235,6 +235,7 @@ hipStream_t stream(int slot) { return g.stream[slot]; }
 uint64_t* dev_out(int slot) { return g.d_out[slot]; }
 uint64_t* host_out() { return g.h_out; }
 int count_async(const uint16_t* d, uint64_t n, int slot) { return count_device_async(d, n, g.d_out[slot], g.stream[slot], g.ws[slot]); }
+int count_async_to(const uint16_t* d, uint64_t n, uint64_t* d_out, int slot) { return count_device_async(d, n, d_out, g.stream[slot], g.ws[slot]); }
 int count_host_array(const uint16_t* h, uint64_t n, uint64_t* out) { return count_host(h, n, out); }
 uint64_t chunk_bytes() { return g.chunk_flags * 2; }
 // three pinned host buffers of >= bytes each, allocated once and reused by later calls

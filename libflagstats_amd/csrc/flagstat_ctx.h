@@ -19,6 +19,7 @@ hipStream_t stream(int slot);
 uint64_t* dev_out(int slot);                     // device uint64[32] per slot
 uint64_t* host_out();                            // pinned uint64[2][32]
 int count_async(const uint16_t* d, uint64_t n, int slot);   // K1+K2 on stream(slot): dev_out(slot) += counters
+int count_async_to(const uint16_t* d, uint64_t n, uint64_t* d_out, int slot);  // same, caller-owned device counters
 int count_host_array(const uint16_t* h, uint64_t n, uint64_t* out);  // the FLAGSTATS_u16_x64 body
 uint64_t chunk_bytes();                            // host streaming chunk (knob chunk_flags) in bytes
 int pinned_reserve(uint64_t bytes, void* bufs[3]);   // persistent pinned chunk buffers

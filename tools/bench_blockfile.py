@@ -103,6 +103,27 @@ def main():
                                       counters.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)))
             pos += cs
         res[what] = time.perf_counter() - t0
+    # the same serial caller loop, kernel call replaced by a streaming session (acquire -> liblz4
+    # decodes straight into pinned memory -> commit): counting happens behind the decode thread
+    from libflagstats_amd.session import StreamSession
+    with StreamSession() as sess:
+        best = None
+        for rep in range(2):
+            t0 = time.perf_counter()
+            pos = 0
+            while pos < len(img):
+                us, cs = struct.unpack_from("<ii", img, pos)
+                pos += 8
+                p = sess.acquire_ptr((us >> 1) + 1)
+                r = lz.LZ4_decompress_safe(base + pos, p, cs, us)
+                assert r == us
+                sess.commit(us >> 1)
+                pos += cs
+            got = sess.finish()
+            dt = time.perf_counter() - t0
+            assert np.array_equal(got, want), "PARITY (session)"
+            best = dt if best is None else min(best, dt)
+    res["decode_into_session_1_thread"] = best
     print(json.dumps({"workload": "%d NA12878-like flags, %d-byte LZ4-%s-%d blocks" % (n, bt.BLOCK_BYTES, args.mode, args.level),
                       "file_bytes": size, "product": rows,
                       "host_serial_reference_shape": {k: {"s": round(v, 4), "Gflags_s": round(n / v / 1e9, 3)}
