@@ -121,3 +121,8 @@ def test_product_never_imports_oracle():
                 src = open(os.path.join(dirpath, f)).read()
                 assert "import oracle" not in src and "from oracle" not in src and "oracle/" not in src, f
     assert "oracle" not in open(os.path.join(ROOT, "pyflagstats.py")).read()
+    # measurement helpers outside tests/ must not lean on it either
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            src = open(os.path.join(ROOT, "tools", f)).read()
+            assert "import oracle" not in src and "from oracle" not in src, f
