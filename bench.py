@@ -137,6 +137,9 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: put every rank on GPU 0 (use with --backend gloo) to exercise the multi-rank "
                          "launch contract on a single-GPU box; the number it prints is not a scaling result")
+    ap.add_argument("--no-overlap", action="store_true",
+                    help="N > 1: wait for each step's all-reduce before the next step's K1 (default: the all-reduce "
+                         "of step i overlaps K1 of step i+1)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 step (store + RCCL all-reduce) even at world size 1: exercises the multi-GPU "
                          "code path on a single-GPU box")
@@ -183,13 +186,43 @@ def main():
     counters = torch.zeros(32, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
+    overlap = multi and not args.no_overlap
+    main_stream = torch.cuda.current_stream(dev)
+    comm_stream = torch.cuda.Stream(device=dev) if overlap else None
+    bufs = [counters, torch.zeros(32, dtype=torch.int64, device=dev)]
+    reduced = [None, None]     # event: the all-reduce that last used bufs[k] has finished
+    state = {"i": 0}
+
     def step():
         # N = 1: counters accumulate across steps (the ABI's += contract, as the reference's
         # bench accumulates across blocks, benchmark/flagstats.cpp:304,328-329), so a step is
-        # exactly K1 + K2.  N > 1: a step is one whole query: count (K2 stores), all-reduce.
-        device.count_torch(flags, counters, store=multi)   # K1 + K2 on torch's current stream
-        if multi:
-            allreduce_counters(counters)          # the path's only exchange: 256 B over xGMI
+        # exactly K1 + K2.  N > 1: a step is one whole query: count (K2 stores), all-reduce of the
+        # 32 counters.  The all-reduce of query i runs on a side stream while K1 of query i+1 streams
+        # its shard (two counter buffers), so the collective's latency is off the critical path;
+        # every query's all-reduce still completes inside the timed region (drain() below).
+        if not overlap:
+            device.count_torch(flags, counters, store=multi)   # K1 + K2 on torch's current stream
+            if multi:
+                allreduce_counters(counters)      # the path's only exchange: 256 B over xGMI
+            return
+        k = state["i"] & 1
+        state["i"] += 1
+        buf = bufs[k]
+        if reduced[k] is not None:
+            main_stream.wait_event(reduced[k])    # K2 may overwrite buf only after its last all-reduce
+        device.count_torch(flags, buf, store=True)
+        counted = torch.cuda.Event()
+        counted.record(main_stream)
+        with torch.cuda.stream(comm_stream):
+            comm_stream.wait_event(counted)
+            allreduce_counters(buf)
+            ev = torch.cuda.Event()
+            ev.record(comm_stream)
+        reduced[k] = ev
+
+    def drain():
+        if overlap:
+            main_stream.wait_stream(comm_stream)
 
     def barrier():
         if multi:
@@ -198,8 +231,10 @@ def main():
 
     for _ in range(args.warmup):
         step()
+    drain()
     barrier()
-    counters.zero_()
+    if not multi:
+        counters.zero_()
     barrier()
     e0 = torch.cuda.Event(enable_timing=True)
     e1 = torch.cuda.Event(enable_timing=True)
@@ -207,6 +242,7 @@ def main():
     e0.record()
     for _ in range(args.steps):
         step()
+    drain()
     e1.record()
     barrier()
     wall = time.perf_counter() - t0
@@ -225,7 +261,8 @@ def main():
 
     result = None
     if rank == 0:
-        got = counters.cpu().numpy().view(np.uint64)
+        last = bufs[(state["i"] - 1) & 1] if overlap else counters
+        got = last.cpu().numpy().view(np.uint64)
         passes = 1 if multi else args.steps   # N = 1 accumulated `steps` identical passes
         assert not (got % np.uint64(passes)).any(), "accumulated counters are not a multiple of the step count"
         got = got // np.uint64(passes)
@@ -259,7 +296,7 @@ def main():
             "config": {"workload": "%.3g GiB uniform-random uint16 FLAG array (%d flags) per GPU, device-resident, "
                                    "K1 flagstat_count + K2 flagstat_finalize%s"
                                    % (n * 2 / 2 ** 30, n, " + RCCL all-reduce int64[32]" if world > 1 else ""),
-                       "flags_per_gpu": n, "global_flags": total_flags, "parallelism": "shard%d" % world,
+                       "flags_per_gpu": n, "global_flags": total_flags, "parallelism": "shard%d" % world, "allreduce": ("overlapped" if overlap else "in-line") if multi else None,
                        "kernel_variant": int(lib.FLAGSTATS_hip_get(b"variant")),
                        "grid_blocks": int(lib.FLAGSTATS_hip_get(b"grid"))},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
