@@ -161,6 +161,19 @@ def main():
     from libflagstats_amd import _lib, device
     from libflagstats_amd.dist import allreduce_counters
 
+    if not os.path.exists(_lib.LIB_PATH):
+        # the in-tree extension normally travels with the snapshot; if it does not, build it here
+        # (hipcc is on the GPU image): local rank 0 builds, the other ranks wait for the file
+        if local_rank == 0:
+            import __graft_entry__
+            __graft_entry__.build()
+        else:
+            for _ in range(600):
+                if os.path.exists(_lib.LIB_PATH):
+                    break
+                time.sleep(1.0)
+            time.sleep(2.0)
+
     if args.same_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
