@@ -71,6 +71,23 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
             break
     one = sample_flags * passes / dt / 1e9
 
+    # the reference's only SIMD variant with FLAGSTAT_scalar's exact semantics on full-range input
+    # (libflagstats.h:2445-2644), 1 thread, ~3 s, for context
+    exact = None
+    if ref is not None and hasattr(ref, "ref_FLAGSTAT_avx512_improved3") and ref.ref_has_avx512bw():
+        f32 = np.zeros(32, dtype=np.uint32)
+        p32 = f32.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32))
+        m = min(sample_flags, 2 ** 30)
+        ref.ref_FLAGSTAT_avx512_improved3(p16, m, p32)
+        t1 = time.perf_counter()
+        k = 0
+        while time.perf_counter() - t1 < 3.0:
+            f32[:] = 0
+            ref.ref_FLAGSTAT_avx512_improved3(p16, m, p32)
+            k += 1
+        exact = {"kernel": "FLAGSTAT_avx512_improved3", "value": round(m * k / (time.perf_counter() - t1) / 1e9, 4),
+                 "unit": "Gflags/s", "cores": 1}
+
     # all cores: a larger sample (beyond the host's last-level caches), one contiguous shard and
     # private counters per thread; the pass loop runs inside C (ref_dispatch_repeat), ctypes drops
     # the GIL, so Python is not what is being timed
@@ -115,6 +132,7 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
         "value": round(one, 4), "unit": "Gflags/s", "cores": 1, "kind": kind, "kernel": name,
         "sample": "first %d flags (%.0f MiB) of the rank-0 workload, %d passes in %.1f s, 1 thread"
                   % (sample_flags, sample_flags * 2 / 2 ** 20, passes, dt),
+        "scalar_exact_variant": exact,
         "all_cores": {"value": round(allc, 4), "unit": "Gflags/s", "cores": cores,
                       "sample": "%d flags (%.0f MiB) in %d contiguous shards x %d passes in %.1f s"
                                 % (per * cores, per * cores * 2 / 2 ** 20, cores, reps, dt_all)},
