@@ -1,0 +1,86 @@
+"""GPU: behaviour around the edges of the C-ABI contract: no alignment
+requirement on the host pointer (the reference uses loadu everywhere, libflagstats.h:281,1064,1695),
+reentrancy from several threads, shutdown and lazy re-initialisation, error reporting."""
+import ctypes
+import threading
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_host_pointer_at_odd_byte_address(hip):
+    import oracle
+    from libflagstats_amd import _lib
+    n = 1_000_003
+    flags = oracle.generate(oracle.GEN_UNIFORM, 8, 0xFFFF, 0, n)
+    raw = bytearray(2 * n + 1)
+    raw[1:] = flags.tobytes()                                # the array starts at an ODD byte address
+    base = (ctypes.c_char * len(raw)).from_buffer(raw)
+    out = np.zeros(32, dtype=np.uint32)
+    rc = hip.FLAGSTATS_u16(ctypes.addressof(base) + 1, n, out.ctypes.data)
+    _lib.check(int(rc), "FLAGSTATS_u16")
+    assert np.array_equal(out.astype(np.uint64), oracle.flagstat_hist(flags))
+
+
+def test_concurrent_callers(hip):
+    """The reference is reentrant (no shared state but the cpuid cache); here calls from several
+    threads are serialised inside the library and must each get their own, exact, counters."""
+    import oracle
+    arrays = [oracle.generate(oracle.GEN_UNIFORM, 100 + i, 0xFFFF, 0, 200_000 + 17 * i) for i in range(8)]
+    want = [oracle.flagstat_hist(a) for a in arrays]
+    got = [None] * len(arrays)
+    errs = []
+
+    def work(i):
+        try:
+            for _ in range(20):
+                out = np.zeros(32, dtype=np.uint32)
+                rc = hip.FLAGSTATS_u16(arrays[i].ctypes.data, arrays[i].size, out.ctypes.data)
+                assert rc == 0
+                got[i] = out
+                assert np.array_equal(out.astype(np.uint64), want[i])
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+
+    ths = [threading.Thread(target=work, args=(i,)) for i in range(len(arrays))]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errs, errs
+
+
+def test_errors_are_loud_and_recoverable(hip):
+    import oracle
+    from libflagstats_amd import _lib, device
+    out = np.zeros(32, dtype=np.uint64)
+    # device entry: a uint16_t* must be 2-byte aligned
+    d = device.DeviceFlags(1024)
+    rc = hip.FLAGSTATS_hip_device_u16_sync(d.ptr + 1, 10, out.ctypes.data)
+    assert rc != 0 and b"aligned" in hip.FLAGSTATS_hip_last_error()
+    rc = hip.FLAGSTATS_u16_x64(None, 5, out.ctypes.data)          # NULL array with n > 0
+    assert rc != 0 and b"NULL" in hip.FLAGSTATS_hip_last_error()
+    assert hip.FLAGSTATS_hip_set(b"no_such_knob", 1) != 0
+    assert not out.any()
+    d.free()
+    # still healthy afterwards
+    a = oracle.generate(oracle.GEN_NA12878, 2, 1, 0, 70_001)
+    _lib.check(hip.FLAGSTATS_u16_x64(a.ctypes.data, a.size, out.ctypes.data), "x64")
+    assert np.array_equal(out, oracle.flagstat_hist(a))
+
+
+def test_shutdown_and_lazy_reinit(hip):
+    import oracle
+    from libflagstats_amd import _lib
+    a = oracle.generate(oracle.GEN_UNIFORM, 3, 0xFFFF, 0, 123_457)
+    want = oracle.flagstat_hist(a)
+    knobs = {k: hip.FLAGSTATS_hip_get(k) for k in (b"variant", b"blocks_per_cu", b"fuse", b"chunk_flags")}
+    hip.FLAGSTATS_hip_shutdown()
+    assert hip.FLAGSTATS_hip_device_id() == -1
+    out = np.zeros(32, dtype=np.uint64)
+    _lib.check(hip.FLAGSTATS_u16_x64(a.ctypes.data, a.size, out.ctypes.data), "x64 after shutdown")   # lazy re-init
+    assert np.array_equal(out, want)
+    assert hip.FLAGSTATS_hip_device_id() == 0
+    assert {k: hip.FLAGSTATS_hip_get(k) for k in knobs} == knobs            # knobs survive a shutdown
