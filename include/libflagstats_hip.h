@@ -79,8 +79,8 @@ int FLAGSTATS_hip_compute_units(void);      /* CU count of that device, -1 befor
 /* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _CHUNK_FLAGS).  key =
  *   "blocks_per_cu"  workgroups per CU of K1's grid (default 1)
  *   "variant"        K1 schedule: bit0 non-temporal loads, bit1 chain depth 7, bit2 register
- *                    prefetch, bit3 interleaved waves, bit4 rolling re-issue, bit5 LDS-DMA ring
- *                    (default 25; instantiated: 0, 1, 9, 13, 25, 27, 41)
+ *                    prefetch, bit3 interleaved waves, bit4 rolling re-issue, bit5 LDS-DMA ring, bit6
+ *                    rolling at distance 2 (default 25; instantiated: 0, 1, 9, 13, 25, 27, 41, 89)
  *   "fuse"           0 = K1 + K2 (default); 1 = K1 finalises itself, one kernel per call
  *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB)
  * Returns 0 on success. */

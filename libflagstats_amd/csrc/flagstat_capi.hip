@@ -328,7 +328,7 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         if (value > 16) return fail_msg("blocks_per_cu must be 0 (auto) .. 16");
         g.blocks_per_cu = (uint32_t)value;
     } else if (!std::strcmp(key, "variant")) {
-        if (value > 63) return fail_msg("variant must be 0..63");
+        if (value > 127) return fail_msg("variant must be 0..127");
         g.variant = (int)value;
     } else if (!std::strcmp(key, "fuse")) {
         if (value > 1) return fail_msg("fuse must be 0 or 1");

@@ -380,6 +380,43 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
                 }
                 step_and_count(s, v, blk);
             }
+        } else if constexpr (STAGE == 3) {
+            // Rolling at distance 2: two register buffers, each vector's re-issue targets the lane's
+            // step AFTER NEXT, so 16 loads (16 KiB per wave, 64 KiB per CU at one workgroup per CU) are
+            // in flight at all times -- the deepest configuration of the read-probe sweep.
+            if (st < fast_end) {
+                uint4 va[kUnroll], vb[kUnroll];
+                auto ptr = [&](uint64_t sx) { return a0 + sx * kVecPerStep + lane_off; };
+#pragma unroll
+                for (int u = 0; u < kUnroll; ++u) {
+                    va[u] = load_vec<NT>(ptr(st) + u * US);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (st + G >= fast_end) {
+                    step_and_count(s, va, blk);  // a single step for this workgroup
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        vb[u] = load_vec<NT>(ptr(st + G) + u * US);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    // steady state: buffer A holds step st, B holds st+G, both re-issue two steps ahead;
+                    // exactly 16 loads are outstanding at every wait (vmcnt(15)), on every path
+                    for (; st + 3 * G < fast_end; st += 2 * G) {
+                        step_and_count<DEPTH, 1, NT, US>(s, va, blk, ptr(st + 2 * G));
+                        step_and_count<DEPTH, 1, NT, US>(s, vb, blk, ptr(st + 3 * G));
+                    }
+                    // tail: 2 or 3 steps left (st, st+G and perhaps st+2G)
+                    if (st + 2 * G < fast_end) {
+                        step_and_count<DEPTH, 1, NT, US>(s, va, blk, ptr(st + 2 * G));
+                        step_and_count(s, vb, blk);
+                        step_and_count(s, va, blk);
+                    } else {
+                        step_and_count(s, va, blk);
+                        step_and_count(s, vb, blk);
+                    }
+                }
+            }
         } else {
             // LDS ring: 16 slots of 1 KiB per wave (two steps); slot (k & 1) * 8 + u holds vector u of
             // the wave's k-th step.  DMAs for steps that do not exist re-read the current step (their
@@ -574,10 +611,10 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     hipError_t e;
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
     // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers,
-    // 32 = staging through a per-wave LDS ring filled by LDS-DMA.
+    // 32 = staging through a per-wave LDS ring filled by LDS-DMA, 64 = rolling at distance 2 (two buffers).
     // Only the combinations that mattered in the r01 sweeps are instantiated (profiles/r01/tune_*.log
     // also list 2-7, 11, 17, which lost and were dropped).
-    switch (variant & 63) {
+    switch (variant & 127) {
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
     case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
@@ -585,6 +622,7 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     case 25: e = launch_count_t<8, true, false, true, 1>(a, stream); break;
     case 27: e = launch_count_t<7, true, false, true, 1>(a, stream); break;
     case 41: e = launch_count_t<8, true, false, true, 2>(a, stream); break;  // bit 5: LDS-DMA ring instead of registers
+    case 89: e = launch_count_t<8, true, false, true, 3>(a, stream); break;  // bit 6: rolling registers at distance 2
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;

@@ -32,7 +32,7 @@ def test_random_lengths_offsets_geometries(hip):
                 n = int(rs.randint(0, cap))
             n = max(0, min(n, cap))
             off = int(rs.randint(0, 32))
-            _lib.check(hip.FLAGSTATS_hip_set(b"variant", int(rs.choice([1, 9, 25, 27, 13, 0, 41]))), "variant")
+            _lib.check(hip.FLAGSTATS_hip_set(b"variant", int(rs.choice([1, 9, 25, 27, 13, 0, 41, 89]))), "variant")
             _lib.check(hip.FLAGSTATS_hip_set(b"blocks_per_cu", int(rs.choice([1, 2, 3]))), "bpc")
             _lib.check(hip.FLAGSTATS_hip_set(b"fuse", int(rs.randint(0, 2))), "fuse")  # K1+K2 or K1 finalising itself
             buf.generate(kind, seed=seed, mask=mask, first_index=first, offset=off, n=n)
