@@ -194,6 +194,9 @@ def main():
 
     if args.same_device:
         local_rank = 0
+    ndev = torch.cuda.device_count()
+    if ndev and local_rank >= ndev:
+        local_rank %= ndev   # a launcher that isolates one visible GPU per rank (HIP_VISIBLE_DEVICES)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = _lib.lib()
