@@ -1,25 +1,31 @@
 #!/usr/bin/env python3
 """bench.py -- flagstat hot path on N MI355X of one node.
 
-One "step" = one pass of the hot path (K1 flagstat_count + K2 flagstat_finalize,
-plus the 32-counter all-reduce when N > 1) over this rank's device-resident FLAG
-shard.  Workload = the configuration BASELINE.json's metric is quoted on:
-8 GiB of uniform-random uint16 (2^32 flags) per GPU, generated on device by the
-library's counter-based generator (data: synthetic).  N > 1 is weak scaling:
-every rank holds its own 8 GiB shard (seed + rank), 64 GiB at N = 8
-(BASELINE config 3), one RCCL all-reduce of int64[32] per step.
+One "step" = one pass of the hot path (K1 flagstat_count + K2 flagstat_finalize, plus the
+32-counter all-reduce when N > 1) over this rank's device-resident FLAG shard.  Workload = the
+configuration BASELINE.json's metric is quoted on: 8 GiB of uniform-random uint16 (2^32 flags) per
+GPU, generated on device by the library's counter-based generator (data: synthetic).  N > 1 is weak
+scaling: every rank holds its own 8 GiB shard (seed + rank), 64 GiB at N = 8 (BASELINE config 3);
+the data path of a multi-GPU step is the C ABI's FLAGSTATS_hip_device_u16_store + ONE
+ncclAllReduce(uint64[32]) (FLAGSTATS_hip_allreduce_counters) per step; torch.distributed only carries
+the rendezvous (unique id, barriers, max-over-ranks of the timings).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
-objects: "roofline" (HBM: algorithmic bytes = 2 B/flag over the event-timed
-average step on the launch stream) and "cpu_baseline" (the reference's own
-dispatcher kernel, oracle/_ref, timed on this host on a bounded sample).
+Order of a run: generate -> read-bandwidth probe (untimed; also lets the chip settle: after idle the
+first ~20 launches of ANY kernel run 5-40 % slow, tools/step_times.py) -> W warm-up steps -> barrier ->
+exactly K timed steps, one hipEvent per step on the launch stream -> barrier -> parity of the WHOLE
+array against the oracle -> CPU baseline.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects: "roofline"
+(HBM: algorithmic bytes = 2 B/flag over the event-timed average step on the launch stream) and
+"cpu_baseline" (the reference's own dispatcher kernel, oracle/_ref, timed on this host on a bounded
+sample).
 """
 import argparse
 import ctypes
+import hashlib
 import json
 import os
 import sys
-import threading
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -30,9 +36,20 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak, /opt/skills/guides/MI355X_MICRO
 METRIC = "Gflags/s + achieved HBM GB/s vs roofline, 8 GiB uint16, 1/2/4/8 MI355X"
 
 
+def kernel_source_id():
+    """Identity of the K1/K2 source the shipped .so was built from (profiles/traffic.json carries the
+    same id: a PMC figure measured on another build of the kernel is not reported)."""
+    h = hashlib.sha256()
+    for f in ("flagstat_kernels.hip", "flagstat_device.h", "flagstat_kernels.h"):
+        with open(os.path.join(ROOT, "libflagstats_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
 def cpu_baseline(seconds: float, sample_flags: int, seed: int):
     """Time the reference's own kernel (what FLAGSTATS_get_function returns on this host,
-    libflagstats.h:2976-3022) on a prefix of the rank-0 workload; 1 thread, then all cores."""
+    libflagstats.h:2976-3022) on a prefix of the rank-0 workload: 1 thread, then every core with
+    pinned threads and shard-local memory (ref_dispatch_mt_bench, oracle/ref_wrap.cpp)."""
     import numpy as np
 
     import oracle
@@ -40,24 +57,23 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
     a = oracle.generate(oracle.GEN_UNIFORM, seed, 0xFFFF, 0, sample_flags)
     ref = oracle.load_ref()
     lib = oracle.load_c()
+    p16 = ctypes.cast(a.ctypes.data, ctypes.POINTER(ctypes.c_uint16))
+    u64p = ctypes.POINTER(ctypes.c_uint64)
     if ref is not None:
         kind = "reference"
         name = ref.ref_dispatch_name(min(sample_flags, 2 ** 30)).decode()
-        p16 = ctypes.cast(a.ctypes.data, ctypes.POINTER(ctypes.c_uint16))
 
         def run(ptr, n):
             out = np.zeros(32, dtype=np.uint64)
-            ref.ref_dispatch_x64(ptr, n, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+            ref.ref_dispatch_x64(ptr, n, out.ctypes.data_as(u64p))
             return out
     else:  # reference build absent on this box: time our C restatement instead
         kind = "port"
         name = "oracle_flagstat_hist_u16"
-        lib = oracle.load_c()
-        p16 = ctypes.cast(a.ctypes.data, ctypes.POINTER(ctypes.c_uint16))
 
         def run(ptr, n):
             out = np.zeros(32, dtype=np.uint64)
-            lib.oracle_flagstat_hist_u16(ptr, n, out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64)))
+            lib.oracle_flagstat_hist_u16(ptr, n, out.ctypes.data_as(u64p))
             return out
 
     run(p16, sample_flags)  # warm
@@ -88,55 +104,43 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
         exact = {"kernel": "FLAGSTAT_avx512_improved3", "value": round(m * k / (time.perf_counter() - t1) / 1e9, 4),
                  "unit": "Gflags/s", "cores": 1}
 
-    # all cores: a larger sample (beyond the host's last-level caches), one contiguous shard and
-    # private counters per thread; the pass loop runs inside C (ref_dispatch_repeat), ctypes drops
-    # the GIL, so Python is not what is being timed
-    cores = os.cpu_count() or 1
-    big_flags = max(sample_flags, min(2 ** 30, 4 * 2 ** 20 * cores))
-    per = big_flags // cores
-    big = np.empty(per * cores, dtype=np.uint16)
-
-    def fill(k):
-        oracle.load_c().oracle_generate_u16(oracle.GEN_UNIFORM, seed, 0xFFFF, per * k, per,
-                                            ctypes.cast(big.ctypes.data + 2 * per * k, ctypes.POINTER(ctypes.c_uint16)))
-
-    def timed(reps):
-        def worker(k):
-            ptr = ctypes.cast(big.ctypes.data + 2 * per * k, ctypes.POINTER(ctypes.c_uint16))
-            out = np.zeros(32, dtype=np.uint64)
-            p64 = out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint64))
-            if ref is not None:
-                ref.ref_dispatch_repeat(ptr, per, reps, p64)
-            else:
-                for _ in range(reps):
-                    lib.oracle_flagstat_hist_u16(ptr, per, p64)
-        ths = [threading.Thread(target=worker, args=(k,)) for k in range(cores)]
-        t0 = time.perf_counter()
-        for t in ths:
-            t.start()
-        for t in ths:
-            t.join()
-        return time.perf_counter() - t0
-
-    ths = [threading.Thread(target=fill, args=(k,)) for k in range(cores)]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
-    probe = timed(2)
-    reps = max(2, min(100000, int(2 * 5.0 / max(probe, 1e-6))))   # aim at ~5 s
-    dt_all = timed(reps)
-    allc = per * cores * reps / dt_all / 1e9
+    # all cores: one pinned thread per logical CPU, 8 MiB of its own (first-touched, so socket-local)
+    # uniform-random flags each -- beyond the per-core caches -- timed inside C between two barriers
+    allc = None
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if ref is not None and hasattr(ref, "ref_dispatch_mt_bench"):
+        ref.ref_dispatch_mt_bench.restype = ctypes.c_double
+        ref.ref_dispatch_mt_bench.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, u64p]
+        per = 4 * 2 ** 20
+        out = np.zeros(32, dtype=np.uint64)
+        probe = ref.ref_dispatch_mt_bench(per, cores, 4, seed, out.ctypes.data_as(u64p))
+        reps = max(4, min(100000, int(4 * 5.0 / max(probe, 1e-6))))   # aim at ~5 s
+        runs = []
+        for _ in range(3):
+            out[:] = 0
+            dt_all = ref.ref_dispatch_mt_bench(per, cores, reps, seed, out.ctypes.data_as(u64p))
+            runs.append(per * cores * reps / dt_all / 1e9)
+        runs.sort()
+        allc = {"value": round(runs[1], 4), "unit": "Gflags/s", "cores": cores, "min": round(runs[0], 4),
+                "max": round(runs[2], 4),
+                "sample": "%d flags (%.0f MiB) in %d pinned, shard-local shards x %d passes, median of 3 runs"
+                          % (per * cores, per * cores * 2 / 2 ** 20, cores, reps)}
 
     return {
         "value": round(one, 4), "unit": "Gflags/s", "cores": 1, "kind": kind, "kernel": name,
         "sample": "first %d flags (%.0f MiB) of the rank-0 workload, %d passes in %.1f s, 1 thread"
                   % (sample_flags, sample_flags * 2 / 2 ** 20, passes, dt),
         "scalar_exact_variant": exact,
-        "all_cores": {"value": round(allc, 4), "unit": "Gflags/s", "cores": cores,
-                      "sample": "%d flags (%.0f MiB) in %d contiguous shards x %d passes in %.1f s"
-                                % (per * cores, per * cores * 2 / 2 ** 20, cores, reps, dt_all)},
-    }, a
+        "all_cores": allc,
+    }
+
+
+def quantiles(ms):
+    s = sorted(ms)
+    n = len(s)
+    pick = lambda q: s[min(n - 1, max(0, int(round(q * (n - 1)))))]  # noqa: E731
+    return {"median": round(pick(0.5), 5), "p10": round(pick(0.1), 5), "p90": round(pick(0.9), 5),
+            "min": round(s[0], 5), "max": round(s[-1], 5), "first": round(ms[0], 5)}
 
 
 def main():
@@ -148,13 +152,21 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 27)
     ap.add_argument("--seed", type=int, default=2026)
+    ap.add_argument("--probe-reps", type=int, default=40,
+                    help="read-only bandwidth probe launches before the warm-up steps (0: no probe; the first timed "
+                         "steps then carry the chip's after-idle transient when --warmup is small)")
+    ap.add_argument("--parity", choices=("full", "off"), default="full",
+                    help="full: every rank's whole shard vs the oracle (all host cores, ~1 s per 2^32 flags)")
     ap.add_argument("--strong", action="store_true",
                     help="strong scaling: --flags-per-gpu is the TOTAL array, split into contiguous shards over the ranks "
                          "(default is weak scaling: every rank holds its own --flags-per-gpu shard)")
-    ap.add_argument("--backend", default="nccl", help="torch.distributed backend; nccl = RCCL over xGMI (default)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for the rendezvous; nccl = RCCL (default)")
+    ap.add_argument("--allreduce", choices=("c-abi", "torch"), default="c-abi",
+                    help="who issues the step's all-reduce: the library's C entry over its own RCCL communicator "
+                         "(default) or torch.distributed")
     ap.add_argument("--same-device", action="store_true",
-                    help="TEST ONLY: put every rank on GPU 0 (use with --backend gloo) to exercise the multi-rank "
-                         "launch contract on a single-GPU box; the number it prints is not a scaling result")
+                    help="TEST ONLY: put every rank on GPU 0 (use with --backend gloo --allreduce torch) to exercise the "
+                         "multi-rank launch contract on a single-GPU box; the number it prints is not a scaling result")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each step's all-reduce before the next step's K1 (default: the all-reduce "
                          "of step i overlaps K1 of step i+1)")
@@ -177,7 +189,6 @@ def main():
     import torch.distributed as dist
 
     from libflagstats_amd import _lib, device
-    from libflagstats_amd.dist import allreduce_counters
 
     if not os.path.exists(_lib.LIB_PATH):
         # the in-tree extension normally travels with the snapshot; if it does not, build it here
@@ -192,16 +203,21 @@ def main():
                 time.sleep(1.0)
             time.sleep(2.0)
 
+    ndev = torch.cuda.device_count()
     if args.same_device:
         local_rank = 0
-    ndev = torch.cuda.device_count()
-    if ndev and local_rank >= ndev:
-        local_rank %= ndev   # a launcher that isolates one visible GPU per rank (HIP_VISIBLE_DEVICES)
+    elif ndev == 1 and local_rank > 0:
+        local_rank = 0   # the launcher isolates one visible GPU per rank (HIP_VISIBLE_DEVICES)
+    elif local_rank >= ndev:
+        sys.exit("bench.py: local rank %d but only %d GPUs are visible: refusing to share a GPU between ranks "
+                 "(--same-device is the explicit, test-only way)" % (local_rank, ndev))
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     lib = _lib.lib()
     _lib.check(lib.FLAGSTATS_hip_init(local_rank), "FLAGSTATS_hip_init")
     multi = world > 1 or args.force_dist
+    comm = None
+    ar_impl = None
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -209,14 +225,44 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
+        ar_impl = "torch.distributed (%s)" % args.backend
+        if args.allreduce == "c-abi" and not args.same_device:
+            # the library's own RCCL communicator: rank 0 makes the 128-byte id, the rendezvous ships it
+            try:
+                ident = torch.zeros(128, dtype=torch.uint8)
+                if rank == 0:
+                    buf = (ctypes.c_char * 128)()
+                    _lib.check(lib.FLAGSTATS_hip_comm_unique_id(buf), "FLAGSTATS_hip_comm_unique_id")
+                    ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+                if args.backend == "nccl":
+                    ident = ident.to(dev)
+                dist.broadcast(ident, src=0)
+                raw = bytes(ident.cpu().numpy().tobytes())
+                comm = lib.FLAGSTATS_hip_comm_init_rank(raw, world, rank, local_rank)
+                if not comm:
+                    raise _lib.FlagstatsHipError(lib.FLAGSTATS_hip_last_error().decode(errors="replace"))
+                ar_impl = "FLAGSTATS_hip_allreduce_counters (C ABI, ncclAllReduce uint64[32])"
+            except Exception as e:  # noqa: BLE001 -- a scaling run must not die on the communicator; say so instead
+                print("bench.py: C-ABI RCCL communicator unavailable (%r); using torch.distributed all_reduce" % (e,),
+                      file=sys.stderr)
+                comm = None
+            # every rank must take the same path
+            flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0 and comm:
+                lib.FLAGSTATS_hip_comm_destroy(comm)
+                comm = None
+                ar_impl = "torch.distributed (%s)" % args.backend
 
     n = args.flags_per_gpu
+    first = 0
     if args.strong:
         from libflagstats_amd.dist import shard_range
         b, e = shard_range(args.flags_per_gpu, rank, world)
-        n = e - b
+        n, first = e - b, b
     flags = torch.empty(n, dtype=torch.int16, device=dev)           # this rank's shard, resident in HBM
-    device.generate_torch(flags, device.GEN_UNIFORM, seed=args.seed + rank, mask=0xFFFF)
+    shard_seed = args.seed if args.strong else args.seed + rank
+    device.generate_torch(flags, device.GEN_UNIFORM, seed=shard_seed, mask=0xFFFF, first_index=first)
     counters = torch.zeros(32, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
@@ -226,6 +272,13 @@ def main():
     bufs = [counters, torch.zeros(32, dtype=torch.int64, device=dev)]
     reduced = [None, None]     # event: the all-reduce that last used bufs[k] has finished
     state = {"i": 0}
+
+    def allreduce(buf, stream):
+        if comm:
+            _lib.check(lib.FLAGSTATS_hip_allreduce_counters(buf.data_ptr(), comm, ctypes.c_void_p(stream.cuda_stream)),
+                       "FLAGSTATS_hip_allreduce_counters")
+        else:
+            dist.all_reduce(buf, op=dist.ReduceOp.SUM)
 
     def step():
         # N = 1: counters accumulate across steps (the ABI's += contract, as the reference's
@@ -237,7 +290,7 @@ def main():
         if not overlap:
             device.count_torch(flags, counters, store=multi)   # K1 + K2 on torch's current stream
             if multi:
-                allreduce_counters(counters)      # the path's only exchange: 256 B over xGMI
+                allreduce(counters, main_stream)  # the path's only exchange: 256 B over xGMI
             return
         k = state["i"] & 1
         state["i"] += 1
@@ -249,7 +302,7 @@ def main():
         counted.record(main_stream)
         with torch.cuda.stream(comm_stream):
             comm_stream.wait_event(counted)
-            allreduce_counters(buf)
+            allreduce(buf, comm_stream)
             ev = torch.cuda.Event()
             ev.record(comm_stream)
         reduced[k] = ev
@@ -263,6 +316,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # read-only probe with K1's load pattern ("fraction of a measured read-only
+    # probe kernel"): what this chip delivers to ANY kernel reading this buffer, measured in this run
+    probe_gbs = None
+    if args.probe_reps > 0 and n >= 2 ** 22:
+        ms = ctypes.c_float(0.0)
+        _lib.check(lib.FLAGSTATS_hip_read_probe(flags.data_ptr(), 2 * n, 1, args.probe_reps, args.probe_reps,
+                                                ctypes.byref(ms)), "FLAGSTATS_hip_read_probe")
+        probe_gbs = 2.0 * n * args.probe_reps / (ms.value * 1e-3) / 1e9
+
     for _ in range(args.warmup):
         step()
     drain()
@@ -270,20 +332,22 @@ def main():
     if not multi:
         counters.zero_()
     barrier()
-    e0 = torch.cuda.Event(enable_timing=True)
-    e1 = torch.cuda.Event(enable_timing=True)
+    evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
-    e0.record()
-    for _ in range(args.steps):
+    evs[0].record()
+    for i in range(args.steps):
         step()
+        if i + 1 < args.steps:
+            evs[i + 1].record()
     drain()
-    e1.record()
+    evs[args.steps].record()
     barrier()
     wall = time.perf_counter() - t0
-    ev_ms = e0.elapsed_time(e1)
+    ev_ms = evs[0].elapsed_time(evs[args.steps])
+    step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
 
     if multi:
-        tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tmax[0]), float(tmax[1])
 
@@ -300,27 +364,38 @@ def main():
         passes = 1 if multi else args.steps   # N = 1 accumulated `steps` identical passes
         assert not (got % np.uint64(passes)).any(), "accumulated counters are not a multiple of the step count"
         got = got // np.uint64(passes)
-        cpu = None
         parity = "not checked"
-        if args.cpu_seconds > 0 and world == 1:
+        if args.parity == "full":
+            # checker: the oracle regenerates every rank's whole shard (counter-based generator) on all
+            # host cores and counts it with FLAGSTAT_scalar's rule; N > 1: the all-reduced counters must
+            # equal the sum over the ranks' shards
             import oracle
-            cpu, sample = cpu_baseline(args.cpu_seconds, min(args.cpu_sample, n), args.seed)
-            # checker: the oracle on the same sample bytes vs the HIP path on the same prefix
-            want = oracle.flagstat_mt(sample)
-            pre = torch.zeros(32, dtype=torch.int64, device=dev)
-            device.count_torch(flags[: sample.size], pre)
-            torch.cuda.synchronize()
-            ok = np.array_equal(pre.cpu().numpy().view(np.uint64), want)
-            parity = "bit-exact vs oracle on the CPU-baseline sample" if ok else "MISMATCH vs oracle"
+            tp = time.perf_counter()
+            want = np.zeros(32, dtype=np.uint64)
+            for r in range(world):
+                if args.strong:
+                    from libflagstats_amd.dist import shard_range
+                    b, e = shard_range(args.flags_per_gpu, r, world)
+                    want += oracle.flagstat_generated(oracle.GEN_UNIFORM, args.seed, 0xFFFF, b, e - b)
+                else:
+                    want += oracle.flagstat_generated(oracle.GEN_UNIFORM, args.seed + r, 0xFFFF, 0, n)
+            ok = np.array_equal(got, want)
+            parity = ("bit-exact vs oracle on the whole workload (%d flags, all %d shards; oracle took %.1f s)"
+                      % (total_flags, world, time.perf_counter() - tp)) if ok else "MISMATCH vs oracle"
             if not ok:
-                print("PARITY MISMATCH", pre.cpu().numpy().view(np.uint64), want, file=sys.stderr)
+                print("PARITY MISMATCH", got, want, file=sys.stderr)
+        cpu = None
+        if args.cpu_seconds > 0 and world == 1:
+            cpu = cpu_baseline(args.cpu_seconds, min(args.cpu_sample, n), args.seed)
         traffic = None
+        traffic_note = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
             try:
                 t = json.load(open(tpath))
-                if t.get("flags_per_launch") == n:
+                if t.get("flags_per_launch") == n and t.get("kernel_source_id") == kernel_source_id():
                     traffic = t.get("hbm_bytes_per_launch")
+                    traffic_note = t.get("source")
             except Exception:
                 traffic = None
         result = {
@@ -329,14 +404,20 @@ def main():
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
             "config": {"workload": "%.3g GiB uniform-random uint16 FLAG array (%d flags) per GPU, device-resident, "
                                    "K1 flagstat_count + K2 flagstat_finalize%s"
-                                   % (n * 2 / 2 ** 30, n, " + RCCL all-reduce int64[32]" if world > 1 else ""),
-                       "flags_per_gpu": n, "global_flags": total_flags, "parallelism": "shard%d" % world, "allreduce": ("overlapped" if overlap else "in-line") if multi else None,
+                                   % (n * 2 / 2 ** 30, n, " + RCCL all-reduce uint64[32]" if world > 1 else ""),
+                       "flags_per_gpu": n, "global_flags": total_flags, "parallelism": "shard%d" % world,
+                       "allreduce": ("overlapped" if overlap else "in-line") if multi else None,
+                       "allreduce_impl": ar_impl,
                        "kernel_variant": int(lib.FLAGSTATS_hip_get(b"variant")),
-                       "grid_blocks": int(lib.FLAGSTATS_hip_get(b"grid"))},
+                       "grid_blocks": int(lib.FLAGSTATS_hip_get(b"grid")),
+                       "kernel_source_id": kernel_source_id()},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_note,
                          "algorithmic_bytes_per_launch": 2 * n,
-                         "event_ms_per_launch": round(ev_ms_per_step, 5)},
+                         "event_ms_per_launch": round(ev_ms_per_step, 5),
+                         "step_ms": quantiles(step_ms),
+                         "read_probe_GBs": round(probe_gbs, 1) if probe_gbs else None,
+                         "frac_of_read_probe": round(achieved / probe_gbs, 4) if probe_gbs else None},
             "cpu_baseline": cpu,
             "parity": parity,
             "counters_fail_qc_reads": int(got[25]),
@@ -347,6 +428,8 @@ def main():
 
     if multi:
         dist.barrier()
+        if comm:
+            lib.FLAGSTATS_hip_comm_destroy(comm)
         dist.destroy_process_group()
     return result
 

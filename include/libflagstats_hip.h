@@ -15,7 +15,18 @@
  * in the caller).
  *
  * There is NO CPU fallback in this library: if the GPU path cannot run, the
- * call fails loudly (message on stderr + non-zero return).
+ * call fails loudly -- a message on stderr and a non-zero return; the three
+ * reference-shaped entry points (FLAGSTATS_u16, FLAGSTAT_hip, STORM_pospopcnt_u16),
+ * whose reference callers ignore the return value (python/libflagstats.pyx:22,
+ * benchmark/flagstats.cpp:329), abort() after the message instead of handing
+ * back silently-zero counters (knob "on_error" / FLAGSTATS_HIP_ON_ERROR=return
+ * restores the plain non-zero return for callers that check it).
+ *
+ * State: one engine per device (streams, staging, workspaces), created on first
+ * use.  Entry points that take a DEVICE pointer run on the device that pointer
+ * lives on; entry points without one use the default device (FLAGSTATS_hip_init,
+ * else env FLAGSTATS_HIP_DEVICE, else 0).  Every entry point restores the calling
+ * thread's current HIP device before returning and may be called from any thread.
  */
 #ifndef LIBFLAGSTATS_HIP_H_
 #define LIBFLAGSTATS_HIP_H_
@@ -40,7 +51,9 @@ uint64_t FLAGSTATS_u16(const uint16_t* array, uint32_t n_len, uint32_t* flags);
 
 /* replaces: `static FLAGSTATS_func FLAGSTATS_get_function(uint32_t n_len)`
  * libflagstats.h:2976-3022 (callers: benchmark/flagstats.cpp:328,450,665).
- * This library has one kernel family, so it returns &FLAGSTAT_hip for every n. */
+ * This library has one kernel family and no host kernels, so it returns &FLAGSTAT_hip for every n;
+ * the length-aware rule (:2999-3021) stays in the reference's dispatcher, which INTEGRATION.md
+ * section B extends with this library as its first branch (n >= FLAGSTATS_HIP_MIN_LEN). */
 FLAGSTATS_func FLAGSTATS_get_function(uint32_t n_len);
 
 /* the kernel itself, shaped like every FLAGSTAT_<impl> of the reference
@@ -70,19 +83,58 @@ int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t*
 
 /* ---- context ---- */
 int FLAGSTATS_hip_available(void);          /* 1 if a gfx950-capable device can be used */
-int FLAGSTATS_hip_init(int device);         /* optional; lazily called with FLAGSTATS_HIP_DEVICE or 0 */
-void FLAGSTATS_hip_shutdown(void);          /* releases streams and workspaces */
+int FLAGSTATS_hip_device_count(void);       /* HIP devices visible to this process (0 if none) */
+int FLAGSTATS_hip_init(int device);         /* optional: selects the default device (lazily FLAGSTATS_HIP_DEVICE or 0) */
+void FLAGSTATS_hip_shutdown(void);          /* releases every engine (close sessions and contexts first) */
 const char* FLAGSTATS_hip_last_error(void); /* text of the last failure on this thread ("" if none) */
 int FLAGSTATS_hip_device_id(void);          /* device the context is bound to, -1 before init */
 int FLAGSTATS_hip_compute_units(void);      /* CU count of that device, -1 before init */
 
-/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _CHUNK_FLAGS).  key =
+/* explicit contexts: a private engine (own streams, staging and workspaces) on `device`; several may
+ * exist per device and are fully independent of each other and of the default engines -- one per
+ * caller thread gives concurrent host-array calls. */
+typedef struct FLAGSTATS_hip_ctx FLAGSTATS_hip_ctx;
+FLAGSTATS_hip_ctx* FLAGSTATS_hip_ctx_create(int device);   /* device < 0: the default device; NULL on failure */
+void FLAGSTATS_hip_ctx_destroy(FLAGSTATS_hip_ctx* ctx);
+int FLAGSTATS_hip_ctx_device(const FLAGSTATS_hip_ctx* ctx);
+int FLAGSTATS_hip_ctx_u16_x64(FLAGSTATS_hip_ctx* ctx, const uint16_t* array, uint64_t n, uint64_t* out); /* as FLAGSTATS_u16_x64 */
+int FLAGSTATS_hip_ctx_device_u16_sync(FLAGSTATS_hip_ctx* ctx, const uint16_t* d_array, uint64_t n, uint64_t* out);
+
+/* ---- multi-GPU: contiguous shards, counters summed; no other exchange ----
+ * rank's shard of n flags over `world` ranks: [begin, end), remainder to the last rank */
+void FLAGSTATS_hip_shard_range(uint64_t n, int rank, int world, uint64_t* begin, uint64_t* end);
+/* one process, `ndev` devices, HOST array: shard i goes through a private engine on devices[i]
+ * (NULL = devices 0..ndev-1; a device may repeat) over that device's PCIe link, one host thread per
+ * shard; out[32] += the host-side sum of the ndev x 256 bytes of counters. */
+int FLAGSTATS_hip_multi_u16_x64(const uint16_t* array, uint64_t n, const int* devices, int ndev, uint64_t* out);
+/* one process, DEVICE-resident shards (d_arrays[i] holds n[i] flags on whichever device it was
+ * allocated on): counted where they live, all devices concurrently; out[32] += host-side sum. */
+int FLAGSTATS_hip_multi_device_u16(const uint16_t* const* d_arrays, const uint64_t* n, int nshards, uint64_t* out);
+/* one process per device (RCCL over xGMI; librccl.so.1 is bound at first use, env FLAGSTATS_HIP_RCCL
+ * overrides its path).  Communicators travel as void* (an ncclComm_t made here or by the caller):
+ *   rank 0: FLAGSTATS_hip_comm_unique_id(id) -> ship the 128 bytes to every rank by any means
+ *   all:    comm = FLAGSTATS_hip_comm_init_rank(id, nranks, rank, device)
+ *   query:  FLAGSTATS_hip_device_u16_allreduce(d_shard, n, d_out, comm, stream)
+ *           = K1 + K2 storing this shard's counters into d_out[32], then ONE
+ *             ncclAllReduce(d_out, d_out, 32, ncclUint64, ncclSum) on the same stream. */
+int FLAGSTATS_hip_comm_unique_id(void* id128);
+void* FLAGSTATS_hip_comm_init_rank(const void* id128, int nranks, int rank, int device); /* NULL on failure */
+int FLAGSTATS_hip_comm_destroy(void* comm);
+int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* stream);
+int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream);
+
+/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _CHUNK_FLAGS / _ON_ERROR / _NUMA).  key =
  *   "blocks_per_cu"  workgroups per CU of K1's grid (default 1)
  *   "variant"        K1 schedule: bit0 non-temporal loads, bit1 chain depth 7, bit2 register
  *                    prefetch, bit3 interleaved waves, bit4 rolling re-issue, bit5 LDS-DMA ring, bit6
  *                    rolling at distance 2 (default 25; instantiated: 0, 1, 9, 13, 25, 27, 41, 89)
  *   "fuse"           0 = K1 + K2 (default); 1 = K1 finalises itself, one kernel per call
  *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB)
+ *   "on_error"       reference-shaped entry points on failure: 1 abort() after the message (default), 0 return non-zero
+ *   "numa"           1 (default): pinned buffers and block-decoder threads are placed on the GPU's host NUMA node
+ * Read-only keys of FLAGSTATS_hip_get: "grid" (K1 workgroups), "numa_node" (of the default device),
+ * "host_chunks" / "host_overlapped" (last multi-chunk host-pointer call on the default engine: chunks
+ * submitted / chunks handed over while the previous chunk's copy + kernel were still in flight).
  * Returns 0 on success. */
 int FLAGSTATS_hip_set(const char* key, uint64_t value);
 uint64_t FLAGSTATS_hip_get(const char* key);
@@ -90,7 +142,8 @@ uint64_t FLAGSTATS_hip_get(const char* key);
 /* ---- memory helpers for callers without a HIP runtime of their own ---- */
 void* FLAGSTATS_hip_host_alloc(size_t bytes);   /* pinned host memory */
 void FLAGSTATS_hip_host_free(void* p);
-void* FLAGSTATS_hip_device_alloc(size_t bytes); /* device memory */
+void* FLAGSTATS_hip_device_alloc(size_t bytes); /* device memory on the default device */
+void* FLAGSTATS_hip_device_alloc_on(int device, size_t bytes);
 void FLAGSTATS_hip_device_free(void* p);
 int FLAGSTATS_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int FLAGSTATS_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);

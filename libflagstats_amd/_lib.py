@@ -35,6 +35,23 @@ SIGNATURES = {
     "FLAGSTATS_hip_device_u16_store": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
     "FLAGSTATS_hip_device_u16_sync": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
     "FLAGSTATS_hip_available": (ctypes.c_int, []),
+    "FLAGSTATS_hip_device_count": (ctypes.c_int, []),
+    "FLAGSTATS_hip_ctx_create": (ctypes.c_void_p, [ctypes.c_int]),
+    "FLAGSTATS_hip_ctx_destroy": (None, [ctypes.c_void_p]),
+    "FLAGSTATS_hip_ctx_device": (ctypes.c_int, [ctypes.c_void_p]),
+    "FLAGSTATS_hip_ctx_u16_x64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "FLAGSTATS_hip_ctx_device_u16_sync": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "FLAGSTATS_hip_shard_range": (None, [ctypes.c_uint64, ctypes.c_int, ctypes.c_int, _U64P, _U64P]),
+    "FLAGSTATS_hip_multi_u16_x64": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int), ctypes.c_int,
+                                                   ctypes.c_void_p]),
+    "FLAGSTATS_hip_multi_device_u16": (ctypes.c_int, [ctypes.POINTER(ctypes.c_void_p), _U64P, ctypes.c_int, ctypes.c_void_p]),
+    "FLAGSTATS_hip_comm_unique_id": (ctypes.c_int, [ctypes.c_void_p]),
+    "FLAGSTATS_hip_comm_init_rank": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
+    "FLAGSTATS_hip_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
+    "FLAGSTATS_hip_allreduce_counters": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
+    "FLAGSTATS_hip_device_u16_allreduce": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                                          ctypes.c_void_p]),
+    "FLAGSTATS_hip_device_alloc_on": (ctypes.c_void_p, [ctypes.c_int, ctypes.c_size_t]),
     "FLAGSTATS_hip_init": (ctypes.c_int, [ctypes.c_int]),
     "FLAGSTATS_hip_shutdown": (None, []),
     "FLAGSTATS_hip_last_error": (ctypes.c_char_p, []),
@@ -124,6 +141,11 @@ def lib() -> ctypes.CDLL:
         fn = getattr(handle, name)  # AttributeError here = header/library drift
         fn.restype = restype
         fn.argtypes = argtypes
+    # every Python call site checks return codes and raises FlagstatsHipError, so the reference-shaped
+    # entry points return their error here instead of abort()ing (the C default for callers that
+    # ignore it); an explicit FLAGSTATS_HIP_ON_ERROR in the environment wins
+    if "FLAGSTATS_HIP_ON_ERROR" not in os.environ:
+        handle.FLAGSTATS_hip_set(b"on_error", 0)
     _lib = handle
     return handle
 

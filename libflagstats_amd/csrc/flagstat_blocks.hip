@@ -19,6 +19,8 @@
 // length bytes, 2-byte little-endian offset, last sequence literals-only) and is checked in
 // tests/ against the image's liblz4.so.1 (1.9.3) acting as oracle.
 #include <fcntl.h>
+#include <pthread.h>
+#include <sched.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
@@ -33,7 +35,7 @@
 #include <vector>
 
 #include "../../include/libflagstats_hip.h"
-#include "flagstat_ctx.h"
+#include "flagstat_engine.h"
 
 namespace {
 
@@ -184,6 +186,39 @@ int index_blocks(const uint8_t* img, int fd, uint64_t bytes, uint64_t chunk_cap,
     return 0;
 }
 
+// CPUs of a host NUMA node ("/sys/devices/system/node/nodeN/cpulist", e.g. "0-63,128-191")
+bool node_cpuset(int node, cpu_set_t* set)
+{
+    CPU_ZERO(set);
+    if (node < 0) return false;
+    char path[96];
+    std::snprintf(path, sizeof path, "/sys/devices/system/node/node%d/cpulist", node);
+    FILE* f = std::fopen(path, "r");
+    if (!f) return false;
+    char buf[4096];
+    const bool have = std::fgets(buf, sizeof buf, f) != nullptr;
+    std::fclose(f);
+    if (!have) return false;
+    int count = 0;
+    for (char* p = buf; *p && *p != '\n';) {
+        char* end = nullptr;
+        const long a = std::strtol(p, &end, 10);
+        if (end == p) break;
+        long b = a;
+        p = end;
+        if (*p == '-') {
+            b = std::strtol(p + 1, &end, 10);
+            p = end;
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c) {
+            CPU_SET(static_cast<int>(c), set);
+            ++count;
+        }
+        if (*p == ',') ++p;
+    }
+    return count > 0;
+}
+
 struct Pipe {
     std::mutex m;
     std::condition_variable cv_workers;  // "a chunk buffer was released" (orchestrator -> decoders)
@@ -202,7 +237,8 @@ constexpr int kPinned = 3;
 // preads the compressed payload of its block into a private buffer.  (mmap-ing the file instead
 // makes all decode threads fault on one address space; the contention grows with the thread
 // count and was measured to cost more than the extra copy.)
-int run_pipeline(const uint8_t* img, int fd, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* st)
+int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, int threads, uint64_t* out,
+                 FLAGSTATS_blockfile_stats* st)
 {
     const double t0 = now_s();
     uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
@@ -222,11 +258,12 @@ int run_pipeline(const uint8_t* img, int fd, uint64_t bytes, int threads, uint64
     }
     if (static_cast<size_t>(threads) > blocks.size() && !blocks.empty()) threads = static_cast<int>(blocks.size());
 
-    std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
-    rc = fsint::bind_ctx();
-    if (rc) return rc;
+    // the engine's host pipeline (staging buffers, two streams, counters, pinned chunks) is one resource
+    std::lock_guard<std::mutex> lk(eng.mu);
+    fsint::DeviceGuard guard(eng.device);
+    if (!guard.ok()) return -1;
     if (!chunks.empty()) {
-        rc = fsint::stage_reserve(chunk_cap / 2);
+        for (int s = 0; s < 2 && !rc; ++s) rc = fsint::stage_reserve(eng, s, chunk_cap / 2);
         if (rc) return rc;
     }
     uint8_t* pinned[kPinned] = {nullptr, nullptr, nullptr};
@@ -234,7 +271,7 @@ int run_pipeline(const uint8_t* img, int fd, uint64_t bytes, int threads, uint64
     const int npin = chunks.size() < static_cast<size_t>(kPinned) ? static_cast<int>(chunks.size()) : kPinned;
     if (npin) {
         void* bufs[3];
-        rc = fsint::pinned_reserve(chunk_cap, bufs);  // allocated once per process: hipHostMalloc costs ~10 ms / 64 MiB
+        rc = fsint::pinned_reserve(eng, chunk_cap, bufs);  // allocated once per process: hipHostMalloc costs ~10 ms / 64 MiB
         if (rc) return rc;
         for (int i = 0; i < kPinned; ++i) pinned[i] = static_cast<uint8_t*>(bufs[i]);
     }
@@ -244,13 +281,19 @@ int run_pipeline(const uint8_t* img, int fd, uint64_t bytes, int threads, uint64
     }
     const double t_setup = now_s() - t0;
     for (int s = 0; s < 2; ++s) {
-        hipError_t e = hipMemsetAsync(fsint::dev_out(s), 0, 32 * sizeof(uint64_t), fsint::stream(s));
+        hipError_t e = hipMemsetAsync(eng.d_out[s], 0, 32 * sizeof(uint64_t), eng.stream[s]);
         if (e != hipSuccess) return fsint::fail_hip("hipMemsetAsync", e);
     }
 
     Pipe pipe(chunks.size());
     for (auto& a : pipe.next) a.store(0);
+    // decoders run on the CPUs of the GPU's own NUMA node, next to the pinned chunk buffers
+    // (fsint::pinned_reserve places those there): decoded bytes then cross no socket link on their
+    // way to the PCIe root.  Knob "numa" / FLAGSTATS_HIP_NUMA=0 turns both off.
+    cpu_set_t node_cpus;
+    const bool pin_threads = fsint::knobs().numa.load() && node_cpuset(eng.numa_node, &node_cpus);
     auto worker = [&]() {
+        if (pin_threads) (void)pthread_setaffinity_np(pthread_self(), sizeof node_cpus, &node_cpus);
         double busy = 0;
         std::vector<uint8_t> local;  // file mode: this thread's copy of the compressed payload
         for (size_t c = 0; c < chunks.size(); ++c) {
@@ -334,13 +377,13 @@ int run_pipeline(const uint8_t* img, int fd, uint64_t bytes, int threads, uint64
         }
         const int sl = static_cast<int>(c & 1);
         const int pb = static_cast<int>(c % kPinned);
-        hipError_t e = hipMemcpyAsync(fsint::stage_buf(sl), pinned[pb], chunks[c].bytes, hipMemcpyHostToDevice, fsint::stream(sl));
-        if (e == hipSuccess) e = hipEventRecord(copied[pb], fsint::stream(sl));
+        hipError_t e = hipMemcpyAsync(eng.stage[sl], pinned[pb], chunks[c].bytes, hipMemcpyHostToDevice, eng.stream[sl]);
+        if (e == hipSuccess) e = hipEventRecord(copied[pb], eng.stream[sl]);
         if (e != hipSuccess) {
             err = fsint::fail_hip("hipMemcpyAsync(chunk)", e);
             break;
         }
-        err = fsint::count_async(fsint::stage_buf(sl), chunks[c].bytes / 2, sl);
+        err = fsint::count_device_async(eng, eng.stage[sl], chunks[c].bytes / 2, eng.d_out[sl], eng.stream[sl], eng.ws[sl]);
         if (err) break;
         if (c >= 1 && (c - 1) + kPinned < chunks.size()) {
             // The pinned buffer of chunk c-1 is reusable once ITS copy has left the host.  Waiting for
@@ -366,13 +409,13 @@ int run_pipeline(const uint8_t* img, int fd, uint64_t bytes, int threads, uint64
     const double t_d = now_s();
     if (!err) {
         for (int s = 0; s < 2 && !err; ++s) {
-            hipError_t e = hipMemcpyAsync(fsint::host_out() + 32 * s, fsint::dev_out(s), 32 * sizeof(uint64_t),
-                                          hipMemcpyDeviceToHost, fsint::stream(s));
+            hipError_t e = hipMemcpyAsync(eng.h_out + 32 * s, eng.d_out[s], 32 * sizeof(uint64_t),
+                                          hipMemcpyDeviceToHost, eng.stream[s]);
             if (e != hipSuccess) err = fsint::fail_hip("hipMemcpyAsync(counters)", e);
         }
     }
     for (int s = 0; s < 2; ++s) {
-        hipError_t e = hipStreamSynchronize(fsint::stream(s));
+        hipError_t e = hipStreamSynchronize(eng.stream[s]);
         if (e != hipSuccess && !err) err = fsint::fail_hip("hipStreamSynchronize", e);
     }
     for (int i = 0; i < npin; ++i) (void)hipEventDestroy(copied[i]);
@@ -380,7 +423,7 @@ int run_pipeline(const uint8_t* img, int fd, uint64_t bytes, int threads, uint64
         fprintf(stderr, "blocks: spawn %.4f loop %.4f join %.4f sync %.4f\n", t_b - t_a, t_c - t_b, t_d - t_c, now_s() - t_d);
     if (err) return err;
     for (int s = 0; s < 2; ++s)
-        for (int k = 0; k < 32; ++k) out[k] += fsint::host_out()[32 * s + k];
+        for (int k = 0; k < 32; ++k) out[k] += eng.h_out[32 * s + k];
     if (st) {
         st->n_flags = n_flags;
         st->n_blocks = blocks.size();
@@ -444,7 +487,9 @@ int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads,
     if (!out) return fsint::fail_text("NULL out");
     if (!image && bytes) return fsint::fail_text("NULL image");
     static const uint8_t empty = 0;
-    return run_pipeline(image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, out, stats);
+    fsint::Engine* eng = fsint::default_engine();
+    if (!eng) return -1;
+    return run_pipeline(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, out, stats);
 }
 
 int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
@@ -459,7 +504,8 @@ int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FL
         return fsint::fail_text("cannot stat file");
     }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
-    const int rc = run_pipeline(nullptr, fd, static_cast<uint64_t>(sb.st_size), threads, out, stats);
+    fsint::Engine* eng = fsint::default_engine();
+    const int rc = eng ? run_pipeline(*eng, nullptr, fd, static_cast<uint64_t>(sb.st_size), threads, out, stats) : -1;
     close(fd);
     return rc;
 }
@@ -472,13 +518,10 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
     int rc = map_file(path, m);
     if (rc) return rc;
     const uint64_t n = m.bytes / 2;  // a trailing odd byte is dropped, as `read >> 1` at benchmark/flagstats.cpp:450
-    {
-        std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
-        rc = fsint::bind_ctx();
-        if (rc) return rc;
-        rc = fsint::count_host_array(reinterpret_cast<const uint16_t*>(m.p), n, out);
-        if (rc) return rc;
-    }
+    fsint::Engine* eng = fsint::default_engine();
+    if (!eng) return -1;
+    rc = fsint::count_host(*eng, reinterpret_cast<const uint16_t*>(m.p), n, out);
+    if (rc) return rc;
     if (stats) {
         std::memset(stats, 0, sizeof *stats);
         stats->n_flags = n;

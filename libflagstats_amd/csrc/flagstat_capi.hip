@@ -1,436 +1,301 @@
-// flagstat_capi.hip -- the C-ABI boundary (include/libflagstats_hip.h): a thin host
-// shim (hipMalloc / hipMemcpyAsync / kernel launches) around the kernels in
-// flagstat_kernels.hip.  Replaces the dispatch layer of the reference,
-// libflagstats.h:2967-3070 (FLAGSTATS_func, FLAGSTATS_get_function,
-// FLAGSTATS_u16).  No CPU compute path exists here: failures are loud.
+// flagstat_capi.hip -- the C-ABI boundary (include/libflagstats_hip.h): a thin host shim
+// (hipMalloc / hipMemcpyAsync / kernel launches) around the kernels in flagstat_kernels.hip.
+// Replaces the dispatch layer of the reference, libflagstats.h:2967-3070 (FLAGSTATS_func,
+// FLAGSTATS_get_function, FLAGSTATS_u16).  No CPU compute path exists here: failures are loud.
+// State lives in per-device engines (flagstat_engine.h); this file only routes.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
-#include <map>
-#include <mutex>
-#include <string>
 
 #include "../../include/libflagstats_hip.h"
+#include "flagstat_engine.h"
 #include "flagstat_kernels.h"
+
+using fsint::DeviceGuard;
+using fsint::Engine;
+using fsint::fail_hip;
+using fsint::fail_text;
+
+struct FLAGSTATS_hip_ctx {
+    Engine* engine;
+};
 
 namespace {
 
-thread_local std::string g_err;
-
-struct Workspace {
-    uint64_t* partials = nullptr;  // [grid][19]
-    uint32_t grid_cap = 0;
-};
-
-struct Ctx {
-    bool ready = false;
-    int device = -1;
-    int cus = 0;
-    uint32_t blocks_per_cu = 0;  // 0 = auto
-    int variant = 25;                    // DEPTH 8, nt loads, interleaved waves, rolling re-issue (tools/tune.py)
-    int fuse = 0;                        // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
-    uint64_t chunk_flags = 32ull << 20;  // host streaming chunk: 32 Mi flags = 64 MiB
-    hipStream_t stream[2] = {nullptr, nullptr};
-    Workspace ws[2];
-    uint64_t* d_out[2] = {nullptr, nullptr};   // device uint64[32] per slot
-    uint16_t* stage[2] = {nullptr, nullptr};   // device staging for host arrays
-    uint64_t stage_flags = 0;
-    uint64_t* h_out = nullptr;                 // pinned 2 x 32
-    std::map<void*, Workspace> user_ws;        // workspaces for caller-owned streams
-    void* pinned[3] = {nullptr, nullptr, nullptr};  // block-file chunk buffers (flagstat_blocks.hip), kept across calls
-    uint64_t pinned_bytes = 0;
-};
-
-Ctx g;
-std::recursive_mutex g_mu;
-
-int fail(const char* what, hipError_t e)
-{
-    char buf[512];
-    std::snprintf(buf, sizeof buf, "libflagstats_hip: %s failed: %s (%d)", what, hipGetErrorString(e), (int)e);
-    g_err = buf;
-    std::fprintf(stderr, "%s\n", buf);
-    return (int)e ? (int)e : -1;
-}
-
-int fail_msg(const char* msg)
-{
-    g_err = std::string("libflagstats_hip: ") + msg;
-    std::fprintf(stderr, "%s\n", g_err.c_str());
-    return -1;
-}
-
-#define HIP_TRY(expr)                                  \
-    do {                                               \
-        hipError_t e_ = (expr);                        \
-        if (e_ != hipSuccess) return fail(#expr, e_);  \
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t e_ = (expr);                            \
+        if (e_ != hipSuccess) return fail_hip(#expr, e_);  \
     } while (0)
 
-uint64_t env_u64(const char* name, uint64_t dflt)
+// The reference's entry points have no error channel and its callers ignore the return value
+// (python/libflagstats.pyx:22, benchmark/flagstats.cpp:329): a failed GPU call must not turn into
+// silently-zero counters there.  Policy knob "on_error" (env FLAGSTATS_HIP_ON_ERROR=abort|return):
+// 1 (default) = the message is followed by abort(); 0 = return non-zero (for callers that check).
+int legacy_result(int rc, const char* entry)
 {
-    const char* s = std::getenv(name);
-    if (!s || !*s) return dflt;
-    return std::strtoull(s, nullptr, 0);
+    if (rc != 0 && fsint::knobs().on_error.load()) {
+        std::fprintf(stderr,
+                     "libflagstats_hip: %s cannot return an error to a caller of the reference API, and there is no CPU "
+                     "fallback: aborting (FLAGSTATS_HIP_ON_ERROR=return makes it return non-zero instead)\n",
+                     entry);
+        std::fflush(stderr);
+        std::abort();
+    }
+    return rc;
 }
 
-uint32_t grid_for(uint64_t n)
-{
-    (void)n;
-    uint32_t bpc = g.blocks_per_cu ? g.blocks_per_cu : 1;
-    return (uint32_t)g.cus * bpc;
-}
-
-int ensure_ws(Workspace& w, uint32_t grid)
-{
-    if (w.grid_cap >= grid) return 0;
-    if (w.partials) HIP_TRY(hipFree(w.partials));
-    w.partials = nullptr;
-    w.grid_cap = 0;
-    HIP_TRY(hipMalloc(&w.partials, fsk_partials_bytes(grid)));
-    HIP_TRY(hipMemset(w.partials, 0, fsk_partials_bytes(grid)));  // the ticket word must start at 0
-    w.grid_cap = grid;
-    return 0;
-}
-
-int init_locked(int device)
-{
-    if (g.ready) {
-        if (device >= 0 && device != g.device) return fail_msg("already initialised on another device");
+struct EventPair {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ~EventPair()
+    {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+    }
+    int create()
+    {
+        HIP_TRY(hipEventCreate(&e0));
+        HIP_TRY(hipEventCreate(&e1));
         return 0;
     }
-    int count = 0;
-    hipError_t e = hipGetDeviceCount(&count);
-    if (e != hipSuccess || count <= 0) return fail("hipGetDeviceCount (no usable GPU)", e == hipSuccess ? hipErrorNoDevice : e);
-    if (device < 0) device = (int)env_u64("FLAGSTATS_HIP_DEVICE", 0);
-    if (device >= count) return fail_msg("device index out of range");
-    HIP_TRY(hipSetDevice(device));
-    hipDeviceProp_t prop;
-    HIP_TRY(hipGetDeviceProperties(&prop, device));
-    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        char buf[256];
-        std::snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 (MI355X) code only", device,
-                      prop.gcnArchName);
-        return fail_msg(buf);
-    }
-    g.device = device;
-    g.cus = prop.multiProcessorCount;
-    g.blocks_per_cu = (uint32_t)env_u64("FLAGSTATS_HIP_BLOCKS_PER_CU", g.blocks_per_cu);
-    g.variant = (int)env_u64("FLAGSTATS_HIP_VARIANT", (uint64_t)g.variant);
-    g.chunk_flags = env_u64("FLAGSTATS_HIP_CHUNK_FLAGS", g.chunk_flags);
-    g.fuse = (int)env_u64("FLAGSTATS_HIP_FUSE", (uint64_t)g.fuse);
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&g.stream[i], hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&g.d_out[i], 32 * sizeof(uint64_t)));
-    }
-    HIP_TRY(hipHostMalloc(&g.h_out, 2 * 32 * sizeof(uint64_t), hipHostMallocDefault));
-    g.ready = true;
-    return 0;
-}
+};
 
-int ensure_init()
+// device-resident array -> host counters through an engine's own stream; takes e.mu
+int count_device_sync(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* out, int op = fsint::OP_FLAGSTAT)
 {
-    return g.ready ? 0 : init_locked(-1);
-}
-
-// make sure the calling thread targets the context's device
-int bind()
-{
-    int rc = ensure_init();
+    std::lock_guard<std::mutex> lk(e.mu);
+    DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    HIP_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), e.stream[0]));
+    int rc = fsint::count_device_async(e, d_array, n, e.d_out[0], e.stream[0], e.ws[0], op);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(g.device));
+    HIP_TRY(hipMemcpyAsync(e.h_out, e.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, e.stream[0]));
+    HIP_TRY(hipStreamSynchronize(e.stream[0]));
+    for (int s = 0; s < 32; ++s) out[s] += e.h_out[s];
     return 0;
 }
 
-enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2 };
-
-int count_device_async(const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w,
-                       int op = OP_FLAGSTAT)
+Engine* engine_of_array(const uint16_t* d_array, uint64_t n)
 {
-    if (n == 0) {
-        if (op == OP_FLAGSTAT_STORE) HIP_TRY(hipMemsetAsync(d_out, 0, 32 * sizeof(uint64_t), s));
-        return 0;
-    }
-    if (!d_array) return fail_msg("NULL array with n > 0");
-    if (reinterpret_cast<uintptr_t>(d_array) & 1u) return fail_msg("array must be 2-byte aligned");
-    const uint32_t grid = grid_for(n);
-    int rc = ensure_ws(w, grid);
-    if (rc) return rc;
-    if (op == OP_POSPOPCNT)
-        HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s));
-    else
-        HIP_TRY(fsk_launch(d_array, n, grid, g.variant | (op == OP_FLAGSTAT_STORE ? 256 : 0) | (g.fuse ? 512 : 0), w.partials,
-                           reinterpret_cast<uint32_t*>(w.partials + (size_t)w.grid_cap * fsk::kInternal), d_out, s));
-    return 0;
-}
-
-int ensure_stage(uint64_t flags)
-{
-    if (g.stage_flags >= flags) return 0;
-    for (int i = 0; i < 2; ++i) {
-        if (g.stage[i]) HIP_TRY(hipFree(g.stage[i]));
-        g.stage[i] = nullptr;
-    }
-    g.stage_flags = 0;
-    for (int i = 0; i < 2; ++i) HIP_TRY(hipMalloc(&g.stage[i], flags * sizeof(uint16_t)));
-    g.stage_flags = flags;
-    return 0;
-}
-
-// host array -> counters: double-buffered H2D + K1/K2 per chunk on two streams
-int count_host(const uint16_t* h, uint64_t n, uint64_t* out, int op = OP_FLAGSTAT)
-{
-    const int nout = (op == OP_POSPOPCNT) ? 16 : 32;
-    if (n == 0) return 0;
-    if (!h) return fail_msg("NULL array with n > 0");
-    const uint64_t chunk = g.chunk_flags < 8 ? 8 : g.chunk_flags;
-    int rc = ensure_stage(n < chunk ? n : chunk);
-    if (rc) return rc;
-    const int slots = (n > chunk) ? 2 : 1;
-    if (slots == 1 && op == OP_FLAGSTAT) {
-        // latency path (what an unmodified per-block caller of the reference hits, e.g. 512,000 flags
-        // per call, benchmark/flagstats.cpp:328-329): one copy, K1, and K2 STORING straight into the
-        // pinned host result buffer -- no counter memset, no D2H copy
-        uint64_t* h_out_dev = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_out_dev), g.h_out, 0));
-        HIP_TRY(hipMemcpyAsync(g.stage[0], h, n * sizeof(uint16_t), hipMemcpyHostToDevice, g.stream[0]));
-        rc = count_device_async(g.stage[0], n, h_out_dev, g.stream[0], g.ws[0], OP_FLAGSTAT_STORE);
-        if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(g.stream[0]));
-        for (int s = 0; s < 32; ++s) out[s] += g.h_out[s];
-        return 0;
-    }
-    for (int i = 0; i < slots; ++i) HIP_TRY(hipMemsetAsync(g.d_out[i], 0, 32 * sizeof(uint64_t), g.stream[i]));
-    uint64_t done = 0;
-    for (uint64_t k = 0; done < n; ++k) {
-        const int sl = (int)(k & 1);
-        const uint64_t c = (n - done < chunk) ? n - done : chunk;
-        // same stream per slot: the copy into stage[sl] is ordered after the
-        // kernel that last read it
-        HIP_TRY(hipMemcpyAsync(g.stage[sl], h + done, c * sizeof(uint16_t), hipMemcpyHostToDevice, g.stream[sl]));
-        rc = count_device_async(g.stage[sl], c, g.d_out[sl], g.stream[sl], g.ws[sl], op);
-        if (rc) return rc;
-        done += c;
-    }
-    for (int i = 0; i < slots; ++i)
-        HIP_TRY(hipMemcpyAsync(g.h_out + 32 * i, g.d_out[i], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream[i]));
-    for (int i = 0; i < slots; ++i) HIP_TRY(hipStreamSynchronize(g.stream[i]));
-    for (int i = 0; i < slots; ++i)
-        for (int s = 0; s < nout; ++s) out[s] += g.h_out[32 * i + s];
-    return 0;
+    if (n == 0 || !d_array) return fsint::default_engine();
+    int dev = -1;
+    if (fsint::device_of_pointer(d_array, "d_array", &dev)) return nullptr;
+    return fsint::engine_for_device(dev);
 }
 
 }  // namespace
-
-// internal surface for flagstat_blocks.hip (block-file pipeline), declared in flagstat_ctx.h
-namespace fsint {
-std::recursive_mutex& mutex() { return g_mu; }
-int bind_ctx() { return bind(); }
-int fail_text(const char* msg) { return fail_msg(msg); }
-int fail_hip(const char* what, hipError_t e) { return fail(what, e); }
-int stage_reserve(uint64_t flags) { return ensure_stage(flags); }
-uint16_t* stage_buf(int slot) { return g.stage[slot]; }
-hipStream_t stream(int slot) { return g.stream[slot]; }
-uint64_t* dev_out(int slot) { return g.d_out[slot]; }
-uint64_t* host_out() { return g.h_out; }
-int count_async(const uint16_t* d, uint64_t n, int slot) { return count_device_async(d, n, g.d_out[slot], g.stream[slot], g.ws[slot]); }
-int count_async_to(const uint16_t* d, uint64_t n, uint64_t* d_out, int slot) { return count_device_async(d, n, d_out, g.stream[slot], g.ws[slot]); }
-int count_host_array(const uint16_t* h, uint64_t n, uint64_t* out) { return count_host(h, n, out); }
-uint64_t chunk_bytes() { return g.chunk_flags * 2; }
-// three pinned host buffers of >= bytes each, allocated once and reused by later calls
-int pinned_reserve(uint64_t bytes, void* bufs[3])
-{
-    if (g.pinned_bytes < bytes) {
-        for (int i = 0; i < 3; ++i) {
-            if (g.pinned[i]) (void)hipHostFree(g.pinned[i]);
-            g.pinned[i] = nullptr;
-        }
-        g.pinned_bytes = 0;
-        for (int i = 0; i < 3; ++i) {
-            hipError_t e = hipHostMalloc(&g.pinned[i], bytes, hipHostMallocDefault);
-            if (e != hipSuccess) return fail("hipHostMalloc(chunk buffer)", e);
-        }
-        g.pinned_bytes = bytes;
-    }
-    for (int i = 0; i < 3; ++i) bufs[i] = g.pinned[i];
-    return 0;
-}
-}  // namespace fsint
 
 extern "C" {
 
 int FLAGSTATS_hip_available(void)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (g.ready) return 1;
+    if (fsint::default_device() >= 0) return 1;
     int count = 0;
-    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
+        (void)hipGetLastError();
+        return 0;
+    }
     hipDeviceProp_t prop;
-    const int dev = (int)env_u64("FLAGSTATS_HIP_DEVICE", 0);
-    if (dev >= count || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
+    const char* s = std::getenv("FLAGSTATS_HIP_DEVICE");
+    const int dev = (s && *s) ? std::atoi(s) : 0;
+    if (dev < 0 || dev >= count || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 0;
     return std::strncmp(prop.gcnArchName, "gfx950", 6) == 0;
 }
 
-int FLAGSTATS_hip_init(int device)
+int FLAGSTATS_hip_device_count(void)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    return init_locked(device);
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return count;
 }
+
+int FLAGSTATS_hip_init(int device) { return fsint::select_default_device(device); }
 
 void FLAGSTATS_hip_shutdown(void)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!g.ready) return;
-    (void)hipSetDevice(g.device);
-    (void)hipDeviceSynchronize();
-    for (int i = 0; i < 2; ++i) {
-        if (g.ws[i].partials) (void)hipFree(g.ws[i].partials);
-        if (g.d_out[i]) (void)hipFree(g.d_out[i]);
-        if (g.stage[i]) (void)hipFree(g.stage[i]);
-        if (g.stream[i]) (void)hipStreamDestroy(g.stream[i]);
-    }
-    for (auto& kv : g.user_ws)
-        if (kv.second.partials) (void)hipFree(kv.second.partials);
-    if (g.h_out) (void)hipHostFree(g.h_out);
-    for (int i = 0; i < 3; ++i)
-        if (g.pinned[i]) (void)hipHostFree(g.pinned[i]);
-    const uint32_t bpc = g.blocks_per_cu;
-    const int variant = g.variant;
-    const int fuse = g.fuse;
-    const uint64_t chunk = g.chunk_flags;
-    g = Ctx();
-    g.blocks_per_cu = bpc;
-    g.variant = variant;
-    g.fuse = fuse;
-    g.chunk_flags = chunk;
+    fsint::multi_forget();
+    fsint::shutdown_all();
 }
 
-const char* FLAGSTATS_hip_last_error(void) { return g_err.c_str(); }
+const char* FLAGSTATS_hip_last_error(void) { return fsint::last_error_text(); }
 
-int FLAGSTATS_hip_device_id(void)
-{
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    return g.ready ? g.device : -1;
-}
+int FLAGSTATS_hip_device_id(void) { return fsint::default_device(); }
 
 int FLAGSTATS_hip_compute_units(void)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    return g.ready ? g.cus : -1;
+    if (fsint::default_device() < 0) return -1;
+    Engine* e = fsint::default_engine();
+    return e ? e->cus : -1;
 }
 
 int FLAGSTATS_hip_set(const char* key, uint64_t value)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!key) return fail_msg("NULL key");
+    if (!key) return fail_text("NULL key");
+    fsint::Knobs& k = fsint::knobs();
     if (!std::strcmp(key, "blocks_per_cu")) {
-        if (value > 16) return fail_msg("blocks_per_cu must be 0 (auto) .. 16");
-        g.blocks_per_cu = (uint32_t)value;
+        if (value > 16) return fail_text("blocks_per_cu must be 0 (auto) .. 16");
+        k.blocks_per_cu = static_cast<uint32_t>(value);
     } else if (!std::strcmp(key, "variant")) {
-        if (value > 127) return fail_msg("variant must be 0..127");
-        g.variant = (int)value;
+        if (value > 127) return fail_text("variant must be 0..127");
+        k.variant = static_cast<int>(value);
     } else if (!std::strcmp(key, "fuse")) {
-        if (value > 1) return fail_msg("fuse must be 0 or 1");
-        g.fuse = (int)value;
+        if (value > 1) return fail_text("fuse must be 0 or 1");
+        k.fuse = static_cast<int>(value);
     } else if (!std::strcmp(key, "chunk_flags")) {
-        if (value < 8) return fail_msg("chunk_flags must be >= 8");
-        g.chunk_flags = value;
+        if (value < 8) return fail_text("chunk_flags must be >= 8");
+        k.chunk_flags = value;
+    } else if (!std::strcmp(key, "on_error")) {
+        if (value > 1) return fail_text("on_error must be 0 (return) or 1 (abort)");
+        k.on_error = static_cast<int>(value);
+    } else if (!std::strcmp(key, "numa")) {
+        if (value > 1) return fail_text("numa must be 0 or 1");
+        k.numa = static_cast<int>(value);
     } else {
-        return fail_msg("unknown key");
+        return fail_text("unknown key");
     }
     return 0;
 }
 
 uint64_t FLAGSTATS_hip_get(const char* key)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
     if (!key) return 0;
-    if (!std::strcmp(key, "blocks_per_cu")) return g.blocks_per_cu ? g.blocks_per_cu : 1;
-    if (!std::strcmp(key, "variant")) return (uint64_t)g.variant;
-    if (!std::strcmp(key, "chunk_flags")) return g.chunk_flags;
-    if (!std::strcmp(key, "fuse")) return (uint64_t)g.fuse;
-    if (!std::strcmp(key, "grid")) return g.ready ? grid_for(0) : 0;
+    fsint::Knobs& k = fsint::knobs();
+    if (!std::strcmp(key, "blocks_per_cu")) return k.blocks_per_cu ? k.blocks_per_cu.load() : 1;
+    if (!std::strcmp(key, "variant")) return static_cast<uint64_t>(k.variant.load());
+    if (!std::strcmp(key, "chunk_flags")) return k.chunk_flags.load();
+    if (!std::strcmp(key, "fuse")) return static_cast<uint64_t>(k.fuse.load());
+    if (!std::strcmp(key, "on_error")) return static_cast<uint64_t>(k.on_error.load());
+    if (!std::strcmp(key, "numa")) return static_cast<uint64_t>(k.numa.load());
+    if (!std::strcmp(key, "grid")) {
+        if (fsint::default_device() < 0) return 0;
+        Engine* e = fsint::default_engine();
+        return e ? fsint::grid_for(*e) : 0;
+    }
+    if (!std::strcmp(key, "host_chunks") || !std::strcmp(key, "host_overlapped")) {
+        if (fsint::default_device() < 0) return 0;
+        Engine* e = fsint::default_engine();
+        if (!e) return 0;
+        std::lock_guard<std::mutex> lk(e->mu);
+        return key[5] == 'c' ? e->host_chunks : e->host_overlapped;
+    }
+    if (!std::strcmp(key, "numa_node")) {
+        if (fsint::default_device() < 0) return static_cast<uint64_t>(-1);
+        Engine* e = fsint::default_engine();
+        return e ? static_cast<uint64_t>(static_cast<int64_t>(e->numa_node)) : static_cast<uint64_t>(-1);
+    }
     return 0;
 }
 
 int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!out) return fail_msg("NULL out");
-    int rc = bind();
-    if (rc) return rc;
-    return count_host(array, n, out);
+    if (!out) return fail_text("NULL out");
+    Engine* e = fsint::default_engine();
+    if (!e) return -1;
+    return fsint::count_host(*e, array, n, out);
 }
 
-int FLAGSTAT_hip(const uint16_t* array, uint32_t len, uint32_t* flags)
+static int flagstat_hip_u32(const uint16_t* array, uint32_t len, uint32_t* flags)
 {
-    if (!flags) return fail_msg("NULL flags");
+    if (!flags) return fail_text("NULL flags");
     uint64_t wide[32];
     std::memset(wide, 0, sizeof wide);
     const int rc = FLAGSTATS_u16_x64(array, len, wide);
     if (rc) return rc;
-    for (int i = 0; i < 32; ++i) flags[i] += (uint32_t)wide[i];
+    for (int i = 0; i < 32; ++i) flags[i] += static_cast<uint32_t>(wide[i]);
     return 0;
+}
+
+int FLAGSTAT_hip(const uint16_t* array, uint32_t len, uint32_t* flags)
+{
+    return legacy_result(flagstat_hip_u32(array, len, flags), "FLAGSTAT_hip");
 }
 
 uint64_t FLAGSTATS_u16(const uint16_t* array, uint32_t n_len, uint32_t* flags)
 {
     // libflagstats.h:3024-3070 forwards the kernel's int as uint64_t
-    return (uint64_t)(int64_t)FLAGSTAT_hip(array, n_len, flags);
+    return static_cast<uint64_t>(static_cast<int64_t>(legacy_result(flagstat_hip_u32(array, n_len, flags), "FLAGSTATS_u16")));
 }
 
 FLAGSTATS_func FLAGSTATS_get_function(uint32_t n_len)
 {
+    // One kernel family, no host kernels: every length gets the GPU path.  The length-aware rule of
+    // libflagstats.h:2999-3021 (small n stays on the host's own SIMD kernels) belongs to the reference's
+    // dispatcher; INTEGRATION.md section B adds this library as its first branch, threshold
+    // FLAGSTATS_HIP_MIN_LEN (tests/test_reference_patch.py builds and exercises that patch).
     (void)n_len;
     return &FLAGSTAT_hip;
 }
 
+/* ---- explicit contexts ---- */
+FLAGSTATS_hip_ctx* FLAGSTATS_hip_ctx_create(int device)
+{
+    Engine* e = fsint::engine_create(device);
+    if (!e) return nullptr;
+    FLAGSTATS_hip_ctx* c = new FLAGSTATS_hip_ctx;
+    c->engine = e;
+    return c;
+}
+
+void FLAGSTATS_hip_ctx_destroy(FLAGSTATS_hip_ctx* ctx)
+{
+    if (!ctx) return;
+    fsint::engine_destroy(ctx->engine);
+    delete ctx;
+}
+
+int FLAGSTATS_hip_ctx_device(const FLAGSTATS_hip_ctx* ctx) { return ctx ? ctx->engine->device : -1; }
+
+int FLAGSTATS_hip_ctx_u16_x64(FLAGSTATS_hip_ctx* ctx, const uint16_t* array, uint64_t n, uint64_t* out)
+{
+    if (!ctx || !out) return fail_text("NULL context or out");
+    return fsint::count_host(*ctx->engine, array, n, out);
+}
+
+int FLAGSTATS_hip_ctx_device_u16_sync(FLAGSTATS_hip_ctx* ctx, const uint16_t* d_array, uint64_t n, uint64_t* out)
+{
+    if (!ctx || !out) return fail_text("NULL context or out");
+    if (n) {
+        int dev = -1;
+        int rc = fsint::device_of_pointer(d_array, "d_array", &dev);
+        if (rc) return rc;
+        if (dev != ctx->engine->device) return fail_text("d_array does not live on the context's device");
+    }
+    return count_device_sync(*ctx->engine, d_array, n, out);
+}
+
+/* ---- device-resident arrays ---- */
 int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!d_out) return fail_msg("NULL d_out");
-    int rc = bind();
-    if (rc) return rc;
     // `stream` is used as given: NULL is HIP's null stream (what torch's default stream is)
-    return count_device_async(d_array, n, d_out, (hipStream_t)stream, g.user_ws[stream]);
+    return fsint::count_on_user_stream(d_array, n, d_out, stream, fsint::OP_FLAGSTAT);
 }
 
 int FLAGSTATS_hip_device_u16_store(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!d_out) return fail_msg("NULL d_out");
-    int rc = bind();
-    if (rc) return rc;
-    return count_device_async(d_array, n, d_out, (hipStream_t)stream, g.user_ws[stream], OP_FLAGSTAT_STORE);
+    return fsint::count_on_user_stream(d_array, n, d_out, stream, fsint::OP_FLAGSTAT_STORE);
 }
 
 int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t* out)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!out) return fail_msg("NULL out");
-    int rc = bind();
-    if (rc) return rc;
-    HIP_TRY(hipMemsetAsync(g.d_out[0], 0, 32 * sizeof(uint64_t), g.stream[0]));
-    rc = count_device_async(d_array, n, g.d_out[0], g.stream[0], g.ws[0]);
-    if (rc) return rc;
-    HIP_TRY(hipMemcpyAsync(g.h_out, g.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, g.stream[0]));
-    HIP_TRY(hipStreamSynchronize(g.stream[0]));
-    for (int s = 0; s < 32; ++s) out[s] += g.h_out[s];
-    return 0;
+    if (!out) return fail_text("NULL out");
+    Engine* e = engine_of_array(d_array, n);
+    if (!e) return -1;
+    return count_device_sync(*e, d_array, n, out);
 }
 
+/* ---- memory helpers ---- */
 void* FLAGSTATS_hip_host_alloc(size_t bytes)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (bind()) return nullptr;
-    void* p = nullptr;
-    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, hipHostMallocDefault);
-    if (e != hipSuccess) {
-        fail("hipHostMalloc", e);
-        return nullptr;
-    }
-    return p;
+    Engine* e = fsint::default_engine();
+    if (!e) return nullptr;
+    DeviceGuard guard(e->device);
+    if (!guard.ok()) return nullptr;
+    return fsint::host_alloc_on_node(bytes, e->numa_node);
 }
 
 void FLAGSTATS_hip_host_free(void* p)
@@ -440,12 +305,29 @@ void FLAGSTATS_hip_host_free(void* p)
 
 void* FLAGSTATS_hip_device_alloc(size_t bytes)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (bind()) return nullptr;
+    Engine* e = fsint::default_engine();
+    if (!e) return nullptr;
+    DeviceGuard guard(e->device);
+    if (!guard.ok()) return nullptr;
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, bytes ? bytes : 1);
-    if (e != hipSuccess) {
-        fail("hipMalloc", e);
+    hipError_t err = hipMalloc(&p, bytes ? bytes : 1);
+    if (err != hipSuccess) {
+        fail_hip("hipMalloc", err);
+        return nullptr;
+    }
+    return p;
+}
+
+void* FLAGSTATS_hip_device_alloc_on(int device, size_t bytes)
+{
+    Engine* e = fsint::engine_for_device(device);
+    if (!e) return nullptr;
+    DeviceGuard guard(e->device);
+    if (!guard.ok()) return nullptr;
+    void* p = nullptr;
+    hipError_t err = hipMalloc(&p, bytes ? bytes : 1);
+    if (err != hipSuccess) {
+        fail_hip("hipMalloc", err);
         return nullptr;
     }
     return p;
@@ -458,27 +340,22 @@ void FLAGSTATS_hip_device_free(void* p)
 
 int FLAGSTATS_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    int rc = bind();
-    if (rc) return rc;
     HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 
 int FLAGSTATS_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    int rc = bind();
-    if (rc) return rc;
     HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 
 int FLAGSTATS_hip_synchronize(void)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    int rc = bind();
-    if (rc) return rc;
+    Engine* e = fsint::default_engine();
+    if (!e) return -1;
+    DeviceGuard guard(e->device);
+    if (!guard.ok()) return -1;
     HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
@@ -486,126 +363,136 @@ int FLAGSTATS_hip_synchronize(void)
 int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, uint32_t mask,
                                uint64_t first_index, void* stream)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    int rc = bind();
+    if (n == 0) return 0;
+    int dev = -1;
+    int rc = fsint::device_of_pointer(d_array, "d_array", &dev);
     if (rc) return rc;
-    HIP_TRY(fsk_generate(d_array, n, kind, seed, mask, first_index, (hipStream_t)stream));
+    Engine* e = fsint::engine_for_device(dev);
+    if (!e) return -1;
+    DeviceGuard guard(e->device);
+    if (!guard.ok()) return -1;
+    rc = fsint::check_stream_device(static_cast<hipStream_t>(stream), e->device);
+    if (rc) return rc;
+    HIP_TRY(fsk_generate(d_array, n, kind, seed, mask, first_index, static_cast<hipStream_t>(stream)));
     return 0;
 }
 
 int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmup, int reps, float* ms_total,
                                   uint64_t* out)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!ms_total || reps < 1 || warmup < 0) return fail_msg("bad timing arguments");
-    int rc = bind();
+    if (!ms_total || reps < 1 || warmup < 0) return fail_text("bad timing arguments");
+    Engine* ep = engine_of_array(d_array, n);
+    if (!ep) return -1;
+    Engine& e = *ep;
+    std::lock_guard<std::mutex> lk(e.mu);
+    DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    hipStream_t s = e.stream[0];
+    EventPair ev;
+    int rc = ev.create();
     if (rc) return rc;
-    hipStream_t s = g.stream[0];
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
     for (int i = 0; i < warmup; ++i) {
-        rc = count_device_async(d_array, n, g.d_out[0], s, g.ws[0]);
+        rc = fsint::count_device_async(e, d_array, n, e.d_out[0], s, e.ws[0]);
         if (rc) return rc;
     }
-    HIP_TRY(hipMemsetAsync(g.d_out[0], 0, 32 * sizeof(uint64_t), s));
-    HIP_TRY(hipEventRecord(e0, s));
+    HIP_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), s));
+    HIP_TRY(hipEventRecord(ev.e0, s));
     for (int i = 0; i < reps; ++i) {
-        rc = count_device_async(d_array, n, g.d_out[0], s, g.ws[0]);
+        rc = fsint::count_device_async(e, d_array, n, e.d_out[0], s, e.ws[0]);
         if (rc) return rc;
     }
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipMemcpyAsync(g.h_out, g.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipEventRecord(ev.e1, s));
+    HIP_TRY(hipMemcpyAsync(e.h_out, e.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipEventElapsedTime(ms_total, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
+    HIP_TRY(hipEventElapsedTime(ms_total, ev.e0, ev.e1));
     if (out)
-        for (int k = 0; k < 32; ++k) out[k] += g.h_out[k] / (uint64_t)reps;
+        for (int k = 0; k < 32; ++k) out[k] += e.h_out[k] / static_cast<uint64_t>(reps);
     return 0;
 }
 
 /* ---- row f4: plain positional popcount (python/libalgebra.h:3496-3551) ---- */
 int FLAGSTATS_hip_pospopcnt_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!out) return fail_msg("NULL out");
-    int rc = bind();
-    if (rc) return rc;
-    return count_host(array, n, out, OP_POSPOPCNT);
+    if (!out) return fail_text("NULL out");
+    Engine* e = fsint::default_engine();
+    if (!e) return -1;
+    return fsint::count_host(*e, array, n, out, fsint::OP_POSPOPCNT);
 }
 
 int STORM_pospopcnt_u16(const uint16_t* data, size_t len, uint32_t* out)
 {
-    if (!out) return fail_msg("NULL out");
+    if (!out) return legacy_result(fail_text("NULL out"), "STORM_pospopcnt_u16");
     std::memset(out, 0, 16 * sizeof(uint32_t));  // the reference zeroes out[] first (:3497)
     uint64_t wide[16];
     std::memset(wide, 0, sizeof wide);
     const int rc = FLAGSTATS_hip_pospopcnt_u16_x64(data, len, wide);
-    if (rc) return rc;
-    for (int i = 0; i < 16; ++i) out[i] = (uint32_t)wide[i];
+    if (rc) return legacy_result(rc, "STORM_pospopcnt_u16");
+    for (int i = 0; i < 16; ++i) out[i] = static_cast<uint32_t>(wide[i]);
     return 0;
 }
 
 int FLAGSTATS_hip_device_pospopcnt_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!d_out) return fail_msg("NULL d_out");
-    int rc = bind();
+    return fsint::count_on_user_stream(d_array, n, d_out, stream, fsint::OP_POSPOPCNT);
+}
+
+/* ---- read-only bandwidth probes (measurement) ---- */
+extern "C" hipError_t fsk_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads,
+                                      uint32_t grid, int nt, uint32_t* d_sink, hipStream_t stream);
+
+static int probe_common(const void* d_buf, int warmup, int reps, float* ms_total,
+                        hipError_t (*launch)(const void*, uint64_t, uint32_t, uint32_t*, hipStream_t, const int*),
+                        uint64_t bytes, uint32_t grid_override, const int* params)
+{
+    if (!ms_total || reps < 1 || warmup < 0) return fail_text("bad timing arguments");
+    int dev = -1;
+    int rc = fsint::device_of_pointer(d_buf, "d_buf", &dev);
     if (rc) return rc;
-    return count_device_async(d_array, n, d_out, (hipStream_t)stream, g.user_ws[stream], OP_POSPOPCNT);
+    Engine* ep = fsint::engine_for_device(dev);
+    if (!ep) return -1;
+    Engine& e = *ep;
+    std::lock_guard<std::mutex> lk(e.mu);
+    DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    hipStream_t s = e.stream[0];
+    const uint32_t grid = grid_override ? grid_override : fsint::grid_for(e);
+    rc = fsint::ensure_ws(e.ws[0], fsint::grid_for(e));  // reuse the partials buffer as the (never written) sink
+    if (rc) return rc;
+    uint32_t* sink = reinterpret_cast<uint32_t*>(e.ws[0].partials);
+    EventPair ev;
+    rc = ev.create();
+    if (rc) return rc;
+    for (int i = 0; i < warmup; ++i) HIP_TRY(launch(d_buf, bytes, grid, sink, s, params));
+    HIP_TRY(hipEventRecord(ev.e0, s));
+    for (int i = 0; i < reps; ++i) HIP_TRY(launch(d_buf, bytes, grid, sink, s, params));
+    HIP_TRY(hipEventRecord(ev.e1, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventElapsedTime(ms_total, ev.e0, ev.e1));
+    return 0;
 }
 
 int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warmup, int reps, float* ms_total)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!ms_total || reps < 1 || warmup < 0) return fail_msg("bad timing arguments");
-    int rc = bind();
-    if (rc) return rc;
-    hipStream_t s = g.stream[0];
-    const uint32_t grid = grid_for(0);
-    rc = ensure_ws(g.ws[0], grid);  // reuse the partials buffer as the (never written) sink
-    if (rc) return rc;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    for (int i = 0; i < warmup; ++i) HIP_TRY(fsk_read_probe(d_buf, bytes, grid, nt, (uint32_t*)g.ws[0].partials, s));
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i) HIP_TRY(fsk_read_probe(d_buf, bytes, grid, nt, (uint32_t*)g.ws[0].partials, s));
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipEventElapsedTime(ms_total, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return 0;
+    const int params[1] = {nt};
+    return probe_common(
+        d_buf, warmup, reps, ms_total,
+        [](const void* b, uint64_t n, uint32_t grid, uint32_t* sink, hipStream_t s, const int* p) {
+            return fsk_read_probe(b, n, grid, p[0], sink, s);
+        },
+        bytes, 0, params);
 }
-
-extern "C" hipError_t fsk_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads,
-                                      uint32_t grid, int nt, uint32_t* d_sink, hipStream_t stream);
 
 int FLAGSTATS_hip_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads, uint32_t grid,
                               int nt, int warmup, int reps, float* ms_total)
 {
-    std::lock_guard<std::recursive_mutex> lk(g_mu);
-    if (!ms_total || reps < 1 || warmup < 0) return fail_msg("bad timing arguments");
-    int rc = bind();
-    if (rc) return rc;
-    hipStream_t s = g.stream[0];
-    rc = ensure_ws(g.ws[0], grid_for(0));
-    if (rc) return rc;
-    uint32_t* sink = (uint32_t*)g.ws[0].partials;
-    hipEvent_t e0, e1;
-    HIP_TRY(hipEventCreate(&e0));
-    HIP_TRY(hipEventCreate(&e1));
-    for (int i = 0; i < warmup; ++i) HIP_TRY(fsk_read_probe2(d_buf, bytes, mode, unroll, threads, grid, nt, sink, s));
-    HIP_TRY(hipEventRecord(e0, s));
-    for (int i = 0; i < reps; ++i) HIP_TRY(fsk_read_probe2(d_buf, bytes, mode, unroll, threads, grid, nt, sink, s));
-    HIP_TRY(hipEventRecord(e1, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    HIP_TRY(hipEventElapsedTime(ms_total, e0, e1));
-    (void)hipEventDestroy(e0);
-    (void)hipEventDestroy(e1);
-    return 0;
+    const int params[4] = {mode, unroll, static_cast<int>(threads), nt};
+    if (grid == 0) return fail_text("grid must be > 0");
+    return probe_common(
+        d_buf, warmup, reps, ms_total,
+        [](const void* b, uint64_t n, uint32_t g, uint32_t* sink, hipStream_t s, const int* p) {
+            return fsk_read_probe2(b, n, p[0], p[1], static_cast<uint32_t>(p[2]), g, p[3], sink, s);
+        },
+        bytes, grid, params);
 }
 
 }  // extern "C"

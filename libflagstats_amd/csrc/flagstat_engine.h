@@ -1,0 +1,116 @@
+// flagstat_engine.h -- internal: per-device engine contexts behind the C-ABI of libflagstats_hip.so.
+//
+// The reference keeps no state but a cached cpuid (libflagstats.h:2980-2997) and is reentrant.
+// Here the state is an *engine* per device: two streams, device staging for host arrays, K1
+// workspaces, device + pinned counters.  Engines are independent of each other (own mutex), so
+//   * one process can drive several GPUs (FLAGSTATS_hip_multi_*), and a caller's device pointer is
+//     served by the engine of the device that pointer lives on -- never by "the" global context;
+//   * streaming sessions and caller-stream launches own their streams / workspaces and take no
+//     engine-wide lock on the data path.
+// Every entry point restores the calling thread's current HIP device before it returns.
+#ifndef FLAGSTAT_ENGINE_H_
+#define FLAGSTAT_ENGINE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <atomic>
+#include <list>
+#include <mutex>
+#include <utility>
+
+namespace fsint {
+
+struct Workspace {
+    uint64_t* partials = nullptr;  // [19][grid] + ticket block (fsk_partials_bytes)
+    uint32_t grid_cap = 0;
+};
+
+// process-wide tuning knobs (FLAGSTATS_hip_set / env FLAGSTATS_HIP_*); they survive a shutdown
+struct Knobs {
+    std::atomic<uint32_t> blocks_per_cu{0};       // 0 = auto (1)
+    std::atomic<int> variant{25};                 // K1 schedule, see flagstat_kernels.hip
+    std::atomic<int> fuse{0};                     // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
+    std::atomic<uint64_t> chunk_flags{32ull << 20};  // host streaming chunk: 32 Mi flags = 64 MiB
+    std::atomic<int> on_error{1};                 // legacy uint32 entry points: 1 = abort after the message, 0 = return non-zero
+    std::atomic<int> numa{1};                     // block pipeline: 1 = pinned chunks + decoders on the GPU's NUMA node
+};
+Knobs& knobs();
+
+enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2 };
+
+struct Engine {
+    int device = -1;
+    int cus = 0;
+    int numa_node = -1;                            // host NUMA node closest to the device (-1 unknown)
+    std::mutex mu;                                 // guards everything below up to `user_mu`
+    hipStream_t stream[2] = {nullptr, nullptr};
+    Workspace ws[2];
+    uint64_t* d_out[2] = {nullptr, nullptr};       // device uint64[32] per slot
+    uint16_t* stage[2] = {nullptr, nullptr};       // device staging for host arrays
+    uint64_t stage_flags[2] = {0, 0};
+    uint64_t* h_out = nullptr;                     // pinned 2 x 32 (also mapped into the device)
+    hipEvent_t chunk_done[2] = {nullptr, nullptr}; // host streaming: chunk in slot i has been counted
+    uint64_t host_chunks = 0;                      // last multi-chunk host call: chunks submitted ...
+    uint64_t host_overlapped = 0;                  // ... and how many were submitted while the previous one was still in flight
+    void* pinned[3] = {nullptr, nullptr, nullptr}; // block-file chunk buffers, kept across calls
+    uint64_t pinned_bytes = 0;
+    std::mutex user_mu;                            // guards user_ws
+    std::list<std::pair<void*, Workspace>> user_ws;  // caller-owned streams, most recently used first (bounded)
+};
+
+// RAII: make `device` current for the calling thread and put the previous device back afterwards
+class DeviceGuard {
+  public:
+    explicit DeviceGuard(int device);
+    ~DeviceGuard();
+    bool ok() const { return ok_; }
+    DeviceGuard(const DeviceGuard&) = delete;
+    DeviceGuard& operator=(const DeviceGuard&) = delete;
+
+  private:
+    int prev_ = -1;
+    bool switched_ = false;
+    bool ok_ = false;
+};
+
+int fail_text(const char* msg);                    // records (thread-local) + prints, returns -1
+int fail_hip(const char* what, hipError_t e);      // same with the HIP error text, returns non-zero
+int fail_again(const char* full_text, int rc);     // re-records a message another thread already printed
+const char* last_error_text();
+void multi_forget();                               // flagstat_multi.hip: drop cached engine pointers (shutdown)
+
+// default engine of `device` (created on first use); device < 0: the process default device
+// (FLAGSTATS_hip_init / env FLAGSTATS_HIP_DEVICE / 0).  nullptr on failure (error recorded).
+Engine* engine_for_device(int device);
+Engine* default_engine();
+// a private engine (own streams and buffers) on `device`; release with engine_destroy
+Engine* engine_create(int device);
+void engine_destroy(Engine* e);
+void shutdown_all();
+int default_device();                              // -1 before the first successful init
+int select_default_device(int device);             // FLAGSTATS_hip_init
+
+// which device a device pointer lives on; fails loudly for host / unknown pointers
+int device_of_pointer(const void* p, const char* what, int* device);
+// a caller's stream must belong to `device` (NULL = that device's null stream)
+int check_stream_device(hipStream_t s, int device);
+
+uint32_t grid_for(const Engine& e);
+int ensure_ws(Workspace& w, uint32_t grid);
+// K1 + K2 on `s`: d_out += (or =, OP_FLAGSTAT_STORE) counters of d_array[0..n).  Device must be current.
+int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w,
+                       int op = OP_FLAGSTAT);
+// the same for a caller-owned stream: validates devices, finds / creates the stream's workspace
+int count_on_user_stream(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream, int op);
+// host array -> counters through the engine's two-stream pipeline; takes e.mu
+int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op = OP_FLAGSTAT);
+
+int stage_reserve(Engine& e, int slot, uint64_t flags);   // e.mu held
+int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3]);  // e.mu held
+void* host_alloc_on_node(size_t bytes, int numa_node);   // pinned, pages placed on `numa_node` when >= 0
+uint64_t chunk_bytes();
+
+}  // namespace fsint
+
+#endif

@@ -1,0 +1,531 @@
+// flagstat_engine.hip -- per-device engine contexts: registry, device guard, error channel,
+// workspaces, and the two host-side data paths every entry point is built from
+// (device-resident array -> K1+K2 on a stream; host array -> double-buffered H2D + K1+K2).
+// Replaces the state-free dispatch of the reference (libflagstats.h:2976-3070); see flagstat_engine.h.
+#include "flagstat_engine.h"
+
+#include <sys/syscall.h>
+#include <unistd.h>
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "flagstat_kernels.h"
+
+namespace fsint {
+
+namespace {
+
+thread_local std::string g_err;
+
+std::mutex g_reg_mu;                               // registry only; never held across GPU work
+std::vector<std::unique_ptr<Engine>> g_default;    // index = device id
+std::vector<Engine*> g_private;                    // engine_create()d, for shutdown_all
+std::atomic<int> g_default_device{-1};
+Knobs g_knobs;
+std::once_flag g_env_once;
+
+uint64_t env_u64(const char* name, uint64_t dflt)
+{
+    const char* s = std::getenv(name);
+    if (!s || !*s) return dflt;
+    return std::strtoull(s, nullptr, 0);
+}
+
+void read_env_knobs()
+{
+    std::call_once(g_env_once, [] {
+        g_knobs.blocks_per_cu = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_BLOCKS_PER_CU", g_knobs.blocks_per_cu));
+        g_knobs.variant = static_cast<int>(env_u64("FLAGSTATS_HIP_VARIANT", static_cast<uint64_t>(g_knobs.variant)));
+        g_knobs.chunk_flags = env_u64("FLAGSTATS_HIP_CHUNK_FLAGS", g_knobs.chunk_flags);
+        g_knobs.fuse = static_cast<int>(env_u64("FLAGSTATS_HIP_FUSE", static_cast<uint64_t>(g_knobs.fuse)));
+        g_knobs.numa = static_cast<int>(env_u64("FLAGSTATS_HIP_NUMA", static_cast<uint64_t>(g_knobs.numa)));
+        const char* oe = std::getenv("FLAGSTATS_HIP_ON_ERROR");
+        if (oe && *oe) g_knobs.on_error = (!std::strcmp(oe, "return") || !std::strcmp(oe, "0")) ? 0 : 1;
+    });
+}
+
+#define HIP_TRY(expr)                                      \
+    do {                                                   \
+        hipError_t e_ = (expr);                            \
+        if (e_ != hipSuccess) return fail_hip(#expr, e_);  \
+    } while (0)
+
+// host NUMA node of a device, from sysfs via its PCI bus id; -1 if unknown
+int numa_node_of_device(int device)
+{
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, sizeof bus, device) != hipSuccess) return -1;
+    for (char* p = bus; *p; ++p)
+        if (*p >= 'A' && *p <= 'F') *p = static_cast<char>(*p - 'A' + 'a');
+    char path[160];
+    std::snprintf(path, sizeof path, "/sys/bus/pci/devices/%s/numa_node", bus);
+    FILE* f = std::fopen(path, "r");
+    if (!f) return -1;
+    int node = -1;
+    if (std::fscanf(f, "%d", &node) != 1) node = -1;
+    std::fclose(f);
+    return node;
+}
+
+void release_engine_resources(Engine& e)
+{
+    (void)hipDeviceSynchronize();
+    for (int i = 0; i < 2; ++i) {
+        if (e.ws[i].partials) (void)hipFree(e.ws[i].partials);
+        if (e.d_out[i]) (void)hipFree(e.d_out[i]);
+        if (e.stage[i]) (void)hipFree(e.stage[i]);
+        if (e.stream[i]) (void)hipStreamDestroy(e.stream[i]);
+    }
+    for (auto& kv : e.user_ws)
+        if (kv.second.partials) (void)hipFree(kv.second.partials);
+    e.user_ws.clear();
+    if (e.h_out) (void)hipHostFree(e.h_out);
+    for (int i = 0; i < 2; ++i)
+        if (e.chunk_done[i]) (void)hipEventDestroy(e.chunk_done[i]);
+    for (int i = 0; i < 3; ++i)
+        if (e.pinned[i]) (void)hipHostFree(e.pinned[i]);
+}
+
+// build an engine on `device`; the caller holds no engine lock (the engine is not published yet)
+int engine_setup(Engine& e, int device)
+{
+    int count = 0;
+    hipError_t err = hipGetDeviceCount(&count);
+    if (err != hipSuccess || count <= 0)
+        return fail_hip("hipGetDeviceCount (no usable GPU)", err == hipSuccess ? hipErrorNoDevice : err);
+    if (device < 0 || device >= count) return fail_text("device index out of range");
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 (MI355X) code only", device,
+                      prop.gcnArchName);
+        return fail_text(buf);
+    }
+    DeviceGuard guard(device);
+    if (!guard.ok()) return -1;
+    e.device = device;
+    e.cus = prop.multiProcessorCount;
+    e.numa_node = numa_node_of_device(device);
+    for (int i = 0; i < 2; ++i) {
+        HIP_TRY(hipStreamCreateWithFlags(&e.stream[i], hipStreamNonBlocking));
+        HIP_TRY(hipMalloc(&e.d_out[i], 32 * sizeof(uint64_t)));
+        HIP_TRY(hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming));
+    }
+    HIP_TRY(hipHostMalloc(&e.h_out, 2 * 32 * sizeof(uint64_t), hipHostMallocDefault));
+    return 0;
+}
+
+}  // namespace
+
+Knobs& knobs()
+{
+    read_env_knobs();
+    return g_knobs;
+}
+
+int fail_hip(const char* what, hipError_t e)
+{
+    char buf[512];
+    std::snprintf(buf, sizeof buf, "libflagstats_hip: %s failed: %s (%d)", what, hipGetErrorString(e), static_cast<int>(e));
+    g_err = buf;
+    std::fprintf(stderr, "%s\n", buf);
+    return static_cast<int>(e) ? static_cast<int>(e) : -1;
+}
+
+int fail_text(const char* msg)
+{
+    g_err = std::string("libflagstats_hip: ") + msg;
+    std::fprintf(stderr, "%s\n", g_err.c_str());
+    return -1;
+}
+
+int fail_again(const char* full_text, int rc)
+{
+    g_err = (full_text && *full_text) ? full_text : "libflagstats_hip: a worker thread failed";
+    return rc ? rc : -1;
+}
+
+const char* last_error_text() { return g_err.c_str(); }
+
+DeviceGuard::DeviceGuard(int device)
+{
+    hipError_t e = hipGetDevice(&prev_);
+    if (e != hipSuccess) {
+        fail_hip("hipGetDevice", e);
+        return;
+    }
+    if (prev_ != device) {
+        e = hipSetDevice(device);
+        if (e != hipSuccess) {
+            fail_hip("hipSetDevice", e);
+            return;
+        }
+        switched_ = true;
+    }
+    ok_ = true;
+}
+
+DeviceGuard::~DeviceGuard()
+{
+    if (switched_) (void)hipSetDevice(prev_);
+}
+
+int default_device() { return g_default_device.load(); }
+
+Engine* engine_for_device(int device)
+{
+    read_env_knobs();
+    if (device < 0) {
+        device = g_default_device.load();
+        if (device < 0) device = static_cast<int>(env_u64("FLAGSTATS_HIP_DEVICE", 0));
+    }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    if (device < static_cast<int>(g_default.size()) && g_default[device]) {
+        if (g_default_device.load() < 0) g_default_device = device;
+        return g_default[device].get();
+    }
+    std::unique_ptr<Engine> e(new Engine());
+    if (engine_setup(*e, device)) {
+        if (e->device >= 0) {
+            DeviceGuard guard(e->device);
+            release_engine_resources(*e);
+        }
+        return nullptr;
+    }
+    if (static_cast<int>(g_default.size()) <= device) g_default.resize(device + 1);
+    g_default[device] = std::move(e);
+    if (g_default_device.load() < 0) g_default_device = device;
+    return g_default[device].get();
+}
+
+Engine* default_engine() { return engine_for_device(-1); }
+
+int select_default_device(int device)
+{
+    read_env_knobs();
+    if (device < 0) return default_engine() ? 0 : -1;
+    // the entry points that take no device (host-pointer calls, allocators, sessions) follow the latest
+    // selection; device pointers are always served by the engine of the device they live on
+    Engine* e = engine_for_device(device);
+    if (!e) return -1;
+    g_default_device = device;
+    return 0;
+}
+
+Engine* engine_create(int device)
+{
+    read_env_knobs();
+    if (device < 0) {
+        device = g_default_device.load();
+        if (device < 0) device = static_cast<int>(env_u64("FLAGSTATS_HIP_DEVICE", 0));
+    }
+    std::unique_ptr<Engine> e(new Engine());
+    if (engine_setup(*e, device)) {
+        if (e->device >= 0) {
+            DeviceGuard guard(e->device);
+            release_engine_resources(*e);
+        }
+        return nullptr;
+    }
+    std::lock_guard<std::mutex> lk(g_reg_mu);
+    g_private.push_back(e.get());
+    return e.release();
+}
+
+void engine_destroy(Engine* e)
+{
+    if (!e) return;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        bool found = false;
+        for (size_t i = 0; i < g_private.size(); ++i)
+            if (g_private[i] == e) {
+                g_private.erase(g_private.begin() + static_cast<long>(i));
+                found = true;
+                break;
+            }
+        if (!found) return;  // default engines are released by shutdown_all only
+    }
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        DeviceGuard guard(e->device);
+        release_engine_resources(*e);
+    }
+    delete e;
+}
+
+void shutdown_all()
+{
+    std::vector<std::unique_ptr<Engine>> defaults;
+    std::vector<Engine*> privates;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        defaults.swap(g_default);
+        privates.swap(g_private);
+        g_default_device = -1;
+    }
+    for (auto& e : defaults) {
+        if (!e) continue;
+        std::lock_guard<std::mutex> lk(e->mu);
+        DeviceGuard guard(e->device);
+        release_engine_resources(*e);
+    }
+    for (Engine* e : privates) {
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            DeviceGuard guard(e->device);
+            release_engine_resources(*e);
+        }
+        delete e;
+    }
+}
+
+int device_of_pointer(const void* p, const char* what, int* device)
+{
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof attr);
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    char buf[192];
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        std::snprintf(buf, sizeof buf, "%s (%p) is not a device pointer known to this HIP runtime", what, p);
+        return fail_text(buf);
+    }
+    if (attr.type != hipMemoryTypeDevice && attr.type != hipMemoryTypeManaged && attr.type != hipMemoryTypeHost) {
+        std::snprintf(buf, sizeof buf, "%s (%p) is not device-accessible memory", what, p);
+        return fail_text(buf);
+    }
+    *device = attr.device;
+    return 0;
+}
+
+int check_stream_device(hipStream_t s, int device)
+{
+    if (s == nullptr) return 0;  // the null stream of the device made current by the guard
+    hipDevice_t d = -1;
+    const hipError_t e = hipStreamGetDevice(s, &d);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return fail_hip("hipStreamGetDevice(caller stream)", e);
+    }
+    if (static_cast<int>(d) != device) {
+        char buf[160];
+        std::snprintf(buf, sizeof buf, "the stream belongs to device %d but the array lives on device %d", static_cast<int>(d),
+                      device);
+        return fail_text(buf);
+    }
+    return 0;
+}
+
+uint32_t grid_for(const Engine& e)
+{
+    const uint32_t bpc = g_knobs.blocks_per_cu.load();
+    return static_cast<uint32_t>(e.cus) * (bpc ? bpc : 1);
+}
+
+int ensure_ws(Workspace& w, uint32_t grid)
+{
+    if (w.grid_cap >= grid) return 0;
+    if (w.partials) {
+        HIP_TRY(hipDeviceSynchronize());  // launches that still use the old workspace
+        HIP_TRY(hipFree(w.partials));
+    }
+    w.partials = nullptr;
+    w.grid_cap = 0;
+    HIP_TRY(hipMalloc(&w.partials, fsk_partials_bytes(grid)));
+    HIP_TRY(hipMemset(w.partials, 0, fsk_partials_bytes(grid)));  // the ticket word must start at 0
+    w.grid_cap = grid;
+    return 0;
+}
+
+int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w, int op)
+{
+    if (n == 0) {
+        if (op == OP_FLAGSTAT_STORE) HIP_TRY(hipMemsetAsync(d_out, 0, 32 * sizeof(uint64_t), s));
+        return 0;
+    }
+    if (!d_array) return fail_text("NULL array with n > 0");
+    if (reinterpret_cast<uintptr_t>(d_array) & 1u) return fail_text("array must be 2-byte aligned");
+    const uint32_t grid = grid_for(e);
+    int rc = ensure_ws(w, grid);
+    if (rc) return rc;
+    if (op == OP_POSPOPCNT) {
+        HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s));
+    } else {
+        const int variant = g_knobs.variant.load() | (op == OP_FLAGSTAT_STORE ? 256 : 0) | (g_knobs.fuse.load() ? 512 : 0);
+        HIP_TRY(fsk_launch(d_array, n, grid, variant, w.partials,
+                           reinterpret_cast<uint32_t*>(w.partials + static_cast<size_t>(w.grid_cap) * fsk::kInternal), d_out, s));
+    }
+    return 0;
+}
+
+int count_on_user_stream(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream, int op)
+{
+    if (!d_out) return fail_text("NULL d_out");
+    int dev_out = -1, dev_in = -1;
+    int rc = device_of_pointer(d_out, "d_out", &dev_out);
+    if (rc) return rc;
+    if (n) {
+        if (!d_array) return fail_text("NULL array with n > 0");
+        rc = device_of_pointer(d_array, "d_array", &dev_in);
+        if (rc) return rc;
+        if (dev_in != dev_out) {
+            char buf[160];
+            std::snprintf(buf, sizeof buf, "d_array lives on device %d but d_out on device %d", dev_in, dev_out);
+            return fail_text(buf);
+        }
+    }
+    Engine* e = engine_for_device(dev_out);
+    if (!e) return -1;
+    DeviceGuard guard(e->device);
+    if (!guard.ok()) return -1;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    rc = check_stream_device(s, e->device);
+    if (rc) return rc;
+    // one workspace per caller stream: launches on a stream are ordered, so they may share it.
+    // Bounded, most recently used first; an evicted stream's workspace is freed after a sync.
+    constexpr size_t kMaxUserStreams = 64;
+    std::lock_guard<std::mutex> lk(e->user_mu);
+    auto it = e->user_ws.begin();
+    for (; it != e->user_ws.end(); ++it)
+        if (it->first == stream) break;
+    if (it == e->user_ws.end()) {
+        if (e->user_ws.size() >= kMaxUserStreams) {
+            Workspace& old = e->user_ws.back().second;
+            if (old.partials) {
+                HIP_TRY(hipDeviceSynchronize());
+                HIP_TRY(hipFree(old.partials));
+            }
+            e->user_ws.pop_back();
+        }
+        e->user_ws.emplace_front(stream, Workspace());
+        it = e->user_ws.begin();
+    } else if (it != e->user_ws.begin()) {
+        e->user_ws.splice(e->user_ws.begin(), e->user_ws, it);
+        it = e->user_ws.begin();
+    }
+    return count_device_async(*e, d_array, n, d_out, s, it->second, op);
+}
+
+int stage_reserve(Engine& e, int slot, uint64_t flags)
+{
+    if (e.stage_flags[slot] >= flags) return 0;
+    // geometric growth up to the streaming chunk: a per-block caller with growing block sizes must not
+    // pay a (device-synchronising) hipFree + hipMalloc on every call
+    uint64_t want = e.stage_flags[slot] ? e.stage_flags[slot] : (1ull << 16);
+    while (want < flags) want *= 2;
+    const uint64_t chunk = g_knobs.chunk_flags.load() < 8 ? 8 : g_knobs.chunk_flags.load();
+    if (want > chunk && flags <= chunk) want = chunk;
+    if (e.stage[slot]) {
+        HIP_TRY(hipStreamSynchronize(e.stream[slot]));
+        HIP_TRY(hipFree(e.stage[slot]));
+    }
+    e.stage[slot] = nullptr;
+    e.stage_flags[slot] = 0;
+    HIP_TRY(hipMalloc(&e.stage[slot], want * sizeof(uint16_t)));
+    e.stage_flags[slot] = want;
+    return 0;
+}
+
+uint64_t chunk_bytes() { return g_knobs.chunk_flags.load() * 2; }
+
+void* host_alloc_on_node(size_t bytes, int numa_node)
+{
+    void* p = nullptr;
+    bool bound = false;
+#ifdef SYS_set_mempolicy
+    if (numa_node >= 0 && numa_node < 64 && g_knobs.numa.load()) {
+        // MPOL_PREFERRED (1) for the calling thread while the pinned pages are created
+        unsigned long mask = 1ul << numa_node;
+        bound = syscall(SYS_set_mempolicy, 1, &mask, sizeof(mask) * 8 + 1) == 0;
+    }
+#endif
+    hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, bound ? hipHostMallocNumaUser : hipHostMallocDefault);
+#ifdef SYS_set_mempolicy
+    if (bound) (void)syscall(SYS_set_mempolicy, 0, nullptr, 0);  // MPOL_DEFAULT
+#endif
+    if (e != hipSuccess) {
+        fail_hip("hipHostMalloc", e);
+        return nullptr;
+    }
+    return p;
+}
+
+int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3])
+{
+    if (e.pinned_bytes < bytes) {
+        for (int i = 0; i < 3; ++i) {
+            if (e.pinned[i]) (void)hipHostFree(e.pinned[i]);
+            e.pinned[i] = nullptr;
+        }
+        e.pinned_bytes = 0;
+        for (int i = 0; i < 3; ++i) {
+            e.pinned[i] = host_alloc_on_node(bytes, e.numa_node);
+            if (!e.pinned[i]) return -1;
+        }
+        e.pinned_bytes = bytes;
+    }
+    for (int i = 0; i < 3; ++i) bufs[i] = e.pinned[i];
+    return 0;
+}
+
+// host array -> counters: double-buffered H2D + K1/K2 per chunk on the engine's two streams
+int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
+{
+    const int nout = (op == OP_POSPOPCNT) ? 16 : 32;
+    if (n == 0) return 0;
+    if (!h) return fail_text("NULL array with n > 0");
+    std::lock_guard<std::mutex> lk(e.mu);
+    DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    const uint64_t chunk = g_knobs.chunk_flags.load() < 8 ? 8 : g_knobs.chunk_flags.load();
+    const int slots = (n > chunk) ? 2 : 1;
+    int rc = 0;
+    for (int i = 0; i < slots && !rc; ++i) rc = stage_reserve(e, i, n < chunk ? n : chunk);
+    if (rc) return rc;
+    if (slots == 1 && op == OP_FLAGSTAT) {
+        // latency path (what an unmodified per-block caller of the reference hits, e.g. 512,000 flags
+        // per call, benchmark/flagstats.cpp:328-329): one copy, K1, and K2 STORING straight into the
+        // pinned host result buffer -- no counter memset, no D2H copy
+        uint64_t* h_out_dev = nullptr;
+        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_out_dev), e.h_out, 0));
+        HIP_TRY(hipMemcpyAsync(e.stage[0], h, n * sizeof(uint16_t), hipMemcpyHostToDevice, e.stream[0]));
+        rc = count_device_async(e, e.stage[0], n, h_out_dev, e.stream[0], e.ws[0], OP_FLAGSTAT_STORE);
+        if (rc) return rc;
+        HIP_TRY(hipStreamSynchronize(e.stream[0]));
+        for (int s = 0; s < 32; ++s) out[s] += e.h_out[s];
+        return 0;
+    }
+    for (int i = 0; i < slots; ++i) HIP_TRY(hipMemsetAsync(e.d_out[i], 0, 32 * sizeof(uint64_t), e.stream[i]));
+    uint64_t done = 0;
+    e.host_chunks = e.host_overlapped = 0;
+    for (uint64_t k = 0; done < n; ++k) {
+        const int sl = static_cast<int>(k & 1);
+        const uint64_t c = (n - done < chunk) ? n - done : chunk;
+        // was the previous chunk (other slot, other stream) still in flight when this one is handed over?
+        // (pinned host memory: yes, the copies are asynchronous; pageable: the runtime stages them itself)
+        if (k > 0 && hipEventQuery(e.chunk_done[sl ^ 1]) == hipErrorNotReady) ++e.host_overlapped;
+        (void)hipGetLastError();
+        // same stream per slot: the copy into stage[sl] is ordered after the kernel that last read it
+        HIP_TRY(hipMemcpyAsync(e.stage[sl], h + done, c * sizeof(uint16_t), hipMemcpyHostToDevice, e.stream[sl]));
+        rc = count_device_async(e, e.stage[sl], c, e.d_out[sl], e.stream[sl], e.ws[sl], op);
+        if (rc) return rc;
+        HIP_TRY(hipEventRecord(e.chunk_done[sl], e.stream[sl]));
+        ++e.host_chunks;
+        done += c;
+    }
+    for (int i = 0; i < slots; ++i)
+        HIP_TRY(hipMemcpyAsync(e.h_out + 32 * i, e.d_out[i], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, e.stream[i]));
+    for (int i = 0; i < slots; ++i) HIP_TRY(hipStreamSynchronize(e.stream[i]));
+    for (int i = 0; i < slots; ++i)
+        for (int s = 0; s < nout; ++s) out[s] += e.h_out[32 * i + s];
+    return 0;
+}
+
+}  // namespace fsint

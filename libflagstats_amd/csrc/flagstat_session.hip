@@ -10,15 +10,23 @@
 //
 // Blocks are packed into pinned chunk buffers (16-byte aligned slots, zero-filled gaps: a zero
 // flag counts nothing, so a chunk is counted as ONE array); 3 pinned chunks, 2 device chunks,
-// 2 streams, session-private device counters.
+// 2 streams, K1 workspaces and device counters, all private to the session: sessions of different
+// caller threads (and the engine's own host entry points) overlap freely; a session's calls are
+// serialised by its own mutex only.
 #include <cstring>
+#include <mutex>
 
 #include "../../include/libflagstats_hip.h"
-#include "flagstat_ctx.h"
+#include "flagstat_engine.h"
 
 struct FLAGSTATS_hip_stream {
+    fsint::Engine* eng = nullptr;
+    std::mutex mu;
+    hipStream_t st[2] = {nullptr, nullptr};
+    fsint::Workspace ws[2];
     uint8_t* pinned[3] = {nullptr, nullptr, nullptr};
     hipEvent_t copied[3];
+    bool have_event[3] = {false, false, false};
     bool in_flight[3] = {false, false, false};
     uint16_t* dstage[2] = {nullptr, nullptr};
     uint64_t* d_out[2] = {nullptr, nullptr};
@@ -37,11 +45,11 @@ int submit(FLAGSTATS_hip_stream* s)
 {
     if (s->used == 0) return 0;
     const int sl = static_cast<int>(s->submitted & 1);
-    hipError_t e = hipMemcpyAsync(s->dstage[sl], s->pinned[s->cur], s->used, hipMemcpyHostToDevice, fsint::stream(sl));
-    if (e == hipSuccess) e = hipEventRecord(s->copied[s->cur], fsint::stream(sl));
+    hipError_t e = hipMemcpyAsync(s->dstage[sl], s->pinned[s->cur], s->used, hipMemcpyHostToDevice, s->st[sl]);
+    if (e == hipSuccess) e = hipEventRecord(s->copied[s->cur], s->st[sl]);
     if (e != hipSuccess) return fsint::fail_hip("session: hipMemcpyAsync", e);
     s->in_flight[s->cur] = true;
-    int rc = fsint::count_async_to(s->dstage[sl], s->used / 2, s->d_out[sl], sl);
+    int rc = fsint::count_device_async(*s->eng, s->dstage[sl], s->used / 2, s->d_out[sl], s->st[sl], s->ws[sl]);
     if (rc) return rc;
     ++s->submitted;
     s->cur = (s->cur + 1) % 3;
@@ -60,18 +68,27 @@ extern "C" {
 
 FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void)
 {
-    std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
-    if (fsint::bind_ctx()) return nullptr;
+    fsint::Engine* eng = fsint::default_engine();
+    if (!eng) return nullptr;
+    fsint::DeviceGuard guard(eng->device);
+    if (!guard.ok()) return nullptr;
     FLAGSTATS_hip_stream* s = new FLAGSTATS_hip_stream();
+    s->eng = eng;
     s->cap = (fsint::chunk_bytes() + 15) & ~15ull;
     if (s->cap < (1ull << 20)) s->cap = 1ull << 20;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-        e = hipHostMalloc(reinterpret_cast<void**>(&s->pinned[i]), s->cap, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&s->copied[i], hipEventDisableTiming);
+        s->pinned[i] = static_cast<uint8_t*>(fsint::host_alloc_on_node(s->cap, eng->numa_node));
+        if (!s->pinned[i]) {
+            FLAGSTATS_hip_stream_close(s);
+            return nullptr;
+        }
+        e = hipEventCreateWithFlags(&s->copied[i], hipEventDisableTiming);
+        if (e == hipSuccess) s->have_event[i] = true;
     }
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipMalloc(reinterpret_cast<void**>(&s->dstage[i]), s->cap);
+        e = hipStreamCreateWithFlags(&s->st[i], hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->dstage[i]), s->cap);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_out[i]), 32 * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMemset(s->d_out[i], 0, 32 * sizeof(uint64_t));
     }
@@ -86,23 +103,25 @@ FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void)
 
 uint16_t* FLAGSTATS_hip_stream_acquire(FLAGSTATS_hip_stream* s, uint64_t n)
 {
-    std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
     if (!s) return nullptr;
+    std::lock_guard<std::mutex> lk(s->mu);
     const uint64_t padded = (2 * n + 15) & ~15ull;
     if (padded > s->cap) {
         fsint::fail_text("session: block larger than the chunk size (knob chunk_flags)");
         return nullptr;
     }
-    if (fsint::bind_ctx()) return nullptr;
-    if (s->used + padded > s->cap && submit(s)) return nullptr;
+    if (s->used + padded > s->cap) {
+        fsint::DeviceGuard guard(s->eng->device);
+        if (!guard.ok() || submit(s)) return nullptr;
+    }
     s->acquired = n;
     return reinterpret_cast<uint16_t*>(s->pinned[s->cur] + s->used);
 }
 
 int FLAGSTATS_hip_stream_commit(FLAGSTATS_hip_stream* s, uint64_t n)
 {
-    std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
     if (!s) return fsint::fail_text("NULL session");
+    std::lock_guard<std::mutex> lk(s->mu);
     if (n > s->acquired) return fsint::fail_text("session: commit exceeds the acquired size");
     const uint64_t padded = (2 * n + 15) & ~15ull;
     std::memset(s->pinned[s->cur] + s->used + 2 * n, 0, padded - 2 * n);
@@ -131,19 +150,19 @@ int FLAGSTATS_hip_stream_push(FLAGSTATS_hip_stream* s, const uint16_t* array, ui
 
 int FLAGSTATS_hip_stream_finish(FLAGSTATS_hip_stream* s, uint64_t* out)
 {
-    std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
     if (!s || !out) return fsint::fail_text("NULL session or out");
-    int rc = fsint::bind_ctx();
-    if (rc) return rc;
-    rc = submit(s);
+    std::lock_guard<std::mutex> lk(s->mu);
+    fsint::DeviceGuard guard(s->eng->device);
+    if (!guard.ok()) return -1;
+    int rc = submit(s);
     if (rc) return rc;
     for (int i = 0; i < 2; ++i) {
-        hipError_t e = hipMemcpyAsync(s->h_out + 32 * i, s->d_out[i], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, fsint::stream(i));
-        if (e == hipSuccess) e = hipMemsetAsync(s->d_out[i], 0, 32 * sizeof(uint64_t), fsint::stream(i));
+        hipError_t e = hipMemcpyAsync(s->h_out + 32 * i, s->d_out[i], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s->st[i]);
+        if (e == hipSuccess) e = hipMemsetAsync(s->d_out[i], 0, 32 * sizeof(uint64_t), s->st[i]);
         if (e != hipSuccess) return fsint::fail_hip("session: finish", e);
     }
     for (int i = 0; i < 2; ++i) {
-        hipError_t e = hipStreamSynchronize(fsint::stream(i));
+        hipError_t e = hipStreamSynchronize(s->st[i]);
         if (e != hipSuccess) return fsint::fail_hip("session: hipStreamSynchronize", e);
     }
     for (int i = 0; i < 3; ++i) s->in_flight[i] = false;
@@ -158,19 +177,24 @@ uint64_t FLAGSTATS_hip_stream_flags(const FLAGSTATS_hip_stream* s) { return s ? 
 void FLAGSTATS_hip_stream_close(FLAGSTATS_hip_stream* s)
 {
     if (!s) return;
-    std::lock_guard<std::recursive_mutex> lk(fsint::mutex());
-    for (int i = 0; i < 2; ++i) (void)hipStreamSynchronize(fsint::stream(i));
-    for (int i = 0; i < 3; ++i) {
-        if (s->pinned[i]) {
-            (void)hipHostFree(s->pinned[i]);
-            (void)hipEventDestroy(s->copied[i]);
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        fsint::DeviceGuard guard(s->eng->device);
+        for (int i = 0; i < 2; ++i)
+            if (s->st[i]) (void)hipStreamSynchronize(s->st[i]);
+        for (int i = 0; i < 3; ++i) {
+            if (s->pinned[i]) (void)hipHostFree(s->pinned[i]);
+            if (s->have_event[i]) (void)hipEventDestroy(s->copied[i]);
         }
+        for (int i = 0; i < 2; ++i) {
+            if (s->dstage[i]) (void)hipFree(s->dstage[i]);
+            if (s->d_out[i]) (void)hipFree(s->d_out[i]);
+            if (s->ws[i].partials) (void)hipFree(s->ws[i].partials);
+            if (s->st[i]) (void)hipStreamDestroy(s->st[i]);
+        }
+        if (s->h_out) (void)hipHostFree(s->h_out);
+        s->h_out = nullptr;
     }
-    for (int i = 0; i < 2; ++i) {
-        if (s->dstage[i]) (void)hipFree(s->dstage[i]);
-        if (s->d_out[i]) (void)hipFree(s->d_out[i]);
-    }
-    if (s->h_out) (void)hipHostFree(s->h_out);
     delete s;
 }
 

@@ -14,8 +14,16 @@
  * by cpuid (libflagstats.h:2976-3022), so the .so also runs on the GPU box's
  * host CPU, whatever it is.
  */
+#include <pthread.h>
+#include <sched.h>
+
+#include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 #include REF_HEADER
 
@@ -110,6 +118,68 @@ void ref_dispatch_x64(const uint16_t* a, uint64_t n, uint64_t out[32])
 void ref_dispatch_repeat(const uint16_t* a, uint64_t n, uint32_t reps, uint64_t out[32])
 {
     for (uint32_t r = 0; r < reps; ++r) ref_dispatch_x64(a, n, out);
+}
+
+/* All-core CPU baseline with reproducible placement: `threads` workers, worker k pinned to the k-th CPU
+ * this process may run on, each allocating, first-touching and filling its OWN shard of
+ * `per_thread_flags` uniform-random uint16 (so the pages are local to the socket that reads them),
+ * then `reps` passes of the dispatcher's kernel between two barriers.  Returns the seconds between the
+ * barriers; out[32] += the counters of one pass over all shards. */
+double ref_dispatch_mt_bench(uint64_t per_thread_flags, int threads, uint32_t reps, uint64_t seed, uint64_t out[32])
+{
+    if (threads < 1 || reps < 1) return -1.0;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    std::vector<int> cpus;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+    std::atomic<int> arrived{0};
+    std::atomic<int> phase{0};
+    std::vector<std::vector<uint64_t>> part(threads, std::vector<uint64_t>(32, 0));
+    std::vector<double> t_begin(threads, 0.0), t_end(threads, 0.0);
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto barrier = [&](int target_phase) {
+        if (arrived.fetch_add(1) + 1 == threads * target_phase) phase.store(target_phase);
+        while (phase.load() < target_phase) std::this_thread::yield();
+    };
+    auto work = [&](int k) {
+        if (!cpus.empty()) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[k % cpus.size()], &one);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+        }
+        uint16_t* a = static_cast<uint16_t*>(std::malloc(per_thread_flags * 2 + 64));
+        uint64_t x = seed * 0x9E3779B97F4A7C15ull + static_cast<uint64_t>(k) * 0xD1B54A32D192ED03ull + 1;
+        for (uint64_t i = 0; i < per_thread_flags; ++i) {  /* xorshift64*: uniform over all 16 bits */
+            x ^= x >> 12;
+            x ^= x << 25;
+            x ^= x >> 27;
+            a[i] = static_cast<uint16_t>((x * 0x2545F4914F6CDD1Dull) >> 48);
+        }
+        uint64_t warm[32] = {0};
+        ref_dispatch_x64(a, per_thread_flags, warm);
+        barrier(1);
+        t_begin[k] = now();
+        uint64_t acc[32] = {0};
+        for (uint32_t r = 0; r < reps; ++r) ref_dispatch_x64(a, per_thread_flags, acc);
+        t_end[k] = now();
+        barrier(2);
+        for (int i = 0; i < 32; ++i) part[k][i] = acc[i] / reps;
+        std::free(a);
+    };
+    std::vector<std::thread> pool;   /* every worker is a fresh thread: the caller's own affinity stays as it was */
+    for (int k = 0; k < threads; ++k) pool.emplace_back(work, k);
+    for (auto& t : pool) t.join();
+    double b = t_begin[0], e = t_end[0];
+    for (int k = 1; k < threads; ++k) {
+        if (t_begin[k] < b) b = t_begin[k];
+        if (t_end[k] > e) e = t_end[k];
+    }
+    for (int k = 0; k < threads; ++k)
+        for (int i = 0; i < 32; ++i) out[i] += part[k][i];
+    return e - b;
 }
 
 void ref_scalar_x64(const uint16_t* a, uint64_t n, uint64_t out[32])

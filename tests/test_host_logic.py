@@ -90,7 +90,12 @@ def test_header_shim_consumer_compiles_and_links(tmp_path):
     r = subprocess.run([exe, "5000"], capture_output=True, text=True)
     if torch.cuda.is_available():
         assert r.returncode == 0, r.stdout + r.stderr
-    else:  # no GPU here: the call must fail loudly, not compute
+    else:
+        # no GPU here: the call must fail loudly, not compute.  Default policy for the reference-shaped
+        # entry points: message + abort() (their reference callers ignore the return value) ...
+        assert r.returncode == -6 and "libflagstats_hip" in r.stderr and "aborting" in r.stderr, r.stderr
+        # ... and FLAGSTATS_HIP_ON_ERROR=return hands the error to callers that check it (exit code 3)
+        r = subprocess.run([exe, "5000"], capture_output=True, text=True, env=dict(os.environ, FLAGSTATS_HIP_ON_ERROR="return"))
         assert r.returncode == 3 and "libflagstats_hip" in r.stderr
 
 

@@ -52,6 +52,12 @@ setup(ext_modules=cythonize([Extension("pyflagstats", ["libflagstats.pyx"],
         want = "RESULT %d %d" % (np.count_nonzero(((v & 4) != 0) & ((v & 512) == 0)), np.count_nonzero(v & 512))
         assert want in r.stdout, r.stdout + r.stderr
     else:
-        # no GPU here: the call goes to the GPU library, which fails loudly; the reference wrapper ignores
-        # the return code (pyx:22 stores it in an unused `ret`), so counters stay zero
+        # no GPU here: the call goes to the GPU library, which fails loudly.  The reference wrapper ignores
+        # the return code (pyx:22 stores it in an unused `ret`), so a plain error return would surface as
+        # all-zero counters; the library's default for the reference-shaped entry points is message + abort()
+        assert r.returncode == -6 and "libflagstats_hip" in r.stderr and "aborting" in r.stderr, r.stdout + r.stderr
+        assert "RESULT" not in r.stdout
+        # opt-out for callers that do check: the error comes back as the return value (which this wrapper drops)
+        r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True,
+                           env=dict(os.environ, FLAGSTATS_HIP_ON_ERROR="return"))
         assert "libflagstats_hip" in r.stderr and "RESULT 0 0" in r.stdout, r.stdout + r.stderr

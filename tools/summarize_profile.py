@@ -1,0 +1,112 @@
+#!/usr/bin/env python3
+"""Turn the rocprofv3 outputs of tools/gpu_profile.sh (gpurun_out/prof_*) into the small, tracked
+summaries under profiles/<round>/ and into profiles/traffic.json (what bench.py reports as
+roofline.traffic).  HBM bytes per launch follow /opt/skills/guides/MI355X_MICROARCH.md, section HBM:
+separate --pmc passes; on gfx950 FETCH_SIZE (KB) reports exactly half of the bytes of a wide coalesced
+streaming read, WRITE_SIZE is exact:  bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE * 1024.
+
+    python tools/summarize_profile.py gpurun_out profiles/r02 [--flags 4294967296]
+"""
+import argparse
+import csv
+import glob
+import hashlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def kernel_source_id():
+    h = hashlib.sha256()
+    for f in ("flagstat_kernels.hip", "flagstat_device.h", "flagstat_kernels.h"):
+        with open(os.path.join(ROOT, "libflagstats_amd", "csrc", f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def find(src, sub, pattern):
+    hits = glob.glob(os.path.join(src, sub, "**", pattern), recursive=True)
+    return hits[0] if hits else None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("src")
+    ap.add_argument("dst")
+    ap.add_argument("--flags", type=int, default=2 ** 32)
+    ap.add_argument("--kernel", default="flagstat_count")
+    ap.add_argument("--tag", default="")
+    args = ap.parse_args()
+    os.makedirs(args.dst, exist_ok=True)
+    tag = ("_" + args.tag) if args.tag else ""
+
+    # kernel trace: keep the stats table (a few lines) and the full-size launches' own average
+    stats = find(args.src, "prof_trace", "*kernel_stats.csv")
+    if stats:
+        rows = list(csv.reader(open(stats)))
+        with open(os.path.join(args.dst, "bench_kernel_stats%s.csv" % tag), "w") as f:
+            for r in rows[:8]:
+                f.write(",".join('"%s"' % c for c in r) + "\n")
+    trace = find(args.src, "prof_trace", "*kernel_trace.csv")
+    launches = None
+    if trace:
+        durs = []
+        name = None
+        for r in csv.DictReader(open(trace)):
+            if args.kernel in r["Kernel_Name"] and "finalize" not in r["Kernel_Name"]:
+                durs.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                name = r["Kernel_Name"]
+        if durs:
+            durs.sort()
+            big = [d for d in durs if d > 0.5 * durs[-1]]   # full-size launches only (parity/prefix launches are shorter)
+            launches = {"kernel": name, "launches": len(durs), "full_size_launches": len(big),
+                        "avg_ns_full_size": sum(big) / len(big), "median_ns_full_size": big[len(big) // 2],
+                        "min_ns": big[0], "max_ns": big[-1]}
+
+    counters = {}
+    vgpr = sgpr = lds = None
+    kname = None
+    for sub in ("prof_pmc_fetch", "prof_pmc_write", "prof_pmc_sq"):
+        cc = find(args.src, sub, "*counter_collection.csv")
+        if not cc:
+            continue
+        for r in csv.DictReader(open(cc)):
+            if args.kernel in r["Kernel_Name"] and "finalize" not in r["Kernel_Name"] and int(r["Grid_Size"]) >= 256 * 64:
+                counters.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                kname, vgpr, sgpr, lds = r["Kernel_Name"], r["VGPR_Count"], r["SGPR_Count"], r["LDS_Block_Size"]
+    summary = {}
+    for k, v in sorted(counters.items()):
+        # the bench's small prefix / parity launches read far less: keep the full-size launches
+        top = max(v)
+        full = [x for x in v if x > 0.5 * top] if k in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU", "SQ_ACTIVE_INST_VALU") else v
+        summary[k] = {"launches": len(full), "mean": sum(full) / len(full), "min": min(full), "max": max(full)}
+    out = {"kernel": kname, "VGPR_Count": vgpr, "SGPR_Count": sgpr, "LDS_Block_Size": lds, "kernel_source_id": kernel_source_id(),
+           "trace": launches, "counters": summary}
+    if "SQ_INSTS_VALU" in summary and args.flags:
+        waves = 256 * 4
+        steps = args.flags / 16384
+        out["valu_per_wave_step"] = summary["SQ_INSTS_VALU"]["mean"] / (steps * 4)
+        out["valu_per_flag_per_lane"] = out["valu_per_wave_step"] / 64.0
+        out["note_valu"] = "SQ_INSTS_VALU / (flags / 16384 steps x 4 waves per step); %d waves in the grid" % waves
+    with open(os.path.join(args.dst, "bench_pmc_%s%s.json" % (args.kernel, tag)), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+    if "FETCH_SIZE" in summary and "WRITE_SIZE" in summary:
+        hbm = int(round(2 * summary["FETCH_SIZE"]["mean"] * 1024 + summary["WRITE_SIZE"]["mean"] * 1024))
+        t = {"flags_per_launch": args.flags, "kernel": kname, "kernel_source_id": kernel_source_id(),
+             "FETCH_SIZE_KB_mean": summary["FETCH_SIZE"]["mean"], "WRITE_SIZE_KB_mean": summary["WRITE_SIZE"]["mean"],
+             "hbm_bytes_per_launch": hbm, "algorithmic_bytes_per_launch": 2 * args.flags,
+             "source": os.path.join(os.path.basename(args.dst.rstrip("/")), "bench_pmc_%s%s.json" % (args.kernel, tag)),
+             "derivation": "MI355X_MICROARCH.md section HBM: on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide "
+                           "coalesced (16 B/lane) streaming read, WRITE_SIZE is exact: bytes = 2*FETCH_SIZE*1024 + "
+                           "WRITE_SIZE*1024. Separate --pmc passes of bench.py (tools/gpu_profile.sh)."}
+        with open(os.path.join(ROOT, "profiles", "traffic.json"), "w") as f:
+            json.dump(t, f, indent=1)
+        print("traffic.json:", hbm, "bytes per launch vs", 2 * args.flags, "algorithmic")
+
+
+if __name__ == "__main__":
+    sys.exit(main())
