@@ -8,16 +8,20 @@
  * and link -lflagstats_hip: the same names resolve to the MI355X engine in
  * libflagstats_hip.so instead, with no source change in the consumer.
  *
- * Only the flagstat API is shimmed: the SAM FLAG constants (values are the SAM
- * specification's; names as at libflagstats.h:69-112) and the three dispatch
- * symbols (libflagstats.h:2970, :2976-2977, :3024-3025).  The STORM_* helpers
- * of libalgebra.h (aligned malloc, cpuid) that the reference's bench programs
- * also pull in are not part of the hot path and are not provided.
+ * Shimmed: the SAM FLAG constants (values are the SAM specification's; names as
+ * at libflagstats.h:69-112), the three dispatch symbols (libflagstats.h:2970,
+ * :2976-2977, :3024-3025) and -- through the libalgebra.h shim next to this
+ * file, which the reference's header also includes (:61) -- the STORM_* helpers
+ * its block readers call (aligned malloc / free, alignment query).  With those,
+ * /root/reference/benchmark/flagstats.cpp builds unmodified against this
+ * directory (tests/test_reference_bench_build.py).
  */
 #ifndef LIBFLAGSTATS_H_SHIM_HIP_
 #define LIBFLAGSTATS_H_SHIM_HIP_
 
 #include <stdint.h>
+
+#include "libalgebra.h"
 
 /* SAM FLAG bits and their counter-slot offsets */
 #define FLAGSTAT_FPAIRED 1

@@ -81,6 +81,18 @@ int FLAGSTATS_hip_device_u16_store(const uint16_t* d_array, uint64_t n, uint64_t
 /* DEVICE-resident array, HOST counters: out[32] += counters; synchronous. */
 int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t* out);
 
+/* Superset forms: the same 19 counters PLUS, counted by the same kernel,
+ *   slot 0 / slot 16  primary paired reads, pass-QC / fail-QC  = samtools' n_pair_all[w]
+ *                     (benchmark/flagstats.cpp:58; paired & !secondary & !supplementary)
+ *   slot 9            pass-QC reads = n - slot 25   (the reference's SIMD kernels' "QC adjust",
+ *                     libflagstats.h:1843)
+ * -- the quantities the reference's SIMD kernels leave in those slots for their SIMD-covered prefix
+ * (SURVEY F6), here for every flag regardless of length.  With them the whole samtools flagstat report
+ * (benchmark/flagstats.cpp:577-588) follows from the 32 slots.  All other slots as FLAGSTAT_scalar. */
+int FLAGSTATS_u16_x64_superset(const uint16_t* array, uint64_t n, uint64_t* out);                       /* host array */
+int FLAGSTATS_hip_device_u16_superset(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream); /* async */
+int FLAGSTATS_hip_device_u16_superset_sync(const uint16_t* d_array, uint64_t n, uint64_t* out);
+
 /* ---- context ---- */
 int FLAGSTATS_hip_available(void);          /* 1 if a gfx950-capable device can be used */
 int FLAGSTATS_hip_device_count(void);       /* HIP devices visible to this process (0 if none) */
@@ -127,7 +139,7 @@ int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint
  *   "blocks_per_cu"  workgroups per CU of K1's grid (default 1)
  *   "variant"        K1 schedule: bit0 non-temporal loads, bit1 chain depth 7, bit2 register
  *                    prefetch, bit3 interleaved waves, bit4 rolling re-issue, bit5 LDS-DMA ring, bit6
- *                    rolling at distance 2 (default 25; instantiated: 0, 1, 9, 13, 25, 27, 41, 89)
+ *                    rolling at distance 2 (default 25; shipped: 9 and 25; the others only in a `make TUNING=1` build)
  *   "fuse"           0 = K1 + K2 (default); 1 = K1 finalises itself, one kernel per call
  *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB)
  *   "on_error"       reference-shaped entry points on failure: 1 abort() after the message (default), 0 return non-zero

@@ -34,6 +34,9 @@ SIGNATURES = {
     "FLAGSTATS_hip_device_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
     "FLAGSTATS_hip_device_u16_store": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
     "FLAGSTATS_hip_device_u16_sync": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "FLAGSTATS_u16_x64_superset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
+    "FLAGSTATS_hip_device_u16_superset": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p]),
+    "FLAGSTATS_hip_device_u16_superset_sync": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p]),
     "FLAGSTATS_hip_available": (ctypes.c_int, []),
     "FLAGSTATS_hip_device_count": (ctypes.c_int, []),
     "FLAGSTATS_hip_ctx_create": (ctypes.c_void_p, [ctypes.c_int]),

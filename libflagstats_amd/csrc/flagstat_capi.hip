@@ -199,6 +199,14 @@ int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
     return fsint::count_host(*e, array, n, out);
 }
 
+int FLAGSTATS_u16_x64_superset(const uint16_t* array, uint64_t n, uint64_t* out)
+{
+    if (!out) return fail_text("NULL out");
+    Engine* e = fsint::default_engine();
+    if (!e) return -1;
+    return fsint::count_host(*e, array, n, out, fsint::OP_FLAGSTAT | fsint::OP_SUPERSET);
+}
+
 static int flagstat_hip_u32(const uint16_t* array, uint32_t len, uint32_t* flags)
 {
     if (!flags) return fail_text("NULL flags");
@@ -286,6 +294,19 @@ int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t*
     Engine* e = engine_of_array(d_array, n);
     if (!e) return -1;
     return count_device_sync(*e, d_array, n, out);
+}
+
+int FLAGSTATS_hip_device_u16_superset(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
+{
+    return fsint::count_on_user_stream(d_array, n, d_out, stream, fsint::OP_FLAGSTAT | fsint::OP_SUPERSET);
+}
+
+int FLAGSTATS_hip_device_u16_superset_sync(const uint16_t* d_array, uint64_t n, uint64_t* out)
+{
+    if (!out) return fail_text("NULL out");
+    Engine* e = engine_of_array(d_array, n);
+    if (!e) return -1;
+    return count_device_sync(*e, d_array, n, out, fsint::OP_FLAGSTAT | fsint::OP_SUPERSET);
 }
 
 /* ---- memory helpers ---- */

@@ -22,7 +22,7 @@
 namespace fsint {
 
 struct Workspace {
-    uint64_t* partials = nullptr;  // [19][grid] + ticket block (fsk_partials_bytes)
+    uint64_t* partials = nullptr;  // [fsk::kInternal][grid] + ticket block (fsk_partials_bytes)
     uint32_t grid_cap = 0;
 };
 
@@ -37,7 +37,8 @@ struct Knobs {
 };
 Knobs& knobs();
 
-enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2 };
+// base operation | OP_SUPERSET (flagstat only: also fill slots 0/16 = primary paired reads, slot 9 = pass-QC reads)
+enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2, OP_BASE_MASK = 3, OP_SUPERSET = 4 };
 
 struct Engine {
     int device = -1;

@@ -346,8 +346,9 @@ int ensure_ws(Workspace& w, uint32_t grid)
 
 int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w, int op)
 {
+    const int base = op & OP_BASE_MASK;
     if (n == 0) {
-        if (op == OP_FLAGSTAT_STORE) HIP_TRY(hipMemsetAsync(d_out, 0, 32 * sizeof(uint64_t), s));
+        if (base == OP_FLAGSTAT_STORE) HIP_TRY(hipMemsetAsync(d_out, 0, 32 * sizeof(uint64_t), s));
         return 0;
     }
     if (!d_array) return fail_text("NULL array with n > 0");
@@ -355,10 +356,11 @@ int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t*
     const uint32_t grid = grid_for(e);
     int rc = ensure_ws(w, grid);
     if (rc) return rc;
-    if (op == OP_POSPOPCNT) {
+    if (base == OP_POSPOPCNT) {
         HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s));
     } else {
-        const int variant = g_knobs.variant.load() | (op == OP_FLAGSTAT_STORE ? 256 : 0) | (g_knobs.fuse.load() ? 512 : 0);
+        const int variant = g_knobs.variant.load() | (base == OP_FLAGSTAT_STORE ? 256 : 0) | (g_knobs.fuse.load() ? 512 : 0) |
+                            ((op & OP_SUPERSET) ? 1024 : 0);
         HIP_TRY(fsk_launch(d_array, n, grid, variant, w.partials,
                            reinterpret_cast<uint32_t*>(w.partials + static_cast<size_t>(w.grid_cap) * fsk::kInternal), d_out, s));
     }
@@ -478,7 +480,7 @@ int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3])
 // host array -> counters: double-buffered H2D + K1/K2 per chunk on the engine's two streams
 int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
 {
-    const int nout = (op == OP_POSPOPCNT) ? 16 : 32;
+    const int nout = ((op & OP_BASE_MASK) == OP_POSPOPCNT) ? 16 : 32;
     if (n == 0) return 0;
     if (!h) return fail_text("NULL array with n > 0");
     std::lock_guard<std::mutex> lk(e.mu);
@@ -489,14 +491,14 @@ int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
     int rc = 0;
     for (int i = 0; i < slots && !rc; ++i) rc = stage_reserve(e, i, n < chunk ? n : chunk);
     if (rc) return rc;
-    if (slots == 1 && op == OP_FLAGSTAT) {
+    if (slots == 1 && (op & OP_BASE_MASK) == OP_FLAGSTAT) {
         // latency path (what an unmodified per-block caller of the reference hits, e.g. 512,000 flags
         // per call, benchmark/flagstats.cpp:328-329): one copy, K1, and K2 STORING straight into the
         // pinned host result buffer -- no counter memset, no D2H copy
         uint64_t* h_out_dev = nullptr;
         HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_out_dev), e.h_out, 0));
         HIP_TRY(hipMemcpyAsync(e.stage[0], h, n * sizeof(uint16_t), hipMemcpyHostToDevice, e.stream[0]));
-        rc = count_device_async(e, e.stage[0], n, h_out_dev, e.stream[0], e.ws[0], OP_FLAGSTAT_STORE);
+        rc = count_device_async(e, e.stage[0], n, h_out_dev, e.stream[0], e.ws[0], OP_FLAGSTAT_STORE | (op & OP_SUPERSET));
         if (rc) return rc;
         HIP_TRY(hipStreamSynchronize(e.stream[0]));
         for (int s = 0; s < 32; ++s) out[s] += e.h_out[s];

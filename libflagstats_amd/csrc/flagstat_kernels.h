@@ -11,7 +11,7 @@ namespace fsk {
 constexpr int kThreads = 256;                       // 4 waves per workgroup
 constexpr int kUnroll = 8;                          // 16-B vectors per lane per step
 constexpr int kVecPerStep = kThreads * kUnroll;     // 2048 vectors = 32 KiB = 16384 flags
-constexpr int kInternal = 19;                       // live counters (libflagstats.h:118-142)
+constexpr int kInternal = 21;                       // 19 live counters (libflagstats.h:118-142) + primary-paired reads x {pass, fail}
 
 struct CountArgs {
     const void* a0;        // 16-B aligned-down base of the array
@@ -23,7 +23,7 @@ struct CountArgs {
     uint64_t* partials;    // [kInternal][grid]
     uint32_t* ticket;      // non-null: fused finalise by the last-arriving workgroup (must be 0 at launch)
     uint64_t* out;         // device uint64[32]
-    int store;             // 0: out += counters, 1: out = counters
+    int mode;              // bit 0: out = counters instead of +=; bit 1: superset slots (0/16 n_pair_all, 9 pass-QC reads)
 };
 
 }  // namespace fsk
@@ -32,7 +32,8 @@ extern "C" {
 // bytes of workspace K1 needs for `grid` workgroups
 size_t fsk_partials_bytes(uint32_t grid);
 // K1 + K2 on `stream`: d_out32[32] += counters of d_array[0..n).  Asynchronous.
-// variant bits 0-4: K1 schedule; bit 8: store instead of accumulate; bit 9: fused finalise (needs d_ticket)
+// variant bits 0-6: K1 schedule; bit 8: store instead of accumulate; bit 9: fused finalise (needs d_ticket);
+// bit 10: superset slots
 hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
                       uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream);
 // positional popcount (flagstat_pospopcnt.hip): d_out16[16] += bit counts.  d_partials as for fsk_launch.

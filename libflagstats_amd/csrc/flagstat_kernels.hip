@@ -21,8 +21,11 @@
 //                          n_pair_map bits; (secondary,paired,supplementary) ->
 //                          category keep-mask; (qcfail,dup) -> fail mask + one-hot;
 //                        * result: T = 8 counter bits per flag (any QC),
-//                          F = T & fail-QC mask, S3 = one-hot(QC-only, DUP-only, both);
-//                        * T/F/S3 dwords go into bit-sliced carry-save counters:
+//                          F = T & fail-QC mask, S = one-hot(QC-only, DUP-only, both) + the
+//                          primary-paired indicator split by QC class (n_pair_all of the samtools
+//                          loop, benchmark/flagstats.cpp:58 -- not among the scalar rule's slots,
+//                          reported only through the superset entry points);
+//                        * T/F/S dwords go into bit-sliced carry-save counters:
 //                          one CSA = 2 x v_bitop3_b32 (0x96 sum, 0xE8 majority).
 //                      16 T-inputs per step collapse through a Harley-Seal tree;
 //                      the weight-16 carry enters a binary-counter chain of
@@ -55,8 +58,9 @@ namespace fsk {
 //   bit4 n_sgltn  (munmap & !unmap & pp)     bit5 n_pair_map (!munmap & !unmap & pp)
 //   bit6 read1 & pp           bit7 read2 & pp
 // where pp = paired & !secondary & !supplementary  (libflagstats.h:129-131).
-// selq: per byte (qcfail | dup<<1), feeds the QC/DUP LUTs.
-__device__ __forceinline__ void front4(uint32_t xa, uint32_t xb, uint32_t& T, uint32_t& selq)
+// selq: per byte (qcfail | dup<<1), feeds the QC/DUP LUTs.  keep: the category keep-mask, whose
+// bits 6 and 7 are set exactly for primary paired reads (pp).
+__device__ __forceinline__ void front4(uint32_t xa, uint32_t xb, uint32_t& T, uint32_t& selq, uint32_t& keep)
 {
     const uint32_t L = perm(xb, xa, 0x06040200u);  // FLAG bits 0..7  of 4 flags
     const uint32_t H = perm(xb, xa, 0x07050301u);  // FLAG bits 8..15 of 4 flags
@@ -76,23 +80,24 @@ __device__ __forceinline__ void front4(uint32_t xa, uint32_t xb, uint32_t& T, ui
     uint32_t idx = (H & 0x01010101u);
     idx = ((H >> 1) & 0x04040404u) | idx;
     idx = ((L << 1) & 0x02020202u) | idx;
-    const uint32_t keep = perm(0x050C050Cu, 0x05F60504u, idx);
+    keep = perm(0x050C050Cu, 0x05F60504u, idx);
     T = m & keep;
 
     selq = (H >> 1) & 0x03030303u;  // bit0 = QCFAIL, bit1 = DUP
 }
 
 // ------------------------------------------------------------------ lane state
-// Bit-sliced counters of one lane.  Streams: T (8 counters x 4 byte slots),
-// F (= T under fail-QC), S (one-hot QC/DUP, two nibble groups x 4 slots).
+// Bit-sliced counters of one lane.  Streams, each one byte per flag (4 flags per dword):
+// T (8 counters), F (= T under fail-QC), S (bits 0-2 one-hot QC-only / DUP-only / both,
+// bit 6 = pp & pass-QC, bit 7 = pp & fail-QC).
 template <int DEPTH>
 struct Lane {
     uint32_t t1, t2, t4, t8;   // T planes of weight 1,2,4,8
     uint32_t f1, f2, f4, f8;
-    uint32_t s1, s2, s4;       // S planes of weight 1,2,4 (8 inputs per step)
+    uint32_t s1, s2, s4, s8;
     uint32_t tA[DEPTH], tB[DEPTH];  // chain level j: weight 16<<j  (accumulator, pending)
     uint32_t fA[DEPTH], fB[DEPTH];
-    uint32_t sA[DEPTH], sB[DEPTH];  // weight 8<<j
+    uint32_t sA[DEPTH], sB[DEPTH];
     uint32_t acc[kInternal];        // flushed lane counters
 };
 
@@ -101,7 +106,7 @@ __device__ __forceinline__ void lane_init(Lane<DEPTH>& s)
 {
     s.t1 = s.t2 = s.t4 = s.t8 = 0;
     s.f1 = s.f2 = s.f4 = s.f8 = 0;
-    s.s1 = s.s2 = s.s4 = 0;
+    s.s1 = s.s2 = s.s4 = s.s8 = 0;
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) s.tA[j] = s.tB[j] = s.fA[j] = s.fB[j] = s.sA[j] = s.sB[j] = 0;
 #pragma unroll
@@ -134,7 +139,7 @@ __device__ __forceinline__ void chain_push(Lane<DEPTH>& s, uint32_t blk, uint32_
     }
 }
 
-// One step: 8 vectors of 16 B per lane = 64 flags -> 16 T, 16 F, 8 S inputs.
+// One step: 8 vectors of 16 B per lane = 64 flags -> 16 T, 16 F, 16 S inputs.
 // ROLL: as soon as vector u has been copied out of its registers, the same registers are
 // re-issued for vector u of the lane's NEXT step (`next`, stride USTRIDE vectors), so a wave
 // keeps ~8 loads in flight through the whole step without a second register buffer.
@@ -168,14 +173,14 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
                                      LdsStage lds = LdsStage{nullptr, 0, 0})
 {
     constexpr bool ROLL = (STAGE == 1);
-    uint32_t t8a = 0, t8b = 0, f8a = 0, f8b = 0, s4a = 0, s4b = 0;
+    uint32_t t8a = 0, t8b = 0, f8a = 0, f8b = 0, s8a = 0, s8b = 0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
-        uint32_t t4a = 0, t4b = 0, f4a = 0, f4b = 0, s2a = 0, s2b = 0;
+        uint32_t t4a = 0, t4b = 0, f4a = 0, f4b = 0, s4a = 0, s4b = 0;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
-            // two vectors -> 4 T/F inputs, 2 S inputs
-            uint32_t T[4], F[4], S[2];
+            // two vectors -> 4 T/F/S inputs
+            uint32_t T[4], F[4], S[4];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
                 uint4 x;
@@ -198,31 +203,37 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
                     v[half * 4 + q * 2 + k] = load_vec<NT>(next + (half * 4 + q * 2 + k) * USTRIDE);
                     __builtin_amdgcn_sched_barrier(0);
                 }
-                uint32_t qa, qb;
-                front4(x.x, x.y, T[2 * k], qa);
-                front4(x.z, x.w, T[2 * k + 1], qb);
-                // fail-QC byte masks and one-hot (QC only, DUP only, both) nibbles
+                uint32_t qa, qb, ka, kb;
+                front4(x.x, x.y, T[2 * k], qa, ka);
+                front4(x.z, x.w, T[2 * k + 1], qb, kb);
+                // fail-QC byte masks
                 F[2 * k] = T[2 * k] & perm(0u, 0xFF00FF00u, qa);
                 F[2 * k + 1] = T[2 * k + 1] & perm(0u, 0xFF00FF00u, qb);
-                S[k] = perm(0u, 0x04020100u, qa) | perm(0u, 0x40201000u, qb);
+                // S byte: LUT over (qcfail, dup) = one-hot {QC only, DUP only, both} in bits 0-2 plus a
+                // QC-class template in bits 6 (pass) / 7 (fail), which survives only for primary paired
+                // reads (bits 6,7 of the keep-mask).  lut & (keep | 0x3f) is ONE v_bitop3_b32.
+                S[2 * k] = perm(0u, 0x84428140u, qa) & (ka | 0x3F3F3F3Fu);
+                S[2 * k + 1] = perm(0u, 0x84428140u, qb) & (kb | 0x3F3F3F3Fu);
             }
-            uint32_t t2a, t2b, f2a, f2b;
+            uint32_t t2a, t2b, f2a, f2b, s2a, s2b;
             csa(t2a, s.t1, s.t1, T[0], T[1]);
             csa(t2b, s.t1, s.t1, T[2], T[3]);
             csa(f2a, s.f1, s.f1, F[0], F[1]);
             csa(f2b, s.f1, s.f1, F[2], F[3]);
+            csa(s2a, s.s1, s.s1, S[0], S[1]);
+            csa(s2b, s.s1, s.s1, S[2], S[3]);
             csa(q ? t4b : t4a, s.t2, s.t2, t2a, t2b);
             csa(q ? f4b : f4a, s.f2, s.f2, f2a, f2b);
-            csa(q ? s2b : s2a, s.s1, s.s1, S[0], S[1]);
+            csa(q ? s4b : s4a, s.s2, s.s2, s2a, s2b);
         }
         csa(half ? t8b : t8a, s.t4, s.t4, t4a, t4b);
         csa(half ? f8b : f8a, s.f4, s.f4, f4a, f4b);
-        csa(half ? s4b : s4a, s.s2, s.s2, s2a, s2b);
+        csa(half ? s8b : s8a, s.s4, s.s4, s4a, s4b);
     }
     uint32_t ct, cf, cs;
-    csa(ct, s.t8, s.t8, t8a, t8b);  // weight-16 carry
+    csa(ct, s.t8, s.t8, t8a, t8b);  // weight-16 carries
     csa(cf, s.f8, s.f8, f8a, f8b);
-    csa(cs, s.s4, s.s4, s4a, s4b);  // weight-8 carry
+    csa(cs, s.s8, s.s8, s8a, s8b);
     chain_push<0, DEPTH>(s, blk, ct, cf, cs);
 }
 
@@ -253,14 +264,15 @@ __device__ __forceinline__ void flush(Lane<DEPTH>& s)
         s.acc[8 + c] += af;
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-        const uint32_t mk = 0x11111111u << c;  // both nibble groups
+    for (int c = 0; c < kInternal - 16; ++c) {
+        const uint32_t mk = 0x01010101u << (c < 3 ? c : c + 3);  // S bits 0,1,2 and 6,7
         uint32_t as = 0;
 #pragma unroll
         for (int j = DEPTH - 1; j >= 0; --j) {
             as = hstep(as, s.sA[j], mk, true);
             as = hstep(as, s.sB[j], mk, false);
         }
+        as = hstep(as, s.s8, mk, true);
         as = hstep(as, s.s4, mk, true);
         as = hstep(as, s.s2, mk, true);
         as = hstep(as, s.s1, mk, true);
@@ -268,15 +280,20 @@ __device__ __forceinline__ void flush(Lane<DEPTH>& s)
     }
     s.t1 = s.t2 = s.t4 = s.t8 = 0;
     s.f1 = s.f2 = s.f4 = s.f8 = 0;
-    s.s1 = s.s2 = s.s4 = 0;
+    s.s1 = s.s2 = s.s4 = s.s8 = 0;
 #pragma unroll
     for (int j = 0; j < DEPTH; ++j) s.tA[j] = s.tB[j] = s.fA[j] = s.fB[j] = s.sA[j] = s.sB[j] = 0;
 }
 
-// Map the 19 internal totals to the reference's 32 slots (index = FLAGSTAT_*_OFF,
+// Map the 21 internal totals to the reference's 32 slots (index = FLAGSTAT_*_OFF,
 // libflagstats.h:69-112; +16 for fail-QC) and add them to / store them in out[32].
 // Called by the first 32 threads of a workgroup after tot[] is complete.
-__device__ __forceinline__ void finalize_slots(const uint64_t* tot, uint64_t* __restrict__ out, int store)
+// mode bit 0: store instead of accumulate.  mode bit 1: superset -- additionally slots 0 / 16 =
+// primary paired reads by QC class (samtools' n_pair_all, benchmark/flagstats.cpp:58; the slot the
+// reference's SIMD kernels fill with the same quantity for their SIMD-covered prefix) and
+// slot 9 = pass-QC reads (the "QC adjust" libflagstats.h:1843 of those kernels: len - fail-QC reads).
+// Without bit 1 the 32 slots are exactly FLAGSTAT_scalar's (libflagstats.h:118-142).
+__device__ __forceinline__ void finalize_slots(const uint64_t* tot, uint64_t* __restrict__ out, int mode, uint64_t n_flags)
 {
     if (threadIdx.x < 32) {
         // reference slot -> internal T index (secondary, n_pair_good, unmap, supplementary,
@@ -289,7 +306,11 @@ __device__ __forceinline__ void finalize_slots(const uint64_t* tot, uint64_t* __
         if (t >= 0) add = fail ? tot[8 + t] : tot[t] - tot[8 + t];  // pass-QC = all - fail
         if (slot == 10) add = fail ? tot[18] : tot[17];              // DUP: fail / pass
         if (slot == 9 && fail) add = tot[16] + tot[18];              // fail-QC read count (slot 25)
-        if (store)
+        if (mode & 2) {
+            if (slot == 0) add = fail ? tot[20] : tot[19];
+            if (slot == 9 && !fail) add = n_flags - (tot[16] + tot[18]);
+        }
+        if (mode & 1)
             out[threadIdx.x] = add;        // "=" form: all 32 slots written, dead slots as 0
         else if (add)
             out[threadIdx.x] += add;       // reference contract: accumulate, never touch dead slots
@@ -334,7 +355,7 @@ template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE>
 __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
                                                            uint64_t* __restrict__ partials, uint32_t* ticket,
-                                                           uint64_t* out, int store)
+                                                           uint64_t* out, int mode)
 {
     Lane<DEPTH> s;
     lane_init(s);
@@ -514,7 +535,7 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
         if (lane == 0) tot[c] = x;
     }
     __syncthreads();
-    finalize_slots(tot, out, store);
+    finalize_slots(tot, out, mode, hi - lo);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
@@ -551,7 +572,7 @@ constexpr int kFinalizeThreads = 1024;
 
 __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint64_t* __restrict__ partials,
                                                                       uint32_t nblocks, uint64_t* __restrict__ out,
-                                                                      int store)
+                                                                      int mode, uint64_t n_flags)
 {
     __shared__ uint64_t tot[32];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -563,7 +584,7 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
         if (lane == 0) tot[c] = x;
     }
     __syncthreads();
-    finalize_slots(tot, out, store);
+    finalize_slots(tot, out, mode, n_flags);
 }
 
 }  // namespace fsk
@@ -577,7 +598,7 @@ static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
     hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, STAGE>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials,
-                       a.ticket, a.out, a.store);
+                       a.ticket, a.out, a.mode);
     return hipGetLastError();
 }
 
@@ -604,7 +625,7 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     if (static_cast<uint64_t>(grid) > a.nsteps) grid = static_cast<uint32_t>(a.nsteps);
     a.grid = grid;
     a.partials = d_partials;
-    a.store = (variant >> 8) & 1;                        // bit 8 of `variant`: store instead of accumulate
+    a.mode = ((variant >> 8) & 1) | (((variant >> 10) & 1) << 1);  // bit 8: store instead of accumulate; bit 10: superset slots
     a.ticket = ((variant >> 9) & 1) ? d_ticket : nullptr;  // bit 9: fused finalise inside K1
     a.out = d_out32;
     if (((variant >> 9) & 1) && d_ticket == nullptr) return hipErrorInvalidValue;
@@ -612,23 +633,26 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
     // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers,
     // 32 = staging through a per-wave LDS ring filled by LDS-DMA, 64 = rolling at distance 2 (two buffers).
-    // Only the combinations that mattered in the r01 sweeps are instantiated (profiles/r01/tune_*.log
-    // also list 2-7, 11, 17, which lost and were dropped).
+    // The shipped library carries the default schedule (25) and the plain loop it is measured against (9).
+    // The schedules that lost the r01 sweeps stay in the source as evidence and are compiled only into a
+    // tuning build (make TUNING=1 -> -DFLAGSTAT_TUNING_VARIANTS; tools/tune.py, profiles/r01/tune_*.log).
     switch (variant & 127) {
+    case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
+    case 25: e = launch_count_t<8, true, false, true, 1>(a, stream); break;
+#ifdef FLAGSTAT_TUNING_VARIANTS
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
-    case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
     case 13: e = launch_count_t<8, true, true, true>(a, stream); break;
-    case 25: e = launch_count_t<8, true, false, true, 1>(a, stream); break;
     case 27: e = launch_count_t<7, true, false, true, 1>(a, stream); break;
     case 41: e = launch_count_t<8, true, false, true, 2>(a, stream); break;  // bit 5: LDS-DMA ring instead of registers
     case 89: e = launch_count_t<8, true, false, true, 3>(a, stream); break;  // bit 6: rolling registers at distance 2
+#endif
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
     if (a.ticket) return hipSuccess;  // K1 finalised by itself
     hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kFinalizeThreads), 0, stream, d_partials, grid, d_out32,
-                       a.store);
+                       a.mode, n);
     return hipGetLastError();
 }
 

@@ -9,10 +9,15 @@ fields and text the reference's bench prints (``benchmark/flagstats.cpp:577-588`
     n_secondary = 8   n_supp = 11   n_dup = 10   n_read1 = 6   n_read2 = 7
     n_pair_good = 12  n_sgltn = 13  n_pair_map = 14
     n_mapped[w] = n_reads[w] - slot 2          (libflagstats counts UNMAP, pyx:34)
-    n_pair_all[w] = n_read1[w] + n_read2[w]    (not among the 19 scalar counters; the reference's
-                                                Python module derives "paired_in_seq" the same way,
-                                                python/libflagstats.pyx:35 -- exact whenever every
-                                                primary paired read is exactly one of read1/read2)
+    n_pair_all[w] = slot 0 + 16*w              COUNTED by K1 (primary paired reads by QC class) and delivered
+                                               by the superset entry points (FLAGSTATS_u16_x64_superset,
+                                               FLAGSTATS_hip_device_u16_superset*): exact on any input,
+                                               like the reference's samtools loop (benchmark/flagstats.cpp:58).
+
+Counters from the scalar-exact entry points carry no n_pair_all (FLAGSTAT_scalar has no such slot);
+``derived_pair_all=True`` then falls back to read1 + read2 -- what the reference's Python module calls
+"paired_in_seq" (python/libflagstats.pyx:35), exact only when every primary paired read is exactly
+one of read1/read2 -- and the text says so on that line.
 
 The two "mate mapped to a different chr" lines of samtools need RNAME/MAPQ, not FLAG, and are
 commented out in the reference as well (``:589-590``).
@@ -22,16 +27,19 @@ from __future__ import annotations
 import numpy as np
 
 
-def samtools_counts(counters, n_values: int) -> dict:
+def samtools_counts(counters, n_values: int, derived_pair_all: bool = False) -> dict:
+    """samtools fields from 32 SUPERSET counters (or scalar-exact ones with ``derived_pair_all=True``)."""
     c = [int(v) for v in np.asarray(counters).ravel()]
     assert len(c) == 32
     n_reads = [int(n_values) - c[25], c[25]]
+    if not derived_pair_all:
+        assert c[9] == n_reads[0], "slot 9 (pass-QC reads) missing: these are not superset counters"
     out = {"n_reads": n_reads}
     for name, k in (("n_secondary", 8), ("n_supp", 11), ("n_dup", 10), ("n_read1", 6), ("n_read2", 7),
                     ("n_pair_good", 12), ("n_sgltn", 13), ("n_pair_map", 14)):
         out[name] = [c[k], c[16 + k]]
     out["n_mapped"] = [n_reads[0] - c[2], n_reads[1] - c[18]]
-    out["n_pair_all"] = [c[6] + c[7], c[22] + c[23]]
+    out["n_pair_all"] = [c[6] + c[7], c[22] + c[23]] if derived_pair_all else [c[0], c[16]]
     return out
 
 
@@ -42,8 +50,8 @@ def _percent(n: int, total: int) -> str:
     return "%.2f%%" % (float(np.float32(n) / np.float32(total)) * 100.0)
 
 
-def samtools_flagstat_text(counters, n_values: int) -> str:
-    s = samtools_counts(counters, n_values)
+def samtools_flagstat_text(counters, n_values: int, derived_pair_all: bool = False) -> str:
+    s = samtools_counts(counters, n_values, derived_pair_all)
     two = lambda k: "%d + %d" % (s[k][0], s[k][1])  # noqa: E731
     pct = lambda a, b: "(%s : %s)" % (_percent(s[a][0], s[b][0]), _percent(s[a][1], s[b][1]))  # noqa: E731
     lines = [
@@ -52,7 +60,7 @@ def samtools_flagstat_text(counters, n_values: int) -> str:
         two("n_supp") + " supplementary",
         two("n_dup") + " duplicates",
         two("n_mapped") + " mapped " + pct("n_mapped", "n_reads"),
-        two("n_pair_all") + " paired in sequencing",
+        two("n_pair_all") + " paired in sequencing" + (" (derived: read1 + read2)" if derived_pair_all else ""),
         two("n_read1") + " read1",
         two("n_read2") + " read2",
         two("n_pair_good") + " properly paired " + pct("n_pair_good", "n_pair_all"),
@@ -68,3 +76,13 @@ def counter_table_text(counters) -> str:
     from .pyflagstats import SAM_FLAG_NAMES
     c = np.asarray(counters).ravel()
     return "".join("%s\t%d\t%d\n" % (SAM_FLAG_NAMES[i], int(c[i]), int(c[16 + i])) for i in range(15))
+
+
+def flagstat_report(values) -> str:
+    """samtools-flagstat text of a host ``uint16`` array: one superset count on the GPU + the mapping above."""
+    from . import _lib
+    v = np.ascontiguousarray(values, dtype=np.uint16)
+    out = np.zeros(32, dtype=np.uint64)
+    _lib.check(_lib.lib().FLAGSTATS_u16_x64_superset(v.ctypes.data if v.size else None, v.size, out.ctypes.data),
+               "FLAGSTATS_u16_x64_superset")
+    return samtools_flagstat_text(out, v.size)

@@ -33,4 +33,7 @@ from .pyoracle import (  # noqa: F401
     ref_pospopcnt,
     pyflagstats_dict,
     ref_call,
+    samtools_counts,
+    samtools_counts_python,
+    samtools_text,
 )

@@ -106,6 +106,47 @@ static void hist_to_counters(const uint64_t* hist, uint64_t out[32])
     }
 }
 
+/* ---- the samtools counting loop the reference's bench carries beside its own kernels ----
+ * Restates the `flagstat_loop` macro, benchmark/flagstats.cpp:51-70, field by field; field order of
+ * `bam_flagstat_t` (:42-48): n_reads, n_mapped, n_pair_all, n_pair_map, n_pair_good, n_sgltn, n_read1,
+ * n_read2, n_dup, n_diffchr, n_diffhigh, n_secondary, n_supp; out[2 * field + w], w = 1 for fail-QC. */
+enum { SAM_READS, SAM_MAPPED, SAM_PAIR_ALL, SAM_PAIR_MAP, SAM_PAIR_GOOD, SAM_SGLTN, SAM_READ1, SAM_READ2, SAM_DUP,
+       SAM_DIFFCHR, SAM_DIFFHIGH, SAM_SECONDARY, SAM_SUPP };
+
+void oracle_samtools_update(uint16_t c, uint64_t out[26])
+{
+    const int w = (c & F_QCFAIL) ? 1 : 0;                                        /* :52 */
+    out[2 * SAM_READS + w] += 1;                                                 /* :53 */
+    if (c & F_SECONDARY) {                                                       /* :54 */
+        out[2 * SAM_SECONDARY + w] += 1;
+    } else if (c & F_SUPPLEMENTARY) {                                            /* :56 */
+        out[2 * SAM_SUPP + w] += 1;
+    } else if (c & F_PAIRED) {                                                   /* :58 */
+        out[2 * SAM_PAIR_ALL + w] += 1;
+        if ((c & F_PROPER) && !(c & F_UNMAP)) out[2 * SAM_PAIR_GOOD + w] += 1;   /* :60 */
+        if (c & F_READ1) out[2 * SAM_READ1 + w] += 1;                            /* :61 */
+        if (c & F_READ2) out[2 * SAM_READ2 + w] += 1;                            /* :62 */
+        if ((c & F_MUNMAP) && !(c & F_UNMAP)) out[2 * SAM_SGLTN + w] += 1;       /* :63 */
+        if (!(c & F_UNMAP) && !(c & F_MUNMAP)) out[2 * SAM_PAIR_MAP + w] += 1;   /* :64-66 */
+    }
+    if (!(c & F_UNMAP)) out[2 * SAM_MAPPED + w] += 1;                            /* :68 */
+    if (c & F_DUP) out[2 * SAM_DUP + w] += 1;                                    /* :69 */
+}
+
+void oracle_samtools_u16(const uint16_t* array, uint64_t n, uint64_t out[26])
+{
+    uint64_t* hist = (uint64_t*)calloc(65536, sizeof(uint64_t));
+    hist_accumulate(array, n, hist);
+    for (int v = 0; v < 65536; ++v) {
+        if (!hist[v]) continue;
+        uint64_t one[26];
+        memset(one, 0, sizeof one);
+        oracle_samtools_update((uint16_t)v, one);
+        for (int s = 0; s < 26; ++s) out[s] += one[s] * hist[v];
+    }
+    free(hist);
+}
+
 void oracle_flagstat_hist_u16(const uint16_t* array, uint64_t n, uint64_t out[32])
 {
     uint64_t* hist = (uint64_t*)calloc(65536, sizeof(uint64_t));

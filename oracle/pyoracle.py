@@ -142,6 +142,8 @@ def load_c():
     lib.oracle_flagstat_mt_u16.restype = None
     lib.oracle_FLAGSTAT_scalar.argtypes = [_U16P, ctypes.c_uint32, _U32P]
     lib.oracle_FLAGSTAT_scalar.restype = ctypes.c_int
+    lib.oracle_samtools_u16.argtypes = [_U16P, ctypes.c_uint64, _U64P]
+    lib.oracle_samtools_u16.restype = None
     lib.oracle_pospopcnt_u16.argtypes = [_U16P, ctypes.c_uint64, _U64P]
     lib.oracle_pospopcnt_u16.restype = None
     lib.oracle_generate_u16.argtypes = [ctypes.c_int, ctypes.c_uint64, ctypes.c_uint32,
@@ -187,6 +189,72 @@ def flagstat_hist(values) -> np.ndarray:
 def flagstat_mt(values, threads: int | None = None) -> np.ndarray:
     threads = threads or (os.cpu_count() or 1)
     return _run(load_c().oracle_flagstat_mt_u16, values, ctypes.c_int(threads))
+
+
+SAMTOOLS_FIELDS = ["n_reads", "n_mapped", "n_pair_all", "n_pair_map", "n_pair_good", "n_sgltn", "n_read1", "n_read2",
+                   "n_dup", "n_diffchr", "n_diffhigh", "n_secondary", "n_supp"]  # bam_flagstat_t, benchmark/flagstats.cpp:42-48
+
+
+def samtools_counts(values) -> dict:
+    """The reference bench's samtools loop (benchmark/flagstats.cpp:51-70): {field: [pass, fail]}."""
+    a = _as_u16(values)
+    if not a.flags["C_CONTIGUOUS"]:
+        a = np.ascontiguousarray(a)
+    out = np.zeros(26, dtype=np.uint64)
+    load_c().oracle_samtools_u16(_ptr16(a), a.size, out.ctypes.data_as(_U64P))
+    return {f: [int(out[2 * i]), int(out[2 * i + 1])] for i, f in enumerate(SAMTOOLS_FIELDS)}
+
+
+def samtools_counts_python(values) -> dict:
+    """Pure-Python statement of the same loop (small inputs): pins the C one."""
+    out = {f: [0, 0] for f in SAMTOOLS_FIELDS}
+    for c in (int(v) for v in np.asarray(values).ravel()):
+        w = 1 if c & 512 else 0
+        out["n_reads"][w] += 1
+        if c & 256:
+            out["n_secondary"][w] += 1
+        elif c & 2048:
+            out["n_supp"][w] += 1
+        elif c & 1:
+            out["n_pair_all"][w] += 1
+            if (c & 2) and not (c & 4):
+                out["n_pair_good"][w] += 1
+            if c & 64:
+                out["n_read1"][w] += 1
+            if c & 128:
+                out["n_read2"][w] += 1
+            if (c & 8) and not (c & 4):
+                out["n_sgltn"][w] += 1
+            if not (c & 4) and not (c & 8):
+                out["n_pair_map"][w] += 1
+        if not (c & 4):
+            out["n_mapped"][w] += 1
+        if c & 1024:
+            out["n_dup"][w] += 1
+    return out
+
+
+def samtools_text(counts: dict) -> str:
+    """The report the reference prints from that struct (benchmark/flagstats.cpp:73-78 `percent`, :577-588)."""
+    def pct(n, total):
+        return "N/A" if total == 0 else "%.2f%%" % (float(np.float32(n) / np.float32(total)) * 100.0)
+
+    s = counts
+    two = lambda k: "%d + %d" % (s[k][0], s[k][1])  # noqa: E731
+    par = lambda a, b: "(%s : %s)" % (pct(s[a][0], s[b][0]), pct(s[a][1], s[b][1]))  # noqa: E731
+    return "".join(line + "\n" for line in [
+        two("n_reads") + " in total (QC-passed reads + QC-failed reads)",
+        two("n_secondary") + " secondary",
+        two("n_supp") + " supplementary",
+        two("n_dup") + " duplicates",
+        two("n_mapped") + " mapped " + par("n_mapped", "n_reads"),
+        two("n_pair_all") + " paired in sequencing",
+        two("n_read1") + " read1",
+        two("n_read2") + " read2",
+        two("n_pair_good") + " properly paired " + par("n_pair_good", "n_pair_all"),
+        two("n_pair_map") + " with itself and mate mapped",
+        two("n_sgltn") + " singletons " + par("n_sgltn", "n_pair_all"),
+    ])
 
 
 def pospopcnt(values) -> np.ndarray:

@@ -61,3 +61,28 @@ setup(ext_modules=cythonize([Extension("pyflagstats", ["libflagstats.pyx"],
         r = subprocess.run([sys.executable, "-c", code], cwd=tmp_path, capture_output=True, text=True,
                            env=dict(os.environ, FLAGSTATS_HIP_ON_ERROR="return"))
         assert "libflagstats_hip" in r.stderr and "RESULT 0 0" in r.stdout, r.stdout + r.stderr
+
+
+REF_BENCH = "/root/reference/benchmark/flagstats.cpp"
+
+
+@pytest.mark.skipif(not os.path.exists(REF_BENCH), reason="reference tree not present on this machine")
+def test_reference_bench_program_builds_unmodified_against_the_shims(tmp_path):
+    """"a header shim so existing includers compile unchanged".  benchmark/flagstats.cpp pulls in
+    libalgebra.h + libflagstats.h and calls STORM_aligned_malloc / STORM_get_alignment / STORM_aligned_free
+    (:239,284,300,...) besides the dispatch symbols; with include/ first on the include path it compiles as it
+    stands (same recipe as oracle/Makefile `refbench`) and binds the engine's exported symbols."""
+    exe = str(tmp_path / "bench_hip")
+    libdir = os.path.join(ROOT, "libflagstats_amd")
+    subprocess.run(["g++", "-O1", "-std=c++11", "-w", "-I", os.path.join(ROOT, "include"), "-I", "/opt/conda/include",
+                    REF_BENCH, "-L", libdir, "-lflagstats_hip", "/opt/conda/lib/liblz4.so", "/opt/conda/lib/libzstd.so",
+                    "-Wl,-rpath," + libdir, "-Wl,-rpath-link,/opt/rocm/lib", "-o", exe], check=True)
+    nm = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True).stdout
+    assert "FLAGSTATS_get_function" in nm                      # resolved from libflagstats_hip.so at run time
+    assert "FLAGSTAT_avx512" not in subprocess.run(["nm", exe], capture_output=True, text=True).stdout   # no CPU kernels inside
+    import torch
+    if not torch.cuda.is_available():
+        # `decompress -d` on a reference-written file: the first block's call reaches the GPU library and fails loudly
+        f = os.path.join(ROOT, "tests", "golden", "blockfiles", "tiny_fast_a2.lz4")
+        r = subprocess.run([exe, "decompress", "-i", f, "-d"], capture_output=True, text=True)
+        assert r.returncode == -6 and "libflagstats_hip" in r.stderr and "Tot flags" not in r.stderr
