@@ -10,7 +10,9 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libflagstats_hip.so")
+# FLAGSTATS_HIP_LIB: load another build of the same library (e.g. `make tuning` -> libflagstats_hip_tuning.so,
+# the measurement build that also carries the K1 schedules that lost the sweeps)
+LIB_PATH = os.environ.get("FLAGSTATS_HIP_LIB") or os.path.join(_HERE, "libflagstats_hip.so")
 
 _U16P = ctypes.POINTER(ctypes.c_uint16)
 _U32P = ctypes.POINTER(ctypes.c_uint32)

@@ -142,10 +142,18 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         k.blocks_per_cu = static_cast<uint32_t>(value);
     } else if (!std::strcmp(key, "variant")) {
         if (value > 127) return fail_text("variant must be 0..127");
+        if (!fsk_variant_supported(static_cast<int>(value)))
+            return fail_text("this build carries K1 schedules 9 and 25 only (the r01 sweep's losers need make TUNING=1)");
         k.variant = static_cast<int>(value);
     } else if (!std::strcmp(key, "fuse")) {
         if (value > 1) return fail_text("fuse must be 0 or 1");
         k.fuse = static_cast<int>(value);
+    } else if (!std::strcmp(key, "anatomy")) {
+        if (!fsk_tuning_build()) return fail_text("anatomy is a tuning-build knob (make TUNING=1)");
+        fsk_set_anatomy(static_cast<int>(value));
+    } else if (!std::strcmp(key, "epilogue")) {
+        if (value > 1) return fail_text("epilogue must be 0 (partials + K2) or 1 (atomic adds from K1)");
+        k.epilogue = static_cast<int>(value);
     } else if (!std::strcmp(key, "chunk_flags")) {
         if (value < 8) return fail_text("chunk_flags must be >= 8");
         k.chunk_flags = value;
@@ -169,6 +177,8 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "variant")) return static_cast<uint64_t>(k.variant.load());
     if (!std::strcmp(key, "chunk_flags")) return k.chunk_flags.load();
     if (!std::strcmp(key, "fuse")) return static_cast<uint64_t>(k.fuse.load());
+    if (!std::strcmp(key, "epilogue")) return static_cast<uint64_t>(k.epilogue.load());
+    if (!std::strcmp(key, "tuning_build")) return static_cast<uint64_t>(fsk_tuning_build());
     if (!std::strcmp(key, "on_error")) return static_cast<uint64_t>(k.on_error.load());
     if (!std::strcmp(key, "numa")) return static_cast<uint64_t>(k.numa.load());
     if (!std::strcmp(key, "grid")) {

@@ -27,6 +27,21 @@ __device__ __forceinline__ uint32_t hstep(uint32_t acc, uint32_t plane, uint32_t
     return __builtin_popcount(plane & mask) + (dbl ? (acc << 1) : acc);
 }
 
+// Sum of x over the 64 lanes of a wave, valid in lane 63 only.  Six DPP adds on the VALU (quad
+// swaps, half-row and row mirrors, then the two row broadcasts), no LDS round trips: the
+// ds_bpermute butterfly __shfl_xor compiles to waits out the LDS latency at every one of its
+// 6 x 21 steps, which was 2.5 us of every launch (profiles/r02/launch_anatomy.log).
+__device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t x)
+{
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x141, 0xF, 0xF, false));  // row_half_mirror
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x140, 0xF, 0xF, false));  // row_mirror: every lane = its row's sum
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xA, 0xF, false));  // row_bcast:15 into rows 1 and 3
+    x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xC, 0xF, false));  // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 // The array is addressed on the 16-byte grid of its aligned-down base `a0`:
 // vector j holds flag positions [8j, 8j+8); positions in [lo, hi) are the
 // caller's flags, everything else reads as zero (a zero flag counts nothing).

@@ -31,6 +31,8 @@ struct Knobs {
     std::atomic<uint32_t> blocks_per_cu{0};       // 0 = auto (1)
     std::atomic<int> variant{25};                 // K1 schedule, see flagstat_kernels.hip
     std::atomic<int> fuse{0};                     // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
+    std::atomic<int> epilogue{1};                 // accumulate form into device memory: 1 = K1 adds its workgroup totals to
+                                                  // out[] with atomics (one launch), 0 = partials + K2
     std::atomic<uint64_t> chunk_flags{32ull << 20};  // host streaming chunk: 32 Mi flags = 64 MiB
     std::atomic<int> on_error{1};                 // legacy uint32 entry points: 1 = abort after the message, 0 = return non-zero
     std::atomic<int> numa{1};                     // block pipeline: 1 = pinned chunks + decoders on the GPU's NUMA node
@@ -38,7 +40,8 @@ struct Knobs {
 Knobs& knobs();
 
 // base operation | OP_SUPERSET (flagstat only: also fill slots 0/16 = primary paired reads, slot 9 = pass-QC reads)
-enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2, OP_BASE_MASK = 3, OP_SUPERSET = 4 };
+// | OP_HOST_OUT (d_out is pinned-host or managed memory: counters are written by K2, never by device atomics)
+enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2, OP_BASE_MASK = 3, OP_SUPERSET = 4, OP_HOST_OUT = 8 };
 
 struct Engine {
     int device = -1;
@@ -93,7 +96,7 @@ int default_device();                              // -1 before the first succes
 int select_default_device(int device);             // FLAGSTATS_hip_init
 
 // which device a device pointer lives on; fails loudly for host / unknown pointers
-int device_of_pointer(const void* p, const char* what, int* device);
+int device_of_pointer(const void* p, const char* what, int* device, bool* plain_device_memory = nullptr);
 // a caller's stream must belong to `device` (NULL = that device's null stream)
 int check_stream_device(hipStream_t s, int device);
 

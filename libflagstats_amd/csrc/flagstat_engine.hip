@@ -43,6 +43,7 @@ void read_env_knobs()
         g_knobs.variant = static_cast<int>(env_u64("FLAGSTATS_HIP_VARIANT", static_cast<uint64_t>(g_knobs.variant)));
         g_knobs.chunk_flags = env_u64("FLAGSTATS_HIP_CHUNK_FLAGS", g_knobs.chunk_flags);
         g_knobs.fuse = static_cast<int>(env_u64("FLAGSTATS_HIP_FUSE", static_cast<uint64_t>(g_knobs.fuse)));
+        g_knobs.epilogue = static_cast<int>(env_u64("FLAGSTATS_HIP_EPILOGUE", static_cast<uint64_t>(g_knobs.epilogue)));
         g_knobs.numa = static_cast<int>(env_u64("FLAGSTATS_HIP_NUMA", static_cast<uint64_t>(g_knobs.numa)));
         const char* oe = std::getenv("FLAGSTATS_HIP_ON_ERROR");
         if (oe && *oe) g_knobs.on_error = (!std::strcmp(oe, "return") || !std::strcmp(oe, "0")) ? 0 : 1;
@@ -286,7 +287,7 @@ void shutdown_all()
     }
 }
 
-int device_of_pointer(const void* p, const char* what, int* device)
+int device_of_pointer(const void* p, const char* what, int* device, bool* plain_device_memory)
 {
     hipPointerAttribute_t attr;
     std::memset(&attr, 0, sizeof attr);
@@ -302,6 +303,7 @@ int device_of_pointer(const void* p, const char* what, int* device)
         return fail_text(buf);
     }
     *device = attr.device;
+    if (plain_device_memory) *plain_device_memory = (attr.type == hipMemoryTypeDevice);
     return 0;
 }
 
@@ -359,8 +361,10 @@ int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t*
     if (base == OP_POSPOPCNT) {
         HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s));
     } else {
-        const int variant = g_knobs.variant.load() | (base == OP_FLAGSTAT_STORE ? 256 : 0) | (g_knobs.fuse.load() ? 512 : 0) |
-                            ((op & OP_SUPERSET) ? 1024 : 0);
+        // accumulate into plain device memory: K1 alone, its workgroups add their totals to d_out with atomics
+        const bool direct = base == OP_FLAGSTAT && !(op & OP_HOST_OUT) && g_knobs.epilogue.load() && !g_knobs.fuse.load();
+        const int variant = g_knobs.variant.load() | (base == OP_FLAGSTAT_STORE ? 256 : 0) |
+                            ((g_knobs.fuse.load() && !direct) ? 512 : 0) | ((op & OP_SUPERSET) ? 1024 : 0) | (direct ? 2048 : 0);
         HIP_TRY(fsk_launch(d_array, n, grid, variant, w.partials,
                            reinterpret_cast<uint32_t*>(w.partials + static_cast<size_t>(w.grid_cap) * fsk::kInternal), d_out, s));
     }
@@ -371,8 +375,10 @@ int count_on_user_stream(const uint16_t* d_array, uint64_t n, uint64_t* d_out, v
 {
     if (!d_out) return fail_text("NULL d_out");
     int dev_out = -1, dev_in = -1;
-    int rc = device_of_pointer(d_out, "d_out", &dev_out);
+    bool out_plain = false;
+    int rc = device_of_pointer(d_out, "d_out", &dev_out, &out_plain);
     if (rc) return rc;
+    if (!out_plain) op |= OP_HOST_OUT;  // pinned-host / managed counters: K2 writes them, no atomics over the bus
     if (n) {
         if (!d_array) return fail_text("NULL array with n > 0");
         rc = device_of_pointer(d_array, "d_array", &dev_in);

@@ -23,7 +23,8 @@ struct CountArgs {
     uint64_t* partials;    // [kInternal][grid]
     uint32_t* ticket;      // non-null: fused finalise by the last-arriving workgroup (must be 0 at launch)
     uint64_t* out;         // device uint64[32]
-    int mode;              // bit 0: out = counters instead of +=; bit 1: superset slots (0/16 n_pair_all, 9 pass-QC reads)
+    int mode;              // bit 0: out = counters instead of +=; bit 1: superset slots (0/16 n_pair_all, 9 pass-QC reads);
+                           // bit 2: direct epilogue -- every workgroup adds its totals to out[] with atomics, no K2
 };
 
 }  // namespace fsk
@@ -33,9 +34,12 @@ extern "C" {
 size_t fsk_partials_bytes(uint32_t grid);
 // K1 + K2 on `stream`: d_out32[32] += counters of d_array[0..n).  Asynchronous.
 // variant bits 0-6: K1 schedule; bit 8: store instead of accumulate; bit 9: fused finalise (needs d_ticket);
-// bit 10: superset slots
+// bit 10: superset slots; bit 11: direct atomic epilogue (accumulate form only; K1 alone, no K2)
 hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
                       uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream);
+int fsk_variant_supported(int variant);   // K1 schedule compiled into this build?
+void fsk_set_anatomy(int bits);           // tuning builds only: skip parts of K1 to time the rest (results wrong)
+int fsk_tuning_build(void);               // 1: built with -DFLAGSTAT_TUNING_VARIANTS (make TUNING=1)
 // positional popcount (flagstat_pospopcnt.hip): d_out16[16] += bit counts.  d_partials as for fsk_launch.
 hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, uint32_t grid, uint64_t* d_partials,
                                 uint64_t* d_out16, hipStream_t stream);

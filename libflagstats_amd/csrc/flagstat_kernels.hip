@@ -237,52 +237,66 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
     chain_push<0, DEPTH>(s, blk, ct, cf, cs);
 }
 
-// Epoch flush: fold every plane into the 19 u32 lane counters and clear them.
+// Flush: fold every plane into the 21 u32 lane counters and clear them.  `pushed` = steps pushed
+// since the last flush (wave-uniform): chain level j can hold a carry only after 2^j steps, so a
+// short run (a mid-size array leaves each workgroup a few dozen steps) skips the empty upper levels
+// with scalar branches -- the flush is ~1300 VALU ops at full depth, paid once per kernel, and is
+// part of the fixed cost that keeps sub-GiB launches off the roofline.
 template <int DEPTH>
-__device__ __forceinline__ void flush(Lane<DEPTH>& s)
+__device__ __forceinline__ void flush(Lane<DEPTH>& s, uint32_t pushed)
 {
+    constexpr int NS = kInternal - 16;
+    uint32_t at[8], af[8], as[NS];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) at[c] = af[c] = 0;
+#pragma unroll
+    for (int c = 0; c < NS; ++c) as[c] = 0;
+#pragma unroll
+    for (int j = DEPTH - 1; j >= 0; --j) {
+        if (pushed >= (1u << j)) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const uint32_t mk = 0x01010101u << c;
+                at[c] = hstep(at[c], s.tA[j], mk, true);
+                at[c] = hstep(at[c], s.tB[j], mk, false);
+                af[c] = hstep(af[c], s.fA[j], mk, true);
+                af[c] = hstep(af[c], s.fB[j], mk, false);
+            }
+#pragma unroll
+            for (int c = 0; c < NS; ++c) {
+                const uint32_t mk = 0x01010101u << (c < 3 ? c : c + 3);  // S bits 0,1,2 and 6,7
+                as[c] = hstep(as[c], s.sA[j], mk, true);
+                as[c] = hstep(as[c], s.sB[j], mk, false);
+            }
+            s.tA[j] = s.tB[j] = s.fA[j] = s.fB[j] = s.sA[j] = s.sB[j] = 0;
+        }
+    }
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
         const uint32_t mk = 0x01010101u << c;
-        uint32_t at = 0, af = 0;
-#pragma unroll
-        for (int j = DEPTH - 1; j >= 0; --j) {
-            at = hstep(at, s.tA[j], mk, true);
-            at = hstep(at, s.tB[j], mk, false);
-            af = hstep(af, s.fA[j], mk, true);
-            af = hstep(af, s.fB[j], mk, false);
-        }
-        at = hstep(at, s.t8, mk, true);
-        at = hstep(at, s.t4, mk, true);
-        at = hstep(at, s.t2, mk, true);
-        at = hstep(at, s.t1, mk, true);
-        af = hstep(af, s.f8, mk, true);
-        af = hstep(af, s.f4, mk, true);
-        af = hstep(af, s.f2, mk, true);
-        af = hstep(af, s.f1, mk, true);
-        s.acc[c] += at;
-        s.acc[8 + c] += af;
+        at[c] = hstep(at[c], s.t8, mk, true);
+        at[c] = hstep(at[c], s.t4, mk, true);
+        at[c] = hstep(at[c], s.t2, mk, true);
+        at[c] = hstep(at[c], s.t1, mk, true);
+        af[c] = hstep(af[c], s.f8, mk, true);
+        af[c] = hstep(af[c], s.f4, mk, true);
+        af[c] = hstep(af[c], s.f2, mk, true);
+        af[c] = hstep(af[c], s.f1, mk, true);
+        s.acc[c] += at[c];
+        s.acc[8 + c] += af[c];
     }
 #pragma unroll
-    for (int c = 0; c < kInternal - 16; ++c) {
-        const uint32_t mk = 0x01010101u << (c < 3 ? c : c + 3);  // S bits 0,1,2 and 6,7
-        uint32_t as = 0;
-#pragma unroll
-        for (int j = DEPTH - 1; j >= 0; --j) {
-            as = hstep(as, s.sA[j], mk, true);
-            as = hstep(as, s.sB[j], mk, false);
-        }
-        as = hstep(as, s.s8, mk, true);
-        as = hstep(as, s.s4, mk, true);
-        as = hstep(as, s.s2, mk, true);
-        as = hstep(as, s.s1, mk, true);
-        s.acc[16 + c] += as;
+    for (int c = 0; c < NS; ++c) {
+        const uint32_t mk = 0x01010101u << (c < 3 ? c : c + 3);
+        as[c] = hstep(as[c], s.s8, mk, true);
+        as[c] = hstep(as[c], s.s4, mk, true);
+        as[c] = hstep(as[c], s.s2, mk, true);
+        as[c] = hstep(as[c], s.s1, mk, true);
+        s.acc[16 + c] += as[c];
     }
     s.t1 = s.t2 = s.t4 = s.t8 = 0;
     s.f1 = s.f2 = s.f4 = s.f8 = 0;
     s.s1 = s.s2 = s.s4 = s.s8 = 0;
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j) s.tA[j] = s.tB[j] = s.fA[j] = s.fB[j] = s.sA[j] = s.sB[j] = 0;
 }
 
 // Map the 21 internal totals to the reference's 32 slots (index = FLAGSTAT_*_OFF,
@@ -293,6 +307,9 @@ __device__ __forceinline__ void flush(Lane<DEPTH>& s)
 // reference's SIMD kernels fill with the same quantity for their SIMD-covered prefix) and
 // slot 9 = pass-QC reads (the "QC adjust" libflagstats.h:1843 of those kernels: len - fail-QC reads).
 // Without bit 1 the 32 slots are exactly FLAGSTAT_scalar's (libflagstats.h:118-142).
+// ATOMIC (K1's direct epilogue): tot[] are ONE workgroup's totals, added with relaxed agent-scope
+// atomics -- any number of launches, on any streams, may target the same out[32].
+template <bool ATOMIC = false>
 __device__ __forceinline__ void finalize_slots(const uint64_t* tot, uint64_t* __restrict__ out, int mode, uint64_t n_flags)
 {
     if (threadIdx.x < 32) {
@@ -308,12 +325,18 @@ __device__ __forceinline__ void finalize_slots(const uint64_t* tot, uint64_t* __
         if (slot == 9 && fail) add = tot[16] + tot[18];              // fail-QC read count (slot 25)
         if (mode & 2) {
             if (slot == 0) add = fail ? tot[20] : tot[19];
+            // ATOMIC: n_flags is the launch's flag count in workgroup 0 and 0 elsewhere; the partial
+            // sums wrap modulo 2^64 and the total over all workgroups is len - fail-QC reads
             if (slot == 9 && !fail) add = n_flags - (tot[16] + tot[18]);
         }
-        if (mode & 1)
-            out[threadIdx.x] = add;        // "=" form: all 32 slots written, dead slots as 0
-        else if (add)
-            out[threadIdx.x] += add;       // reference contract: accumulate, never touch dead slots
+        if constexpr (ATOMIC) {
+            if (add) (void)__hip_atomic_fetch_add(&out[threadIdx.x], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            if (mode & 1)
+                out[threadIdx.x] = add;        // "=" form: all 32 slots written, dead slots as 0
+            else if (add)
+                out[threadIdx.x] += add;       // reference contract: accumulate, never touch dead slots
+        }
     }
 }
 
@@ -342,7 +365,7 @@ __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnrol
     step<DEPTH, STAGE, NT, USTRIDE>(s, v, blk, next, lds);
     ++blk;
     if (blk == (1u << DEPTH) - 1u) {
-        flush(s);
+        flush(s, (1u << DEPTH) - 1u);
         blk = 0;
     }
 }
@@ -481,22 +504,48 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
             st += G;
         }
     }
-    flush(s);
+#ifdef FLAGSTAT_TUNING_VARIANTS
+    // launch anatomy (tools/launch_anatomy.py; timing only, results are wrong): bit 9 skips the final
+    // flush, bit 10 everything after it
+    if (!(mode & 512)) flush(s, blk);
+    if (mode & 1024) {
+        uint32_t x = 0;
+#pragma unroll
+        for (int c = 0; c < kInternal; ++c) x ^= s.acc[c];
+        if (x == 0x9E3779B9u) out[0] = x;
+        return;
+    }
+#else
+    flush(s, blk);
+#endif
 
-    // wave butterfly, then 4 waves through LDS
+    // wave sums on the VALU (DPP), then the 4 waves through LDS
     __shared__ uint32_t red[kThreads / 64][kInternal];
+    uint32_t wsum[kInternal];
 #pragma unroll
-    for (int c = 0; c < kInternal; ++c) {
-        uint32_t x = s.acc[c];
+    for (int c = 0; c < kInternal; ++c) wsum[c] = wave_sum_lane63(s.acc[c]);
+    if (lane == 63) {
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-        if (lane == 0) red[wave][c] = x;
+        for (int c = 0; c < kInternal; ++c) red[wave][c] = wsum[c];
     }
     __syncthreads();
+    uint64_t sum = 0;
     if (threadIdx.x < kInternal) {
-        uint64_t sum = 0;
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) sum += red[w][threadIdx.x];
+    }
+    if (mode & 4) {
+        // Direct epilogue (accumulate contract only): this workgroup maps ITS 21 totals to the
+        // reference's slots and adds them to out[32] with relaxed agent-scope atomics (no return, no
+        // fence, no ticket, no K2 launch).  Integer sums are exact in any order; pass-QC = T - F holds
+        // per workgroup because F counts a subset of T.  Kernel end is the only ordering anyone needs.
+        __shared__ uint64_t wg_tot[32];
+        if (threadIdx.x < kInternal) wg_tot[threadIdx.x] = sum;
+        __syncthreads();
+        finalize_slots<true>(wg_tot, out, mode, blockIdx.x == 0 ? hi - lo : 0);
+        return;
+    }
+    if (threadIdx.x < kInternal) {
         // [counter][block]; write-through (sc1) so the finalising workgroup -- on whichever XCD -- sees it
         __hip_atomic_store(&partials[static_cast<uint64_t>(threadIdx.x) * gridDim.x + blockIdx.x], sum, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
@@ -593,6 +642,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
 // partials[19][grid] followed by a 256-byte block holding the hand-off ticket
 extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 256; }
 
+#ifdef FLAGSTAT_TUNING_VARIANTS
+static int g_anatomy = 0;  // bit 0: no steps, bit 1: no final flush, bit 2: nothing after the flush (timing only)
+#endif
+
 template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE = 0>
 static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
@@ -625,7 +678,13 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     if (static_cast<uint64_t>(grid) > a.nsteps) grid = static_cast<uint32_t>(a.nsteps);
     a.grid = grid;
     a.partials = d_partials;
-    a.mode = ((variant >> 8) & 1) | (((variant >> 10) & 1) << 1);  // bit 8: store instead of accumulate; bit 10: superset slots
+    // bit 8: store instead of accumulate; bit 10: superset slots; bit 11: direct (atomic) epilogue, no K2
+    a.mode = ((variant >> 8) & 1) | (((variant >> 10) & 1) << 1) | (((variant >> 11) & 1) << 2);
+    if ((a.mode & 4) && ((a.mode & 1) || ((variant >> 9) & 1))) return hipErrorInvalidValue;  // accumulate form only
+#ifdef FLAGSTAT_TUNING_VARIANTS
+    a.mode |= (g_anatomy & 6) << 8;
+    if (g_anatomy & 1) a.nsteps = a.fast_begin = a.fast_end = 0;  // no steps at all: launch + epilogue only
+#endif
     a.ticket = ((variant >> 9) & 1) ? d_ticket : nullptr;  // bit 9: fused finalise inside K1
     a.out = d_out32;
     if (((variant >> 9) & 1) && d_ticket == nullptr) return hipErrorInvalidValue;
@@ -650,10 +709,43 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
-    if (a.ticket) return hipSuccess;  // K1 finalised by itself
+    if (a.ticket || (a.mode & 4)) return hipSuccess;  // K1 finalised by itself
     hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kFinalizeThreads), 0, stream, d_partials, grid, d_out32,
                        a.mode, n);
     return hipGetLastError();
+}
+
+#ifdef FLAGSTAT_TUNING_VARIANTS
+extern "C" void fsk_set_anatomy(int bits) { g_anatomy = bits; }
+#else
+extern "C" void fsk_set_anatomy(int) {}
+#endif
+
+// which K1 schedules this build of the library carries (bits 0-6 of `variant`)
+extern "C" int fsk_variant_supported(int variant)
+{
+    switch (variant & 127) {
+    case 9:
+    case 25: return 1;
+#ifdef FLAGSTAT_TUNING_VARIANTS
+    case 0:
+    case 1:
+    case 13:
+    case 27:
+    case 41:
+    case 89: return 1;
+#endif
+    default: return 0;
+    }
+}
+
+extern "C" int fsk_tuning_build(void)
+{
+#ifdef FLAGSTAT_TUNING_VARIANTS
+    return 1;
+#else
+    return 0;
+#endif
 }
 
 // read-only bandwidth probe over the first floor(bytes / 32 KiB) steps of a 16-B aligned buffer

@@ -151,12 +151,12 @@ __global__ __launch_bounds__(kThreads) void pospopcnt_count(const uint4* __restr
     pos_flush(s);
 
     __shared__ uint32_t red[kThreads / 64][16];
+    uint32_t wsum[16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c) {
-        uint32_t x = s.acc[c];
+    for (int c = 0; c < 16; ++c) wsum[c] = wave_sum_lane63(s.acc[c]);
+    if (lane == 63) {
 #pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-        if (lane == 0) red[wave][c] = x;
+        for (int c = 0; c < 16; ++c) red[wave][c] = wsum[c];
     }
     __syncthreads();
     if (threadIdx.x < 16) {

@@ -1,0 +1,121 @@
+"""GPU: the two finalisation forms of the accumulate contract (libflagstats.h:118-142 `++f[...]`,
+SURVEY F9) -- K1 adding its workgroup totals to out[32] with atomics (default, one launch) and
+partials + K2 -- must be indistinguishable: same 32 slots, dead slots untouched, `+=` onto whatever
+the caller's counters held, also when several launches on different streams target one out[32]."""
+import ctypes
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+LIVE = [2, 6, 7, 8, 10, 11, 12, 13, 14, 18, 22, 23, 24, 25, 26, 27, 28, 29, 30]
+
+
+@pytest.fixture()
+def knob(hip):
+    old = hip.FLAGSTATS_hip_get(b"epilogue")
+    yield lambda v: hip.FLAGSTATS_hip_set(b"epilogue", v)
+    hip.FLAGSTATS_hip_set(b"epilogue", old)
+
+
+@pytest.mark.parametrize("epilogue", [0, 1])
+@pytest.mark.parametrize("n", [0, 1, 16383, 16384 * 3 + 5, 5_000_011, 16384 * 256 * 2])
+def test_accumulates_onto_caller_counters(hip, knob, epilogue, n):
+    import torch
+
+    import oracle
+    from libflagstats_amd import device
+    assert knob(epilogue) == 0
+    t = torch.empty(max(n, 1), dtype=torch.int16, device="cuda:0")[:n]
+    device.generate_torch(t, device.GEN_UNIFORM, seed=77 + n % 13, mask=0xFFFF)
+    start = torch.arange(100, 132, dtype=torch.int64, device="cuda:0")
+    out = start.clone()
+    device.count_torch(t, out)
+    device.count_torch(t, out)                      # a second pass accumulates
+    torch.cuda.synchronize()
+    want = oracle.flagstat_generated(oracle.GEN_UNIFORM, 77 + n % 13, 0xFFFF, 0, n).astype(np.int64)
+    got = out.cpu().numpy() - start.cpu().numpy()
+    assert np.array_equal(got, 2 * want), (epilogue, n)
+    dead = [i for i in range(32) if i not in LIVE]
+    assert not got[dead].any()                      # slots the scalar rule never writes stay untouched
+
+
+@pytest.mark.parametrize("epilogue", [0, 1])
+def test_superset_slots(hip, knob, epilogue):
+    """Superset form: slots 0 / 16 = primary paired reads by QC class, slot 9 = pass-QC reads
+    (len - fail-QC reads; with the atomic epilogue the per-workgroup terms wrap modulo 2^64 and
+    only their sum is meaningful)."""
+    import torch
+
+    import oracle
+    from libflagstats_amd import _lib, device
+    assert knob(epilogue) == 0
+    n = 7_654_321
+    t = torch.empty(n, dtype=torch.int16, device="cuda:0")
+    device.generate_torch(t, device.GEN_UNIFORM, seed=5, mask=0xFFFF)
+    out = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    _lib.check(hip.FLAGSTATS_hip_device_u16_superset(t.data_ptr(), n, out.data_ptr(), stream), "superset")
+    torch.cuda.synchronize()
+    got = out.cpu().numpy().view(np.uint64)
+    want = oracle.flagstat_generated(oracle.GEN_UNIFORM, 5, 0xFFFF, 0, n)
+    a = t.cpu().numpy().view(np.uint16)
+    pp = ((a & 0x100) == 0) & ((a & 0x800) == 0) & ((a & 1) == 1)
+    fail = (a & 0x200) != 0
+    want = want.copy()
+    want[0] = int((pp & ~fail).sum())
+    want[16] = int((pp & fail).sum())
+    want[9] = n - int(fail.sum())
+    assert np.array_equal(got, want)
+
+
+def test_two_streams_one_counter_array(hip, knob):
+    """Launches on different streams into the same out[32]: with the atomic epilogue every add is an
+    atomic, so nothing is lost (the K2 form's plain += needs one stream per out[32])."""
+    import torch
+
+    import oracle
+    from libflagstats_amd import device
+    assert knob(1) == 0
+    n = 3_000_017
+    a = torch.empty(n, dtype=torch.int16, device="cuda:0")
+    b = torch.empty(n, dtype=torch.int16, device="cuda:0")
+    device.generate_torch(a, device.GEN_UNIFORM, seed=1, mask=0xFFFF)
+    device.generate_torch(b, device.GEN_NA12878, seed=2, mask=1)
+    out = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    reps = 40
+    for _ in range(reps):
+        with torch.cuda.stream(s1):
+            device.count_torch(a, out)
+        with torch.cuda.stream(s2):
+            device.count_torch(b, out)
+    torch.cuda.synchronize()
+    want = reps * (oracle.flagstat_generated(oracle.GEN_UNIFORM, 1, 0xFFFF, 0, n) +
+                   oracle.flagstat_generated(oracle.GEN_NA12878, 2, 1, 0, n))
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+
+
+def test_pinned_host_counters_use_k2(hip, knob):
+    """out[32] in pinned host memory (FLAGSTATS_hip_host_alloc): counters are written by K2 through
+    the mapping, never by device atomics over the bus -- and are right."""
+    import oracle
+    from libflagstats_amd import _lib, device
+    assert knob(1) == 0
+    n = 2_000_003
+    d = device.DeviceFlags(n).generate(device.GEN_UNIFORM, seed=31, mask=0x0FFF)
+    hp = hip.FLAGSTATS_hip_host_alloc(256)
+    assert hp
+    try:
+        host = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_uint64)), shape=(32,))
+        host[:] = 3
+        _lib.check(hip.FLAGSTATS_hip_device_u16(d.ptr, n, hp, None), "FLAGSTATS_hip_device_u16(host counters)")
+        _lib.check(hip.FLAGSTATS_hip_synchronize(), "sync")
+        want = oracle.flagstat_generated(oracle.GEN_UNIFORM, 31, 0x0FFF, 0, n)
+        live = want != 0
+        assert np.array_equal(host[live], want[live] + 3) and (host[~live] == 3).all()
+    finally:
+        hip.FLAGSTATS_hip_host_free(hp)
+        d.free()

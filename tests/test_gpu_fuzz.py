@@ -13,7 +13,9 @@ def test_random_lengths_offsets_geometries(hip):
     cap = 3_000_000
     buf = device.DeviceFlags(cap + 64)
     old_v, old_b = hip.FLAGSTATS_hip_get(b"variant"), hip.FLAGSTATS_hip_get(b"blocks_per_cu")
-    old_f = hip.FLAGSTATS_hip_get(b"fuse")
+    old_f, old_e = hip.FLAGSTATS_hip_get(b"fuse"), hip.FLAGSTATS_hip_get(b"epilogue")
+    # the shipped library carries the default schedule and the plain loop; a tuning build (make TUNING=1) all of them
+    variants = [9, 25] + ([0, 1, 13, 27, 41, 89] if hip.FLAGSTATS_hip_get(b"tuning_build") else [])
     try:
         for it in range(150):
             kind = int(rs.randint(0, 3))
@@ -32,9 +34,10 @@ def test_random_lengths_offsets_geometries(hip):
                 n = int(rs.randint(0, cap))
             n = max(0, min(n, cap))
             off = int(rs.randint(0, 32))
-            _lib.check(hip.FLAGSTATS_hip_set(b"variant", int(rs.choice([1, 9, 25, 27, 13, 0, 41, 89]))), "variant")
+            _lib.check(hip.FLAGSTATS_hip_set(b"variant", int(rs.choice(variants))), "variant")
             _lib.check(hip.FLAGSTATS_hip_set(b"blocks_per_cu", int(rs.choice([1, 2, 3]))), "bpc")
             _lib.check(hip.FLAGSTATS_hip_set(b"fuse", int(rs.randint(0, 2))), "fuse")  # K1+K2 or K1 finalising itself
+            _lib.check(hip.FLAGSTATS_hip_set(b"epilogue", int(rs.randint(0, 2))), "epilogue")  # atomic adds from K1 or K2
             buf.generate(kind, seed=seed, mask=mask, first_index=first, offset=off, n=n)
             got = buf.count(offset=off, n=n)
             want = oracle.flagstat_generated(kind, seed, mask, first, n, threads=4)
@@ -43,6 +46,7 @@ def test_random_lengths_offsets_geometries(hip):
         hip.FLAGSTATS_hip_set(b"variant", old_v)
         hip.FLAGSTATS_hip_set(b"blocks_per_cu", old_b)
         hip.FLAGSTATS_hip_set(b"fuse", old_f)
+        hip.FLAGSTATS_hip_set(b"epilogue", old_e)
         buf.free()
 
 

@@ -116,6 +116,12 @@ def test_empty_and_null(hip):
 def test_kernel_variants_agree_with_oracle(hip, variant):
     import oracle
     from libflagstats_amd import _lib, device
+    if variant not in (9, 25) and not hip.FLAGSTATS_hip_get(b"tuning_build"):
+        # the schedules that lost the r01 sweeps are compiled only into `make TUNING=1`; the shipped
+        # library must refuse them loudly instead of launching something else
+        assert hip.FLAGSTATS_hip_set(b"variant", variant) != 0
+        assert b"TUNING=1" in hip.FLAGSTATS_hip_last_error()
+        return
     old = hip.FLAGSTATS_hip_get(b"variant")
     _lib.check(hip.FLAGSTATS_hip_set(b"variant", variant), "set variant")
     try:

@@ -1,8 +1,12 @@
 #!/usr/bin/env python3
-"""K1+K2 latency / throughput vs array size on one MI355X (device-resident, back-to-back launches),
-for the sizes BASELINE.json's configs name (1 M flags, 1 GiB, 8 GiB) and points between, on uniform
-and NA12878-like data.  Arrays <= 256 MiB can sit in the Infinity Cache between launches; the
-'rot' column rotates over enough distinct buffers to defeat that."""
+"""Hot-path latency / throughput vs array size on one MI355X (device-resident, back-to-back launches)
+for the sizes BASELINE.json's configs name (1 M flags, 1 GiB, 8 GiB) and points between.
+
+Columns compare the two finalisation forms of the accumulate contract: `k2` = K1 writes partials and
+K2 sums them (r01's only form), `atomic` = K1's workgroups add their totals to out[32] themselves
+(one launch).  Arrays <= 256 MiB can sit in the Infinity Cache between launches; the `rot` columns
+rotate over disjoint slices of an 8 GiB buffer to defeat that.  --bpc also sweeps workgroups per CU."""
+import argparse
 import os
 import statistics
 import sys
@@ -10,34 +14,56 @@ import sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from libflagstats_amd import _lib, device  # noqa: E402
 
-lib = _lib.lib()
-_lib.check(lib.FLAGSTATS_hip_init(0), "init")
-total = 2 ** 32
-d = device.DeviceFlags(total).generate(0, seed=5, mask=0xFFFF)
-print("kind      flags        MiB   ms(same buf)  TB/s     ms(rotating)  TB/s")
-for kind, name in ((0, "uniform"), (1, "na12878")):
-    if kind == 1:
-        d.generate(1, seed=5, mask=1)
-    for n in (10 ** 6, 2 ** 22, 2 ** 24, 2 ** 26, 2 ** 28, 2 ** 29, 2 ** 30, 2 ** 32):
-        reps = max(5, min(200, (2 ** 33) // n))
-        same = []
-        for r in range(5):
-            ms, _ = device.time_device_ptr(d.ptr, n, 2, reps)
-            same.append(ms / reps)
-        # rotate through disjoint slices of the 8 GiB buffer
-        slots = max(1, total // n)
-        rot = []
-        if slots > 1:
-            import ctypes
-            import numpy as np
-            for r in range(3):
-                t = 0.0
-                k = min(slots, 64)
-                for i in range(k):
-                    ms, _ = device.time_device_ptr(d.ptr + 2 * n * ((i * 7919) % slots), n, 0, 1)
-                    t += ms
-                rot.append(t / k)
-        a = statistics.median(same)
-        b = statistics.median(rot) if rot else float("nan")
-        print("%-8s %11d %8.1f   %9.4f  %7.3f   %9.4f  %7.3f" % (name, n, n * 2 / 2 ** 20, a, 2 * n / a / 1e9, b,
-                                                               2 * n / b / 1e9 if rot else float("nan")))
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kinds", default="0,1")
+    ap.add_argument("--bpc", default="1")
+    ap.add_argument("--epilogues", default="0,1")
+    ap.add_argument("--sizes", default="1000000,4194304,16777216,67108864,268435456,536870912,1073741824,4294967296")
+    args = ap.parse_args()
+    lib = _lib.lib()
+    _lib.check(lib.FLAGSTATS_hip_init(0), "init")
+    total = 2 ** 32
+    d = device.DeviceFlags(total)
+    names = {0: "uniform", 1: "na12878"}
+    eps = [int(e) for e in args.epilogues.split(",")]
+    head = "kind     bpc       flags      MiB"
+    for e in eps:
+        tag = "atomic" if e else "k2"
+        head += "   us(%s) TB/s   us(%s,rot) TB/s" % (tag, tag)
+    print(head)
+    for kind in [int(k) for k in args.kinds.split(",")]:
+        d.generate(kind, seed=5, mask=0xFFFF if kind == 0 else 1)
+        for bpc in [int(b) for b in args.bpc.split(",")]:
+            _lib.check(lib.FLAGSTATS_hip_set(b"blocks_per_cu", bpc), "bpc")
+            for n in [int(s) for s in args.sizes.split(",")]:
+                line = "%-8s %3d %11d %8.1f" % (names[kind], bpc, n, n * 2 / 2 ** 20)
+                for e in eps:
+                    _lib.check(lib.FLAGSTATS_hip_set(b"epilogue", e), "epilogue")
+                    reps = max(5, min(200, (2 ** 33) // n))
+                    same = []
+                    for r in range(5):
+                        ms, _ = device.time_device_ptr(d.ptr, n, 2, reps)
+                        same.append(ms / reps)
+                    slots = max(1, total // n)
+                    rot = []
+                    if slots > 1:
+                        for r in range(3):
+                            t = 0.0
+                            k = min(slots, 64)
+                            for i in range(k):
+                                ms, _ = device.time_device_ptr(d.ptr + 2 * n * ((i * 7919) % slots), n, 0, 1)
+                                t += ms
+                            rot.append(t / k)
+                    a = statistics.median(same)
+                    b = statistics.median(rot) if rot else float("nan")
+                    line += "   %9.2f %6.3f   %9.2f %6.3f" % (a * 1e3, 2 * n / a / 1e9, b * 1e3,
+                                                             2 * n / b / 1e9 if rot else float("nan"))
+                print(line, flush=True)
+    lib.FLAGSTATS_hip_set(b"blocks_per_cu", 0)
+    lib.FLAGSTATS_hip_set(b"epilogue", 1)
+
+
+if __name__ == "__main__":
+    main()
