@@ -46,6 +46,35 @@ def kernel_source_id():
     return h.hexdigest()[:16]
 
 
+def usable_cpus():
+    """Threads the all-core leg may really run: the affinity mask, capped by the cgroup CPU quota
+    (a GPU box hands a 1-GPU job a CPU *share*, e.g. 16 of 256 logical CPUs, as a CFS quota: 256
+    spinning threads under a 16-CPU quota measure the throttler, not the kernel -- r01's all-core
+    figures ranged 5-47 Gflags/s for that reason)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    note = "%d CPUs in the affinity mask" % n
+    quota = None
+    try:
+        with open("/sys/fs/cgroup/cpu.max") as f:          # cgroup v2: "<quota|max> <period>"
+            q, p = f.read().split()[:2]
+            if q != "max":
+                quota = int(q) / int(p)
+    except (OSError, ValueError):
+        try:
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us") as f:   # cgroup v1
+                q = int(f.read())
+            with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as f:
+                p = int(f.read())
+            if q > 0:
+                quota = q / p
+        except (OSError, ValueError):
+            pass
+    if quota is not None and quota < n:
+        n = max(1, int(quota))
+        note += ", cgroup quota %.1f CPUs" % quota
+    return n, note
+
+
 def cpu_baseline(seconds: float, sample_flags: int, seed: int):
     """Time the reference's own kernel (what FLAGSTATS_get_function returns on this host,
     libflagstats.h:2976-3022) on a prefix of the rank-0 workload: 1 thread, then every core with
@@ -107,7 +136,7 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
     # all cores: one pinned thread per logical CPU, 8 MiB of its own (first-touched, so socket-local)
     # uniform-random flags each -- beyond the per-core caches -- timed inside C between two barriers
     allc = None
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores, cores_note = usable_cpus()
     if ref is not None and hasattr(ref, "ref_dispatch_mt_bench"):
         ref.ref_dispatch_mt_bench.restype = ctypes.c_double
         ref.ref_dispatch_mt_bench.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, u64p]
@@ -123,8 +152,8 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
         runs.sort()
         allc = {"value": round(runs[1], 4), "unit": "Gflags/s", "cores": cores, "min": round(runs[0], 4),
                 "max": round(runs[2], 4),
-                "sample": "%d flags (%.0f MiB) in %d pinned, shard-local shards x %d passes, median of 3 runs"
-                          % (per * cores, per * cores * 2 / 2 ** 20, cores, reps)}
+                "sample": "%d flags (%.0f MiB) in %d pinned, shard-local shards x %d passes, median of 3 runs; %s"
+                          % (per * cores, per * cores * 2 / 2 ** 20, cores, reps, cores_note)}
 
     return {
         "value": round(one, 4), "unit": "Gflags/s", "cores": 1, "kind": kind, "kernel": name,

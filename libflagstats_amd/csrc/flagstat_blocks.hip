@@ -36,96 +36,11 @@
 
 #include "../../include/libflagstats_hip.h"
 #include "flagstat_engine.h"
+#include "lz4_block_decode.h"
 
 namespace {
 
-// ---------------------------------------------------------------- LZ4 block decoder (safe)
-// Returns decoded byte count, or -1 on malformed input / output overflow.  Never reads outside
-// [src, src+n) nor writes outside [dst, dst+cap).
-int64_t lz4_block_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap)
-{
-    const uint8_t* ip = src;
-    const uint8_t* const iend = src + n;
-    uint8_t* op = dst;
-    uint8_t* const oend = dst + cap;
-    if (n == 0) return -1;
-    for (;;) {
-        if (ip >= iend) return -1;
-        const unsigned token = *ip++;
-        size_t lit = token >> 4;
-        // Shortcut for the common sequence (<= 14 literals, match of <= 18 bytes at distance >= 8)
-        // while far from both buffer ends: fixed-size copies, one bounds check.  With >= 18 input
-        // bytes left and <= 14 literals this cannot be the literals-only last sequence.
-        if (lit < 15 && static_cast<size_t>(iend - ip) >= 18 && static_cast<size_t>(oend - op) >= 36) {
-            std::memcpy(op, ip, 16);
-            ip += lit;
-            op += lit;
-            const size_t soff = static_cast<size_t>(ip[0]) | (static_cast<size_t>(ip[1]) << 8);
-            const size_t sml = token & 15u;
-            if (sml < 15 && soff >= 8 && soff <= static_cast<size_t>(op - dst)) {
-                const uint8_t* m = op - soff;
-                std::memcpy(op, m, 8);
-                std::memcpy(op + 8, m + 8, 8);
-                std::memcpy(op + 16, m + 16, 2);
-                ip += 2;
-                op += sml + 4;
-                continue;
-            }
-            // not a shortcut match: undo and take the general path below
-            ip -= lit;
-            op -= lit;
-        }
-        if (lit == 15) {
-            unsigned b;
-            do {
-                if (ip >= iend) return -1;
-                b = *ip++;
-                lit += b;
-            } while (b == 255);
-        }
-        if (lit > static_cast<size_t>(iend - ip) || lit > static_cast<size_t>(oend - op)) return -1;
-        if (lit <= 32 && static_cast<size_t>(iend - ip) >= 32 && static_cast<size_t>(oend - op) >= 32) {
-            std::memcpy(op, ip, 32);  // short literal run: one fixed-size copy, tail bytes are overwritten later
-        } else {
-            std::memcpy(op, ip, lit);
-        }
-        ip += lit;
-        op += lit;
-        if (ip == iend) break;  // last sequence carries literals only
-        if (iend - ip < 2) return -1;
-        const size_t off = static_cast<size_t>(ip[0]) | (static_cast<size_t>(ip[1]) << 8);
-        ip += 2;
-        if (off == 0 || off > static_cast<size_t>(op - dst)) return -1;
-        size_t ml = token & 15u;
-        if (ml == 15) {
-            unsigned b;
-            do {
-                if (ip >= iend) return -1;
-                b = *ip++;
-                ml += b;
-            } while (b == 255);
-        }
-        ml += 4;
-        if (ml > static_cast<size_t>(oend - op)) return -1;
-        const uint8_t* m = op - off;
-        if (off >= 16 && static_cast<size_t>(oend - op) >= ml + 16) {
-            // non-overlapping at 16-byte granularity: wild copy in 16-byte steps
-            uint8_t* d = op;
-            const uint8_t* const dend = op + ml;
-            do {
-                std::memcpy(d, m, 16);
-                d += 16;
-                m += 16;
-            } while (d < dend);
-        } else if (off >= ml) {
-            std::memcpy(op, m, ml);
-        } else {
-            for (size_t i = 0; i < ml; ++i) op[i] = m[i];  // overlapping run (RLE-like)
-        }
-        op += ml;
-    }
-    return op - dst;
-}
+using fslz4::lz4_block_decode;
 
 struct BlockRef {
     const uint8_t* src;   // payload in memory (image mode) or nullptr (file mode: pread at file_off)

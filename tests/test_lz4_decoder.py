@@ -79,3 +79,22 @@ def test_offset_beyond_output_is_rejected():
     assert blockfile.lz4_block_decode(b"\x10A\x00\x00" + b"\x50ABCDE", 64) is None
     # valid: 'A' then match offset 1 length 4 -> 'AAAAA', then 5 literals
     assert blockfile.lz4_block_decode(b"\x10A\x01\x00" + b"\x50BCDEF", 64) == b"AAAAABCDEF"
+
+
+def test_fast_loops_are_memory_safe_under_asan(tmp_path):
+    """The decoder's fast loops start after 64 KiB of output, so the small cases above never reach them:
+    tests/lz4_fuzz_asan.cpp decodes damaged / truncated ~1 MB blocks (LZ4-fast and LZ4-HC of four
+    flag-like streams) into exact-size buffers under AddressSanitizer + UBSan, and compares with liblz4
+    whenever both accept."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = tmp_path / "lz4fuzz"
+    subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                    "-o", str(exe), os.path.join(ROOT, "tests", "lz4_fuzz_asan.cpp"), "-ldl"], check=True)
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0")
+    env.pop("LD_PRELOAD", None)
+    r = subprocess.run([str(exe), "120"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert r.stdout.startswith("OK") or r.stdout.startswith("SKIP"), r.stdout
