@@ -134,6 +134,19 @@ bool node_cpuset(int node, cpu_set_t* set)
     return count > 0;
 }
 
+// CPUs this process may use per the cgroup v2 CPU controller ("<quota> <period>" or "max <period>"); 0 = no limit known
+double cgroup_cpu_quota()
+{
+    FILE* f = std::fopen("/sys/fs/cgroup/cpu.max", "r");
+    if (!f) return 0;
+    char q[32] = {0};
+    long period = 0;
+    const int got = std::fscanf(f, "%31s %ld", q, &period);
+    std::fclose(f);
+    if (got != 2 || period <= 0 || !std::strcmp(q, "max")) return 0;
+    return std::strtod(q, nullptr) / static_cast<double>(period);
+}
+
 struct Pipe {
     std::mutex m;
     std::condition_variable cv_workers;  // "a chunk buffer was released" (orchestrator -> decoders)
@@ -153,7 +166,7 @@ constexpr int kPinned = 3;
 // makes all decode threads fault on one address space; the contention grows with the thread
 // count and was measured to cost more than the extra copy.)
 int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, int threads, uint64_t* out,
-                 FLAGSTATS_blockfile_stats* st)
+                 FLAGSTATS_blockfile_stats* st, const uint8_t* map = nullptr)
 {
     const double t0 = now_s();
     uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
@@ -163,12 +176,18 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
     uint64_t uncompressed = 0;
     int rc = index_blocks(img, fd, bytes, chunk_cap, blocks, chunks, uncompressed);
     if (rc) return rc;
+    if (map)  // file mode with a mapping: headers were pread (no fault per block), payloads are decoded in place
+        for (BlockRef& b : blocks) b.src = map + b.file_off;
     const double t_index = now_s() - t0;
     uint64_t n_flags = 0;
     for (const BlockRef& b : blocks) n_flags += b.usize >> 1;  // as benchmark/flagstats.cpp:323
     if (threads <= 0) {
         threads = static_cast<int>(std::thread::hardware_concurrency());
-        if (threads > 24) threads = 24;  // ~PCIe-bound from 16-24 decoders on 2x EPYC 9575F (profiles/r01)
+        if (threads > 24) threads = 24;  // ~PCIe-bound from 16-24 decoders on 2x EPYC 9575F (profiles/r01, r02)
+        // a container's CPU quota (cgroup v2 cpu.max) is what the decoders really get: more runnable
+        // threads than that are throttled, not run (the GPU boxes hand a 1-GPU job 16 of 256 CPUs)
+        const double quota = cgroup_cpu_quota();
+        if (quota > 0 && threads > static_cast<int>(quota * 1.25)) threads = static_cast<int>(quota * 1.25);
         if (threads < 1) threads = 1;
     }
     if (static_cast<size_t>(threads) > blocks.size() && !blocks.empty()) threads = static_cast<int>(blocks.size());
@@ -191,7 +210,9 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
         for (int i = 0; i < kPinned; ++i) pinned[i] = static_cast<uint8_t*>(bufs[i]);
     }
     for (int i = 0; i < npin; ++i) {
-        hipError_t e = hipEventCreateWithFlags(&copied[i], hipEventDisableTiming);
+        // blocking sync: the orchestrator sleeps in hipEventSynchronize instead of spinning on a CPU
+        // the decoders could use (it waits ~70 % of the wall time once the pipeline is PCIe-bound)
+        hipError_t e = hipEventCreateWithFlags(&copied[i], hipEventDisableTiming | hipEventBlockingSync);
         if (e != hipSuccess) return fsint::fail_hip("hipEventCreate", e);
     }
     const double t_setup = now_s() - t0;
@@ -228,6 +249,13 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
                 uint8_t* dst = base + br.dst_off;
                 const uint64_t padded = (static_cast<uint64_t>(br.usize) + 15) & ~15ull;
                 const uint8_t* src = br.src;
+                if (src && map && br.csize) {
+                    // map this block's pages of the page cache in ONE call (Linux >= 5.14) instead of one
+                    // fault per 16 pages; where the kernel does not know the advice, faults do the same lazily
+                    const uintptr_t a0 = reinterpret_cast<uintptr_t>(src) & ~static_cast<uintptr_t>(4095);
+                    const uintptr_t a1 = (reinterpret_cast<uintptr_t>(src) + br.csize + 4095) & ~static_cast<uintptr_t>(4095);
+                    (void)madvise(reinterpret_cast<void*>(a0), a1 - a0, 22 /* MADV_POPULATE_READ */);
+                }
                 if (!src) {
                     if (local.size() < br.csize) local.resize(br.csize + (br.csize >> 2) + 64);
                     size_t have = 0;
@@ -419,8 +447,20 @@ int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FL
         return fsint::fail_text("cannot stat file");
     }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    // File mode: every worker preads the compressed payload of its block into a private buffer (30 % of
+    // the decoders' CPU time).  FLAGSTATS_HIP_BLOCK_IO=mmap decodes straight out of a read-only mapping
+    // instead (each worker populates its own block's pages with one madvise): built and measured SLOWER
+    // on the page cache of the r02 boxes -- populating and tearing down 490 k PTEs costs what the copy
+    // costs (19-22 vs 24-26 Gflags/s, profiles/r02/blockfile_lz4_4GiB.log) -- so it is opt-in.
+    const uint64_t bytes = static_cast<uint64_t>(sb.st_size);
+    const char* io = std::getenv("FLAGSTATS_HIP_BLOCK_IO");
+    void* map = MAP_FAILED;
+    if (bytes && io && !std::strcmp(io, "mmap")) map = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
     fsint::Engine* eng = fsint::default_engine();
-    const int rc = eng ? run_pipeline(*eng, nullptr, fd, static_cast<uint64_t>(sb.st_size), threads, out, stats) : -1;
+    const int rc = eng ? run_pipeline(*eng, nullptr, fd, bytes, threads, out, stats,
+                                      map == MAP_FAILED ? nullptr : static_cast<const uint8_t*>(map))
+                       : -1;
+    if (map != MAP_FAILED) munmap(map, bytes);
     close(fd);
     return rc;
 }

@@ -36,6 +36,9 @@ def main():
     ap.add_argument("--level", type=int, default=2)
     ap.add_argument("--dir", default=None)
     ap.add_argument("--chunk-mib", default="64")
+    ap.add_argument("--image", action="store_true", help="also time FLAGSTATS_hip_blockimage_lz4 on the file read into memory "
+                                                         "(no pread of the compressed payload in the workers)")
+    ap.add_argument("--no-serial", action="store_true", help="skip the serial host loops of the reference shape")
     args = ap.parse_args()
     import oracle
 
@@ -64,22 +67,36 @@ def main():
     want = oracle.flagstat_generated(oracle.GEN_NA12878, 7, 1, 0, n)
 
     rows = []
-    for cm, th in [(int(c), int(t)) for c in args.chunk_mib.split(",") for t in args.threads.split(",")]:
+    image = np.fromfile(path, dtype=np.uint8) if args.image else None
+    modes = ["file"] + (["image"] if args.image else [])
+    for mode, cm, th in [(m, int(c), int(t)) for m in modes for c in args.chunk_mib.split(",") for t in args.threads.split(",")]:
         lib.FLAGSTATS_hip_set(b"chunk_flags", cm << 19)
         best = None
         for rep in range(3):
             t0 = time.perf_counter()
-            got, st = blockfile.flagstat_lz4_file(path, th)
+            if mode == "file":
+                got, st = blockfile.flagstat_lz4_file(path, th)
+            else:
+                got = np.zeros(32, dtype=np.uint64)
+                stc = _lib.BlockfileStats()
+                _lib.check(lib.FLAGSTATS_hip_blockimage_lz4(image.ctypes.data, image.size, th, got.ctypes.data, ctypes.byref(stc)),
+                           "FLAGSTATS_hip_blockimage_lz4")
+                st = {name: getattr(stc, name) for name, _ in stc._fields_}
             dt = time.perf_counter() - t0
             assert np.array_equal(got, want), "PARITY"
             if best is None or dt < best[0]:
                 best = (dt, st)
         dt, st = best
-        rows.append({"chunk_MiB": cm, "threads": st["threads"], "wall_s": round(dt, 4), "Gflags_s": round(n / dt / 1e9, 2),
+        rows.append({"mode": mode, "chunk_MiB": cm, "threads": st["threads"], "wall_s": round(dt, 4), "Gflags_s": round(n / dt / 1e9, 2),
                      "compressed_GB_s": round(size / dt / 1e9, 2), "decode_cpu_s": round(st["decode_cpu_s"], 3), "setup_s": round(st["setup_s"], 4), "wait_decode_s": round(st["wait_decode_s"], 4), "wait_copy_s": round(st["wait_copy_s"], 4),
                      "decode_GB_s_per_thread": round(2 * n / max(st["decode_cpu_s"], 1e-9) / 1e9, 2)})
         print(rows[-1], flush=True)
 
+    if args.no_serial:
+        print(json.dumps({"workload": "%d NA12878-like flags, %d-byte LZ4-%s-%d blocks" % (n, bt.BLOCK_BYTES, args.mode, args.level),
+                          "file_bytes": size, "product": rows}))
+        os.remove(path)
+        return
     # the reference's loop shape on this host: one thread, per block liblz4 decode then its dispatcher kernel
     ref = oracle.load_ref()
     img = open(path, "rb").read()
