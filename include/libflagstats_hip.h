@@ -167,6 +167,14 @@ int FLAGSTATS_hip_synchronize(void);
 int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, uint32_t mask,
                                uint64_t first_index, void* stream);
 
+/* ---- FLAG text -> uint16 array (counterpart of benchmark/utility.cpp:9-16, the reference's
+ * `samtools view FILE | cut -f 2 | utility > FLAGS.bin` step): one decimal FLAG per line, std::getline +
+ * atoi rules (a final unterminated line counts; an empty or non-numeric line is 0; "99\r" is 99; the
+ * int is truncated to 16 bits).  Host code.  Returns the number of values written to out[0..cap), or
+ * < 0 if `cap` is too small; FLAGSTATS_text_count_lines gives the exact count beforehand. */
+int64_t FLAGSTATS_text_to_u16(const char* text, uint64_t len, uint16_t* out, uint64_t cap);
+uint64_t FLAGSTATS_text_count_lines(const char* text, uint64_t len);
+
 /* ---- measurement: `reps` back-to-back K1+K2 launches between two hipEvents on
  * the library's stream, after `warmup` untimed ones.  *ms_total = elapsed ms of
  * the timed region; out[32] += counters of ONE pass.  Returns 0 on success. */

@@ -64,6 +64,8 @@ SIGNATURES = {
     "FLAGSTATS_hip_compute_units": (ctypes.c_int, []),
     "FLAGSTATS_hip_set": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64]),
     "FLAGSTATS_hip_get": (ctypes.c_uint64, [ctypes.c_char_p]),
+    "FLAGSTATS_text_to_u16": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]),
+    "FLAGSTATS_text_count_lines": (ctypes.c_uint64, [ctypes.c_char_p, ctypes.c_uint64]),
     "FLAGSTATS_hip_host_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),
     "FLAGSTATS_hip_host_free": (None, [ctypes.c_void_p]),
     "FLAGSTATS_hip_device_alloc": (ctypes.c_void_p, [ctypes.c_size_t]),

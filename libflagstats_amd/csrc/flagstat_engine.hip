@@ -359,7 +359,7 @@ int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t*
     int rc = ensure_ws(w, grid);
     if (rc) return rc;
     if (base == OP_POSPOPCNT) {
-        HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s));
+        HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s, (!(op & OP_HOST_OUT) && g_knobs.epilogue.load()) ? 1 : 0));
     } else {
         // accumulate into plain device memory: K1 alone, its workgroups add their totals to d_out with atomics
         const bool direct = base == OP_FLAGSTAT && !(op & OP_HOST_OUT) && g_knobs.epilogue.load() && !g_knobs.fuse.load();

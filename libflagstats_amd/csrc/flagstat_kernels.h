@@ -41,8 +41,9 @@ int fsk_variant_supported(int variant);   // K1 schedule compiled into this buil
 void fsk_set_anatomy(int bits);           // tuning builds only: skip parts of K1 to time the rest (results wrong)
 int fsk_tuning_build(void);               // 1: built with -DFLAGSTAT_TUNING_VARIANTS (make TUNING=1)
 // positional popcount (flagstat_pospopcnt.hip): d_out16[16] += bit counts.  d_partials as for fsk_launch.
+// direct != 0: the count kernel adds its workgroup totals to d_out16 with atomics (device memory only), no finalize launch.
 hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, uint32_t grid, uint64_t* d_partials,
-                                uint64_t* d_out16, hipStream_t stream);
+                                uint64_t* d_out16, hipStream_t stream, int direct);
 // read-only bandwidth probe (measurement only)
 hipError_t fsk_read_probe(const void* d_buf, uint64_t bytes, uint32_t grid, int nt, uint32_t* d_sink, hipStream_t stream);
 // on-device input makers (flagstat_generate.hip)

@@ -110,7 +110,7 @@ __device__ __forceinline__ void pos_step_and_count(PosLane& s, uint4 (&v)[kUnrol
 
 __global__ __launch_bounds__(kThreads) void pospopcnt_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                             uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
-                                                            uint64_t* __restrict__ partials)
+                                                            uint64_t* __restrict__ partials, uint64_t* __restrict__ out)
 {
     PosLane s;
     s.p1 = s.p2 = s.p4 = s.p8 = s.p16 = 0;
@@ -163,7 +163,12 @@ __global__ __launch_bounds__(kThreads) void pospopcnt_count(const uint4* __restr
         uint64_t sum = 0;
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) sum += red[w][threadIdx.x];
-        partials[static_cast<uint64_t>(threadIdx.x) * gridDim.x + blockIdx.x] = sum;  // [bit][block]
+        if (out) {
+            // direct epilogue, as K1's: this workgroup's 16 totals go to out[16] with relaxed atomics, no finalize launch
+            if (sum) (void)__hip_atomic_fetch_add(&out[threadIdx.x], sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            partials[static_cast<uint64_t>(threadIdx.x) * gridDim.x + blockIdx.x] = sum;  // [bit][block]
+        }
     }
 }
 
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(1024) void pospopcnt_finalize(const uint64_t* __res
 
 // d_out16[16] += positional popcounts of d_array[0..n).  Asynchronous.  d_partials: >= grid*19*8 bytes.
 extern "C" hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, uint32_t grid, uint64_t* d_partials,
-                                           uint64_t* d_out16, hipStream_t stream)
+                                           uint64_t* d_out16, hipStream_t stream, int direct)
 {
     if (n == 0) return hipSuccess;
     if (grid == 0 || d_array == nullptr || d_partials == nullptr || d_out16 == nullptr) return hipErrorInvalidValue;
@@ -198,9 +203,10 @@ extern "C" hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, 
     if (fast_end < fast_begin) fast_end = fast_begin;
     if (static_cast<uint64_t>(grid) > nsteps) grid = static_cast<uint32_t>(nsteps);
     hipLaunchKernelGGL(fsk::pospopcnt_count, dim3(grid), dim3(fsk::kThreads), 0, stream,
-                       reinterpret_cast<const uint4*>(base), lo, hi, nsteps, fast_begin, fast_end, d_partials);
+                       reinterpret_cast<const uint4*>(base), lo, hi, nsteps, fast_begin, fast_end, d_partials,
+                       direct ? d_out16 : nullptr);
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return e;
+    if (e != hipSuccess || direct) return e;
     hipLaunchKernelGGL(fsk::pospopcnt_finalize, dim3(1), dim3(1024), 0, stream, d_partials, grid, d_out16);
     return hipGetLastError();
 }

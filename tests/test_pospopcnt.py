@@ -35,11 +35,23 @@ def test_gpu_host_entry_matches_golden(hip):
 
 
 @pytest.mark.gpu
-def test_gpu_device_entry_large_and_ragged(hip):
+@pytest.mark.parametrize("epilogue", [1, 0])
+def test_gpu_device_entry_large_and_ragged(hip, epilogue):
+    """Both finalisation forms: the count kernel adding its workgroup totals to out[16] with atomics
+    (default) and partials + a finalize launch."""
     import torch
 
     import oracle
     from libflagstats_amd import device
+    old = hip.FLAGSTATS_hip_get(b"epilogue")
+    assert hip.FLAGSTATS_hip_set(b"epilogue", epilogue) == 0
+    try:
+        _device_entry_large_and_ragged(torch, oracle, device)
+    finally:
+        hip.FLAGSTATS_hip_set(b"epilogue", old)
+
+
+def _device_entry_large_and_ragged(torch, oracle, device):
     n = 300_000_007                                          # > one epoch per workgroup, ragged tail
     t = torch.empty(n + 8, dtype=torch.int16, device="cuda:0")
     device.generate_torch(t, device.GEN_UNIFORM, seed=77, mask=0xFFFF)
