@@ -196,6 +196,16 @@ typedef struct FLAGSTATS_blockfile_stats {
 int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads, uint64_t* out,
                                  FLAGSTATS_blockfile_stats* stats); /* same, file already in memory */
+/* Zstandard block files (.zst: benchmark/flagstats.cpp:192-226 writer, :636-682 reader): same block header,
+ * payload = one Zstandard frame.  libzstd stays the third-party dependency it is in the reference; it is
+ * resolved at run time (libzstd.so.1, or env FLAGSTATS_HIP_ZSTD_LIB) when a .zst file is opened, and the
+ * call fails loudly without it.  Same pipeline, threads and stats as the LZ4 entries. */
+int FLAGSTATS_hip_blockfile_zstd(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
+int FLAGSTATS_hip_blockimage_zstd(const void* image, uint64_t bytes, int threads, uint64_t* out,
+                                  FLAGSTATS_blockfile_stats* stats);
+int FLAGSTATS_hip_zstd_available(void);   /* 1 if libzstd could be loaded */
+/* codec by extension as the reference's check_file_extension (benchmark/flagstats.cpp:828-839): .lz4 | .zst */
+int FLAGSTATS_hip_blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 /* raw uint16 file (benchmark/flagstats.cpp:415-468, `-D`): mmap + FLAGSTATS_u16_x64 */
 int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 /* the host LZ4 *block* decoder used above (replaces the reference's call to liblz4's

@@ -35,6 +35,33 @@ def flagstat_lz4_image(image: bytes, threads: int = 0):
     return out, _stats(st)
 
 
+def flagstat_zstd_file(path: str, threads: int = 0):
+    """``.zst`` block file (``benchmark/flagstats.cpp:636-682``); needs libzstd.so.1 at run time."""
+    out = np.zeros(32, dtype=np.uint64)
+    st = _lib.BlockfileStats()
+    _lib.check(_lib.lib().FLAGSTATS_hip_blockfile_zstd(str(path).encode(), threads, out.ctypes.data, ctypes.byref(st)),
+               "FLAGSTATS_hip_blockfile_zstd")
+    return out, _stats(st)
+
+
+def flagstat_zstd_image(image: bytes, threads: int = 0):
+    out = np.zeros(32, dtype=np.uint64)
+    st = _lib.BlockfileStats()
+    buf = (ctypes.c_char * len(image)).from_buffer_copy(image) if image else None
+    _lib.check(_lib.lib().FLAGSTATS_hip_blockimage_zstd(buf, len(image), threads, out.ctypes.data, ctypes.byref(st)),
+               "FLAGSTATS_hip_blockimage_zstd")
+    return out, _stats(st)
+
+
+def flagstat_file(path: str, threads: int = 0):
+    """Codec by extension (``.lz4`` / ``.zst``), as the reference's ``check_file_extension`` (``:828-839``)."""
+    out = np.zeros(32, dtype=np.uint64)
+    st = _lib.BlockfileStats()
+    _lib.check(_lib.lib().FLAGSTATS_hip_blockfile(str(path).encode(), threads, out.ctypes.data, ctypes.byref(st)),
+               "FLAGSTATS_hip_blockfile")
+    return out, _stats(st)
+
+
 def flagstat_raw_file(path: str):
     out = np.zeros(32, dtype=np.uint64)
     st = _lib.BlockfileStats()

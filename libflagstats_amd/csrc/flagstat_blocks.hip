@@ -18,6 +18,7 @@
 // LZ4 *block* format (token = 4 bits literal length | 4 bits match length - 4, 255-continued
 // length bytes, 2-byte little-endian offset, last sequence literals-only) and is checked in
 // tests/ against the image's liblz4.so.1 (1.9.3) acting as oracle.
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <pthread.h>
 #include <sched.h>
@@ -26,6 +27,7 @@
 #include <unistd.h>
 
 #include <atomic>
+#include <mutex>
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
@@ -41,6 +43,52 @@
 namespace {
 
 using fslz4::lz4_block_decode;
+
+// ---------------------------------------------------------------- block codecs
+// The reference's bench writes the same int32,int32 block header around raw LZ4 blocks (.lz4) or Zstandard
+// frames (.zst; benchmark/flagstats.cpp:192-226 writer, :636-682 reader calling ZSTD_decompress).  LZ4 is
+// decoded by this library's own decoder.  Zstandard is the reference's third-party dependency (libzstd,
+// found at build time via ZSTD_PATH, Makefile:28-39) and stays one here: libzstd.so.1 is resolved at run
+// time, only when a .zst file is actually opened (as RCCL is in flagstat_multi.hip); without it the call
+// fails loudly -- there is no second decoder to fall back to.
+typedef int64_t (*block_decode_fn)(const uint8_t* src, size_t n, uint8_t* dst, size_t cap);
+
+struct ZstdApi {
+    void* handle = nullptr;
+    size_t (*decompress)(void*, size_t, const void*, size_t) = nullptr;
+    unsigned (*is_error)(size_t) = nullptr;
+};
+ZstdApi g_zstd;
+std::once_flag g_zstd_once;
+char g_zstd_why[256] = {0};
+
+bool zstd_load()
+{
+    std::call_once(g_zstd_once, [] {
+        const char* env = std::getenv("FLAGSTATS_HIP_ZSTD_LIB");
+        const char* names[] = {env && *env ? env : nullptr, "libzstd.so.1", "libzstd.so"};
+        for (const char* nm : names) {
+            if (!nm) continue;
+            g_zstd.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+            if (g_zstd.handle) break;
+        }
+        if (!g_zstd.handle) {
+            std::snprintf(g_zstd_why, sizeof g_zstd_why, "cannot load libzstd.so.1 (needed for .zst block files): %s", dlerror());
+            return;
+        }
+        g_zstd.decompress = reinterpret_cast<decltype(g_zstd.decompress)>(dlsym(g_zstd.handle, "ZSTD_decompress"));
+        g_zstd.is_error = reinterpret_cast<decltype(g_zstd.is_error)>(dlsym(g_zstd.handle, "ZSTD_isError"));
+        if (!g_zstd.decompress || !g_zstd.is_error)
+            std::snprintf(g_zstd_why, sizeof g_zstd_why, "libzstd lacks ZSTD_decompress / ZSTD_isError");
+    });
+    return g_zstd.decompress && g_zstd.is_error;
+}
+
+int64_t zstd_block_decode(const uint8_t* src, size_t n, uint8_t* dst, size_t cap)
+{
+    const size_t r = g_zstd.decompress(dst, cap, src, n);
+    return g_zstd.is_error(r) ? -1 : static_cast<int64_t>(r);
+}
 
 struct BlockRef {
     const uint8_t* src;   // payload in memory (image mode) or nullptr (file mode: pread at file_off)
@@ -166,7 +214,7 @@ constexpr int kPinned = 3;
 // makes all decode threads fault on one address space; the contention grows with the thread
 // count and was measured to cost more than the extra copy.)
 int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, int threads, uint64_t* out,
-                 FLAGSTATS_blockfile_stats* st, const uint8_t* map = nullptr)
+                 FLAGSTATS_blockfile_stats* st, const uint8_t* map = nullptr, block_decode_fn decode = lz4_block_decode)
 {
     const double t0 = now_s();
     uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
@@ -270,7 +318,7 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
                     }
                     src = local.data();
                 }
-                const int64_t got = lz4_block_decode(src, br.csize, dst, br.usize);
+                const int64_t got = decode(src, br.csize, dst, br.usize);
                 if (got != static_cast<int64_t>(br.usize)) {
                     bad = true;
                     break;
@@ -313,7 +361,7 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
             std::unique_lock<std::mutex> ul(pipe.m);
             pipe.cv_main.wait(ul, [&] { return pipe.done[c] == chunks[c].b1 - chunks[c].b0 || pipe.failed; });
             if (pipe.failed) {
-                err = fsint::fail_text("block file: LZ4 block failed to decode to its declared size");
+                err = fsint::fail_text("block file: a block failed to decode to its declared size");
                 break;
             }
             wait_decode += now_s() - w0;
@@ -424,21 +472,40 @@ int64_t FLAGSTATS_lz4_block_decode(const void* src, uint64_t srclen, void* dst, 
     return lz4_block_decode(static_cast<const uint8_t*>(src), srclen, static_cast<uint8_t*>(dst), dstcap);
 }
 
-int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads, uint64_t* out,
-                                 FLAGSTATS_blockfile_stats* stats)
+}  // extern "C"
+
+namespace {
+
+// codec: 0 = raw LZ4 blocks, 1 = Zstandard frames
+int pick_decoder(int codec, block_decode_fn* fn)
+{
+    if (codec == 0) {
+        *fn = lz4_block_decode;
+        return 0;
+    }
+    if (!zstd_load()) return fsint::fail_text(g_zstd_why[0] ? g_zstd_why : "libzstd is not available");
+    *fn = zstd_block_decode;
+    return 0;
+}
+
+int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec)
 {
     if (!out) return fsint::fail_text("NULL out");
     if (!image && bytes) return fsint::fail_text("NULL image");
+    block_decode_fn fn = nullptr;
+    if (int rc = pick_decoder(codec, &fn)) return rc;
     static const uint8_t empty = 0;
     fsint::Engine* eng = fsint::default_engine();
     if (!eng) return -1;
-    return run_pipeline(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, out, stats);
+    return run_pipeline(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, out, stats, nullptr, fn);
 }
 
-int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec)
 {
     if (!out) return fsint::fail_text("NULL out");
     if (!path) return fsint::fail_text("NULL path");
+    block_decode_fn fn = nullptr;
+    if (int rc = pick_decoder(codec, &fn)) return rc;
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fsint::fail_text("cannot open file");
     struct stat sb;
@@ -458,12 +525,51 @@ int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FL
     if (bytes && io && !std::strcmp(io, "mmap")) map = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
     fsint::Engine* eng = fsint::default_engine();
     const int rc = eng ? run_pipeline(*eng, nullptr, fd, bytes, threads, out, stats,
-                                      map == MAP_FAILED ? nullptr : static_cast<const uint8_t*>(map))
+                                      map == MAP_FAILED ? nullptr : static_cast<const uint8_t*>(map), fn)
                        : -1;
     if (map != MAP_FAILED) munmap(map, bytes);
     close(fd);
     return rc;
 }
+
+}  // namespace
+
+extern "C" {
+
+int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads, uint64_t* out,
+                                 FLAGSTATS_blockfile_stats* stats)
+{
+    return blockimage(image, bytes, threads, out, stats, 0);
+}
+
+int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    return blockfile(path, threads, out, stats, 0);
+}
+
+int FLAGSTATS_hip_blockimage_zstd(const void* image, uint64_t bytes, int threads, uint64_t* out,
+                                  FLAGSTATS_blockfile_stats* stats)
+{
+    return blockimage(image, bytes, threads, out, stats, 1);
+}
+
+int FLAGSTATS_hip_blockfile_zstd(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    return blockfile(path, threads, out, stats, 1);
+}
+
+// codec by file extension, as the reference's check_file_extension (benchmark/flagstats.cpp:828-839):
+// ".zst" -> Zstandard, ".lz4" -> LZ4; anything else is refused (the reference prints and exits).
+int FLAGSTATS_hip_blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    if (!path) return fsint::fail_text("NULL path");
+    const char* dot = std::strrchr(path, '.');
+    if (dot && !std::strcmp(dot + 1, "zst")) return blockfile(path, threads, out, stats, 1);
+    if (dot && !std::strcmp(dot + 1, "lz4")) return blockfile(path, threads, out, stats, 0);
+    return fsint::fail_text("block file: unknown extension (expected .lz4 or .zst)");
+}
+
+int FLAGSTATS_hip_zstd_available(void) { return zstd_load() ? 1 : 0; }
 
 int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
 {

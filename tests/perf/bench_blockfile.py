@@ -57,7 +57,7 @@ def main():
     with ThreadPoolExecutor(max_workers=min(64, os.cpu_count() or 1)) as ex:
         parts = list(ex.map(make, range(nblocks)))
     d = args.dir or tempfile.mkdtemp(prefix="fsblk_", dir="/tmp")
-    path = os.path.join(d, "na12878_%s%d.lz4" % (args.mode, args.level))
+    path = os.path.join(d, "na12878_%s%d.%s" % (args.mode, args.level, "zst" if args.mode == "zstd" else "lz4"))
     with open(path, "wb") as f:
         for p in parts:
             f.write(p)
@@ -75,12 +75,12 @@ def main():
         for rep in range(3):
             t0 = time.perf_counter()
             if mode == "file":
-                got, st = blockfile.flagstat_lz4_file(path, th)
+                got, st = blockfile.flagstat_file(path, th)          # codec from the extension
             else:
                 got = np.zeros(32, dtype=np.uint64)
                 stc = _lib.BlockfileStats()
-                _lib.check(lib.FLAGSTATS_hip_blockimage_lz4(image.ctypes.data, image.size, th, got.ctypes.data, ctypes.byref(stc)),
-                           "FLAGSTATS_hip_blockimage_lz4")
+                entry = lib.FLAGSTATS_hip_blockimage_zstd if args.mode == "zstd" else lib.FLAGSTATS_hip_blockimage_lz4
+                _lib.check(entry(image.ctypes.data, image.size, th, got.ctypes.data, ctypes.byref(stc)), "FLAGSTATS_hip_blockimage")
                 st = {name: getattr(stc, name) for name, _ in stc._fields_}
             dt = time.perf_counter() - t0
             assert np.array_equal(got, want), "PARITY"
@@ -92,7 +92,7 @@ def main():
                      "decode_GB_s_per_thread": round(2 * n / max(st["decode_cpu_s"], 1e-9) / 1e9, 2)})
         print(rows[-1], flush=True)
 
-    if args.no_serial:
+    if args.no_serial or args.mode == "zstd":
         print(json.dumps({"workload": "%d NA12878-like flags, %d-byte LZ4-%s-%d blocks" % (n, bt.BLOCK_BYTES, args.mode, args.level),
                           "file_bytes": size, "product": rows}))
         os.remove(path)

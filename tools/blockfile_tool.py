@@ -38,7 +38,35 @@ def lz4():
     return _lz4
 
 
+_zstd = None
+
+
+def zstd():
+    """The image's libzstd.so.1 (what benchmark/flagstats.cpp:85-93 calls): ZSTD_compress / ZSTD_decompress."""
+    global _zstd
+    if _zstd is None:
+        lib = ctypes.CDLL(ctypes.util.find_library("zstd") or "libzstd.so.1")
+        lib.ZSTD_compressBound.restype = ctypes.c_size_t
+        lib.ZSTD_compressBound.argtypes = [ctypes.c_size_t]
+        lib.ZSTD_compress.restype = ctypes.c_size_t
+        lib.ZSTD_compress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        lib.ZSTD_decompress.restype = ctypes.c_size_t
+        lib.ZSTD_decompress.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+        lib.ZSTD_isError.restype = ctypes.c_uint
+        lib.ZSTD_isError.argtypes = [ctypes.c_size_t]
+        _zstd = lib
+    return _zstd
+
+
 def compress_block(raw: bytes, mode: str = "fast", level: int = 2) -> bytes:
+    if mode == "zstd":
+        z = zstd()
+        bound = z.ZSTD_compressBound(len(raw))
+        dst = ctypes.create_string_buffer(max(bound, 1))
+        n = z.ZSTD_compress(dst, bound, raw, len(raw), level)             # benchmark/flagstats.cpp:86
+        if z.ZSTD_isError(n):
+            raise RuntimeError("libzstd compression failed")
+        return dst.raw[:n]
     lib = lz4()
     bound = lib.LZ4_compressBound(len(raw))
     dst = ctypes.create_string_buffer(max(bound, 1))
