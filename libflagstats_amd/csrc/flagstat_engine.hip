@@ -342,6 +342,11 @@ int ensure_ws(Workspace& w, uint32_t grid)
     w.grid_cap = 0;
     HIP_TRY(hipMalloc(&w.partials, fsk_partials_bytes(grid)));
     HIP_TRY(hipMemset(w.partials, 0, fsk_partials_bytes(grid)));  // the ticket word must start at 0
+    // hipMemset on device memory runs on the NULL stream and may return before it has run; the engines'
+    // streams are non-blocking (they do not order against the NULL stream), so without this wait the
+    // memset could land AFTER the first K1 had stored its partials -- whole 4 KiB pages of them read back
+    // as zero by K2 (seen once in tests/test_gpu_multi.py on a freshly created engine).
+    HIP_TRY(hipDeviceSynchronize());
     w.grid_cap = grid;
     return 0;
 }

@@ -92,6 +92,8 @@ FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void)
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_out[i]), 32 * sizeof(uint64_t));
         if (e == hipSuccess) e = hipMemset(s->d_out[i], 0, 32 * sizeof(uint64_t));
     }
+    // the memsets ran on the NULL stream, which the session's non-blocking streams do not order against
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s->h_out), 2 * 32 * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         fsint::fail_hip("FLAGSTATS_hip_stream_open", e);
