@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- flagstat hot path on N MI355X of one node.
 
-One "step" = one pass of the hot path (K1 flagstat_count + K2 flagstat_finalize, plus the
-32-counter all-reduce when N > 1) over this rank's device-resident FLAG shard.  Workload = the
+One "step" = one pass of the hot path over this rank's device-resident FLAG shard: N = 1: ONE launch of
+K1 flagstat_count, whose workgroups add their totals to the 32 counters themselves (the ABI's +=
+contract); N > 1: K1 + K2 flagstat_finalize in store form (one query per step) + the 32-counter all-reduce.  Workload = the
 configuration BASELINE.json's metric is quoted on: 8 GiB of uniform-random uint16 (2^32 flags) per
 GPU, generated on device by the library's counter-based generator (data: synthetic).  N > 1 is weak
 scaling: every rank holds its own 8 GiB shard (seed + rank), 64 GiB at N = 8 (BASELINE config 3);
@@ -312,7 +313,7 @@ def main():
     def step():
         # N = 1: counters accumulate across steps (the ABI's += contract, as the reference's
         # bench accumulates across blocks, benchmark/flagstats.cpp:304,328-329), so a step is
-        # exactly K1 + K2.  N > 1: a step is one whole query: count (K2 stores), all-reduce of the
+        # exactly one K1 launch (its workgroups add their totals to the counters).  N > 1: a step is one whole query: count (K2 stores), all-reduce of the
         # 32 counters.  The all-reduce of query i runs on a side stream while K1 of query i+1 streams
         # its shard (two counter buffers), so the collective's latency is off the critical path;
         # every query's all-reduce still completes inside the timed region (drain() below).
@@ -431,9 +432,11 @@ def main():
             "metric": METRIC, "value": round(value, 3), "unit": "Gflags/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
             "scaling": "strong" if args.strong else "weak", "vs_baseline": None, "dtype": "u16", "data": "synthetic",
-            "config": {"workload": "%.3g GiB uniform-random uint16 FLAG array (%d flags) per GPU, device-resident, "
-                                   "K1 flagstat_count + K2 flagstat_finalize%s"
-                                   % (n * 2 / 2 ** 30, n, " + RCCL all-reduce uint64[32]" if world > 1 else ""),
+            "config": {"workload": "%.3g GiB uniform-random uint16 FLAG array (%d flags) per GPU, device-resident, %s"
+                                   % (n * 2 / 2 ** 30, n,
+                                      "K1 flagstat_count + K2 flagstat_finalize (store form) + RCCL all-reduce uint64[32]" if multi
+                                      else ("K1 flagstat_count accumulating into the 32 counters (atomic epilogue, one launch)"
+                                            if lib.FLAGSTATS_hip_get(b"epilogue") else "K1 flagstat_count + K2 flagstat_finalize")),
                        "flags_per_gpu": n, "global_flags": total_flags, "parallelism": "shard%d" % world,
                        "allreduce": ("overlapped" if overlap else "in-line") if multi else None,
                        "allreduce_impl": ar_impl,
