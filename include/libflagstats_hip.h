@@ -71,7 +71,8 @@ int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out);
 
 /* DEVICE-resident array (any 2-byte alignment), DEVICE counters:
  * d_out[32] (uint64, device memory) += counters, asynchronously on `stream`
- * (a hipStream_t passed as void*; NULL = HIP's null stream, as in every HIP API). */
+ * (a hipStream_t passed as void*; NULL = HIP's null stream, as in every HIP API).
+ * One kernel launch; the adds are atomic, so launches on several streams may share d_out. */
 int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream);
 
 /* same, but d_out[32] = counters (all 32 slots written, never-written slots as 0): one query per
@@ -135,12 +136,16 @@ int FLAGSTATS_hip_comm_destroy(void* comm);
 int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* stream);
 int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream);
 
-/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _CHUNK_FLAGS / _ON_ERROR / _NUMA).  key =
+/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _EPILOGUE / _CHUNK_FLAGS / _ON_ERROR / _NUMA).  key =
  *   "blocks_per_cu"  workgroups per CU of K1's grid (default 1)
  *   "variant"        K1 schedule: bit0 non-temporal loads, bit1 chain depth 7, bit2 register
  *                    prefetch, bit3 interleaved waves, bit4 rolling re-issue, bit5 LDS-DMA ring, bit6
  *                    rolling at distance 2 (default 25; shipped: 9 and 25; the others only in a `make TUNING=1` build)
- *   "fuse"           0 = K1 + K2 (default); 1 = K1 finalises itself, one kernel per call
+ *   "epilogue"       accumulate (+=) forms into device memory: 1 (default) = K1's workgroups add their totals to the
+ *                    counters with atomics, ONE launch per call, any number of streams may share a counter array;
+ *                    0 = partials + K2 (then one counter array must be targeted from one stream at a time).
+ *                    The store forms and counters in pinned host memory always use K2.
+ *   "fuse"           K2 forms only: 0 = K1 + K2 (default); 1 = the last-arriving workgroup of K1 finalises
  *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB)
  *   "on_error"       reference-shaped entry points on failure: 1 abort() after the message (default), 0 return non-zero
  *   "numa"           1 (default): pinned buffers and block-decoder threads are placed on the GPU's host NUMA node
