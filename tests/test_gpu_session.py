@@ -74,3 +74,62 @@ def test_reference_shaped_reader_loop(hip):
             pos += cs
         got = s.finish()
     assert np.array_equal(got, oracle.flagstat_hist(flags))
+
+
+def test_sessions_of_different_threads_overlap(hip):
+    """Sessions own their streams, buffers and lock (no library-wide mutex on the data path): caller
+    threads with a session each -- and a third thread making plain host-pointer calls meanwhile -- run
+    concurrently and every one gets exactly its own counters.  ctypes drops the GIL inside the calls, so
+    the threads really are inside the library at the same time; overlap is asserted on the intervals the
+    threads spent inside it, not on wall-clock ratios."""
+    import threading
+    import time
+
+    import oracle
+    from libflagstats_amd import pyflagstats
+    from libflagstats_amd.session import StreamSession
+    blocks = [oracle.generate(oracle.GEN_NA12878, 100 + k, 1, 0, 512000) for k in range(6)]
+    want_block = [oracle.flagstat_hist(b) for b in blocks]
+    rounds = 40
+    results, spans, errors = {}, {}, []
+    start = threading.Barrier(3)
+
+    def session_worker(tid):
+        try:
+            with StreamSession() as s:
+                start.wait()
+                t0 = time.perf_counter()
+                for r in range(rounds):
+                    s.push(blocks[(tid + r) % len(blocks)])
+                results[tid] = s.finish()
+                spans[tid] = (t0, time.perf_counter())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    def host_call_worker():
+        try:
+            start.wait()
+            t0 = time.perf_counter()
+            acc = np.zeros(32, dtype=np.uint64)
+            for r in range(rounds):
+                acc += pyflagstats.counters_u32(blocks[r % len(blocks)]).astype(np.uint64)
+            results["host"] = acc
+            spans["host"] = (t0, time.perf_counter())
+        except Exception as e:  # noqa: BLE001
+            errors.append(e)
+
+    ths = [threading.Thread(target=session_worker, args=(0,)), threading.Thread(target=session_worker, args=(1,)),
+           threading.Thread(target=host_call_worker)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    assert not errors, errors
+    for tid in (0, 1):
+        want = sum((want_block[(tid + r) % len(blocks)] for r in range(rounds)), np.zeros(32, dtype=np.uint64))
+        assert np.array_equal(results[tid], want), tid
+    want = sum((want_block[r % len(blocks)] for r in range(rounds)), np.zeros(32, dtype=np.uint64))
+    assert np.array_equal(results["host"], want)
+    # the two sessions' busy intervals intersect (a library-wide lock would have run them one after the other)
+    (a0, a1), (b0, b1) = spans[0], spans[1]
+    assert min(a1, b1) > max(a0, b0), spans
