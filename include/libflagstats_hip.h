@@ -145,7 +145,7 @@ int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint
  *                    counters with atomics, ONE launch per call, any number of streams may share a counter array;
  *                    0 = partials + K2 (then one counter array must be targeted from one stream at a time).
  *                    The store forms and counters in pinned host memory always use K2.
- *   "fuse"           K2 forms only: 0 = K1 + K2 (default); 1 = the last-arriving workgroup of K1 finalises
+ *   "fuse"           tuning build only (the r01 experiment that lost): 1 = the last-arriving workgroup of K1 finalises
  *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB)
  *   "on_error"       reference-shaped entry points on failure: 1 abort() after the message (default), 0 return non-zero
  *   "numa"           1 (default): pinned buffers and block-decoder threads are placed on the GPU's host NUMA node

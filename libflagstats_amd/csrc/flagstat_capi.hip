@@ -147,6 +147,8 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         k.variant = static_cast<int>(value);
     } else if (!std::strcmp(key, "fuse")) {
         if (value > 1) return fail_text("fuse must be 0 or 1");
+        if (value && !fsk_tuning_build())
+            return fail_text("the ticket-fused finalise lost to K1 + K2 and to the atomic epilogue; it is carried by the tuning build only (make TUNING=1)");
         k.fuse = static_cast<int>(value);
     } else if (!std::strcmp(key, "anatomy")) {
         if (!fsk_tuning_build()) return fail_text("anatomy is a tuning-build knob (make TUNING=1)");

@@ -42,7 +42,7 @@ void read_env_knobs()
         g_knobs.blocks_per_cu = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_BLOCKS_PER_CU", g_knobs.blocks_per_cu));
         g_knobs.variant = static_cast<int>(env_u64("FLAGSTATS_HIP_VARIANT", static_cast<uint64_t>(g_knobs.variant)));
         g_knobs.chunk_flags = env_u64("FLAGSTATS_HIP_CHUNK_FLAGS", g_knobs.chunk_flags);
-        g_knobs.fuse = static_cast<int>(env_u64("FLAGSTATS_HIP_FUSE", static_cast<uint64_t>(g_knobs.fuse)));
+        g_knobs.fuse = fsk_tuning_build() ? static_cast<int>(env_u64("FLAGSTATS_HIP_FUSE", static_cast<uint64_t>(g_knobs.fuse))) : 0;
         g_knobs.epilogue = static_cast<int>(env_u64("FLAGSTATS_HIP_EPILOGUE", static_cast<uint64_t>(g_knobs.epilogue)));
         g_knobs.numa = static_cast<int>(env_u64("FLAGSTATS_HIP_NUMA", static_cast<uint64_t>(g_knobs.numa)));
         const char* oe = std::getenv("FLAGSTATS_HIP_ON_ERROR");

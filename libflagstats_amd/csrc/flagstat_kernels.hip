@@ -550,13 +550,15 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
         __hip_atomic_store(&partials[static_cast<uint64_t>(threadIdx.x) * gridDim.x + blockIdx.x], sum, __ATOMIC_RELAXED,
                            __HIP_MEMORY_SCOPE_AGENT);
     }
+#ifdef FLAGSTAT_TUNING_VARIANTS
     if (ticket == nullptr) return;  // two-kernel form: K2 (flagstat_finalize) sums the partials
 
-    // Fused form ("one HIP kernel", BASELINE config 1): the workgroup that draws the last ticket
-    // finalises.  Hand-off per the CDNA guide's counter recipe: every storing wave drains its
-    // stores, workgroup barrier, ONE lane: agent-scope release -> drain -> relaxed agent ticket add;
-    // the last arriver: agent-scope acquire -> drain -> barrier -> sc1 (atomic) loads of the partials.
-    // Correct for any placement of workgroups on XCDs; `ticket` is zero before the first launch
+    // Fused form through a last-arriver ticket (r01; measured slower than K1 + K2 at every size,
+    // profiles/r01/fuse_ab.log, and superseded by the fence-free direct epilogue above; kept in the tuning
+    // build as evidence): the workgroup that draws the last ticket finalises.  Hand-off per the CDNA
+    // guide's counter recipe: every storing wave drains its stores, workgroup barrier, ONE lane:
+    // agent-scope release -> drain -> relaxed agent ticket add; the last arriver: agent-scope acquire ->
+    // drain -> barrier -> sc1 (atomic) loads of the partials.  `ticket` is zero before the first launch
     // and reset here for the next one (launches sharing a workspace are stream-ordered).
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __shared__ uint32_t is_last;
@@ -586,6 +588,9 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
     __syncthreads();
     finalize_slots(tot, out, mode, hi - lo);
     if (threadIdx.x == 0) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    (void)ticket;  // two-kernel form: K2 (flagstat_finalize) sums the partials
+#endif
 }
 
 // ------------------------------------------------------------------ read probe
@@ -684,6 +689,9 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
 #ifdef FLAGSTAT_TUNING_VARIANTS
     a.mode |= (g_anatomy & 6) << 8;
     if (g_anatomy & 1) a.nsteps = a.fast_begin = a.fast_end = 0;  // no steps at all: launch + epilogue only
+#endif
+#ifndef FLAGSTAT_TUNING_VARIANTS
+    if ((variant >> 9) & 1) return hipErrorInvalidValue;  // the ticket-fused finalise exists in the tuning build only
 #endif
     a.ticket = ((variant >> 9) & 1) ? d_ticket : nullptr;  // bit 9: fused finalise inside K1
     a.out = d_out32;

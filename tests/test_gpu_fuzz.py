@@ -15,7 +15,8 @@ def test_random_lengths_offsets_geometries(hip):
     old_v, old_b = hip.FLAGSTATS_hip_get(b"variant"), hip.FLAGSTATS_hip_get(b"blocks_per_cu")
     old_f, old_e = hip.FLAGSTATS_hip_get(b"fuse"), hip.FLAGSTATS_hip_get(b"epilogue")
     # the shipped library carries the default schedule and the plain loop; a tuning build (make TUNING=1) all of them
-    variants = [9, 25] + ([0, 1, 13, 27, 41, 89] if hip.FLAGSTATS_hip_get(b"tuning_build") else [])
+    tuning = bool(hip.FLAGSTATS_hip_get(b"tuning_build"))
+    variants = [9, 25] + ([0, 1, 13, 27, 41, 89] if tuning else [])
     try:
         for it in range(150):
             kind = int(rs.randint(0, 3))
@@ -36,7 +37,9 @@ def test_random_lengths_offsets_geometries(hip):
             off = int(rs.randint(0, 32))
             _lib.check(hip.FLAGSTATS_hip_set(b"variant", int(rs.choice(variants))), "variant")
             _lib.check(hip.FLAGSTATS_hip_set(b"blocks_per_cu", int(rs.choice([1, 2, 3]))), "bpc")
-            _lib.check(hip.FLAGSTATS_hip_set(b"fuse", int(rs.randint(0, 2))), "fuse")  # K1+K2 or K1 finalising itself
+            fuse = int(rs.randint(0, 2))                     # drawn in every build so the case sequence is the same
+            if tuning:
+                _lib.check(hip.FLAGSTATS_hip_set(b"fuse", fuse), "fuse")  # K1+K2 or the ticket-fused K1 (tuning build only)
             _lib.check(hip.FLAGSTATS_hip_set(b"epilogue", int(rs.randint(0, 2))), "epilogue")  # atomic adds from K1 or K2
             buf.generate(kind, seed=seed, mask=mask, first_index=first, offset=off, n=n)
             got = buf.count(offset=off, n=n)
@@ -69,17 +72,24 @@ def test_values_concentrated_on_single_categories(hip):
     buf.free()
 
 
-@pytest.mark.parametrize("fuse", [0, 1])
-def test_back_to_back_launches_same_workspace(hip, fuse):
-    """Many launches of very different sizes on one stream and one workspace: with fuse=1 the
-    last-arriving workgroup finalises and re-arms the ticket for the next launch; the accumulated
-    device counters must equal the sum of the oracle's, and a final store-form call must overwrite."""
+@pytest.mark.parametrize("form", ["atomic", "k2", "ticket"])
+def test_back_to_back_launches_same_workspace(hip, form):
+    """Many launches of very different sizes on one stream and one workspace, no host sync between them,
+    in every finalisation form: K1's atomic epilogue (default), partials + K2, and -- tuning build only --
+    the r01 ticket form, whose last-arriving workgroup finalises and re-arms the ticket for the next
+    launch.  The accumulated device counters must equal the sum of the oracle's, and a final store-form
+    call must overwrite."""
     import torch
 
     import oracle
     from libflagstats_amd import _lib, device
+    if form == "ticket" and not hip.FLAGSTATS_hip_get(b"tuning_build"):
+        assert hip.FLAGSTATS_hip_set(b"fuse", 1) != 0 and b"TUNING=1" in hip.FLAGSTATS_hip_last_error()
+        return
     old = hip.FLAGSTATS_hip_get(b"fuse")
-    _lib.check(hip.FLAGSTATS_hip_set(b"fuse", fuse), "fuse")
+    old_e = hip.FLAGSTATS_hip_get(b"epilogue")
+    _lib.check(hip.FLAGSTATS_hip_set(b"fuse", 1 if form == "ticket" else 0), "fuse")
+    _lib.check(hip.FLAGSTATS_hip_set(b"epilogue", 1 if form == "atomic" else 0), "epilogue")
     try:
         n = 50_000_000
         t = torch.empty(n, dtype=torch.int16, device="cuda:0")
@@ -101,3 +111,4 @@ def test_back_to_back_launches_same_workspace(hip, fuse):
         assert np.array_equal(out.cpu().numpy().view(np.uint64), oracle.flagstat_hist(host[5:1005]))
     finally:
         hip.FLAGSTATS_hip_set(b"fuse", old)
+        hip.FLAGSTATS_hip_set(b"epilogue", old_e)
