@@ -72,7 +72,9 @@ int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out);
 /* DEVICE-resident array (any 2-byte alignment), DEVICE counters:
  * d_out[32] (uint64, device memory) += counters, asynchronously on `stream`
  * (a hipStream_t passed as void*; NULL = HIP's null stream, as in every HIP API).
- * One kernel launch; the adds are atomic, so launches on several streams may share d_out. */
+ * One kernel launch; the adds are atomic, so launches on several streams may share d_out.
+ * d_array may also be pinned host memory (FLAGSTATS_hip_host_alloc / hipHostMalloc): it is then read in
+ * place over PCIe, with no staging copy. */
 int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream);
 
 /* same, but d_out[32] = counters (all 32 slots written, never-written slots as 0): one query per

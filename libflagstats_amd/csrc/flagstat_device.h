@@ -31,6 +31,7 @@ __device__ __forceinline__ uint32_t hstep(uint32_t acc, uint32_t plane, uint32_t
 // swaps, half-row and row mirrors, then the two row broadcasts), no LDS round trips: the
 // ds_bpermute butterfly __shfl_xor compiles to waits out the LDS latency at every one of its
 // 6 x 21 steps, which was 2.5 us of every launch (profiles/r02/launch_anatomy.log).
+// Every lane of the wave must be active (the kernels call it outside any divergent region).
 __device__ __forceinline__ uint32_t wave_sum_lane63(uint32_t x)
 {
     x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]

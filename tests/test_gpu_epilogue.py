@@ -119,3 +119,28 @@ def test_pinned_host_counters_use_k2(hip, knob):
     finally:
         hip.FLAGSTATS_hip_host_free(hp)
         d.free()
+
+
+def test_flag_array_in_pinned_host_memory_is_read_in_place(hip, knob):
+    """Zero-copy: a FLAG array that lives in pinned host memory (FLAGSTATS_hip_host_alloc) may be handed
+    to the DEVICE-array entry; K1 then streams it over PCIe straight from host memory (no staging copy),
+    with device counters and the default epilogue."""
+    import torch
+
+    import oracle
+    from libflagstats_amd import _lib
+    assert knob(1) == 0
+    n = 3_000_001
+    hp = hip.FLAGSTATS_hip_host_alloc(2 * n)
+    assert hp
+    try:
+        host = np.ctypeslib.as_array(ctypes.cast(hp, ctypes.POINTER(ctypes.c_uint16)), shape=(n,))
+        host[:] = oracle.generate(oracle.GEN_UNIFORM, 8, 0xFFFF, 0, n)
+        out = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+        torch.cuda.synchronize()
+        stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+        _lib.check(hip.FLAGSTATS_hip_device_u16(hp + 2, n - 1, out.data_ptr(), stream), "device_u16(pinned host array)")
+        torch.cuda.synchronize()
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), oracle.flagstat_hist(host[1:]))
+    finally:
+        hip.FLAGSTATS_hip_host_free(hp)
