@@ -178,13 +178,17 @@ inline void fast_loops(State& s, const uint8_t* const ifast, uint8_t* const ofas
                 ip += 3 + lit;
                 short_match<kLoopBWide>(op, off, mln + 4);
                 op += mln + 4;
-                bare += (tok < 0x0Fu);
-                if (++seqs == 512) {
-                    if (may_pair && bare > 460) {  // > 90 % bare matches: loop A territory
-                        swap = true;
-                        break;
+                if (CHECKED) {
+                    // which loop suits the stream is judged while the first 64 KiB of the block are
+                    // produced (the checked phase); the long unchecked phase then carries no accounting
+                    bare += (tok < 0x0Fu);
+                    if (++seqs >= 512) {
+                        if (may_pair && bare > seqs - seqs / 10) {  // > 90 % bare matches: loop A territory
+                            swap = true;
+                            break;
+                        }
+                        seqs = bare = 0;
                     }
-                    seqs = bare = 0;
                 }
             }
             s.seqs = seqs;
