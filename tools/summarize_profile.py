@@ -27,8 +27,9 @@ def kernel_source_id():
 
 
 def find(src, sub, pattern):
+    # gpurun merges every call's outputs into the same local directory: take the NEWEST match, not the first
     hits = glob.glob(os.path.join(src, sub, "**", pattern), recursive=True)
-    return hits[0] if hits else None
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 def main():
