@@ -213,7 +213,8 @@ int FLAGSTATS_hip_blockimage_zstd(const void* image, uint64_t bytes, int threads
 int FLAGSTATS_hip_zstd_available(void);   /* 1 if libzstd could be loaded */
 /* codec by extension as the reference's check_file_extension (benchmark/flagstats.cpp:828-839): .lz4 | .zst */
 int FLAGSTATS_hip_blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
-/* raw uint16 file (benchmark/flagstats.cpp:415-468, `-D`): mmap + FLAGSTATS_u16_x64 */
+/* raw uint16 file (benchmark/flagstats.cpp:415-468, `-D`): the same threaded pipeline without a codec -- workers
+ * pread 1 MiB slices straight into the pinned chunks (env FLAGSTATS_HIP_RAW_IO=mmap: mmap + FLAGSTATS_u16_x64) */
 int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 /* the host LZ4 *block* decoder used above (replaces the reference's call to liblz4's
  * LZ4_decompress_safe, benchmark/flagstats.cpp:316): returns decoded bytes, < 0 on malformed input */

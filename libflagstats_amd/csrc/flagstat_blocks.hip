@@ -214,7 +214,8 @@ constexpr int kPinned = 3;
 // makes all decode threads fault on one address space; the contention grows with the thread
 // count and was measured to cost more than the extra copy.)
 int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, int threads, uint64_t* out,
-                 FLAGSTATS_blockfile_stats* st, const uint8_t* map = nullptr, block_decode_fn decode = lz4_block_decode)
+                 FLAGSTATS_blockfile_stats* st, const uint8_t* map = nullptr, block_decode_fn decode = lz4_block_decode,
+                 bool raw = false)
 {
     const double t0 = now_s();
     uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
@@ -222,7 +223,32 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
     std::vector<BlockRef> blocks;
     std::vector<ChunkRef> chunks;
     uint64_t uncompressed = 0;
-    int rc = index_blocks(img, fd, bytes, chunk_cap, blocks, chunks, uncompressed);
+    int rc = 0;
+    if (raw) {
+        // raw uint16 file (`bench decompress -D`, benchmark/flagstats.cpp:415-468): no headers, no codec --
+        // the "blocks" are 1 MiB slices that the workers pread straight into their place of the pinned
+        // chunk (many readers in parallel: one thread copying out of the page cache is the bottleneck
+        // of a plain mmap + hipMemcpy, 25 GB/s against the 57 GB/s the bus carries)
+        const uint64_t slice = 1ull << 20;
+        ChunkRef cur{0, 0, 0};
+        for (uint64_t pos = 0; pos < bytes; pos += slice) {
+            const uint64_t len = bytes - pos < slice ? bytes - pos : slice;
+            const uint64_t padded = (len + 15) & ~15ull;
+            if (cur.bytes + padded > chunk_cap) {
+                cur.b1 = blocks.size();
+                chunks.push_back(cur);
+                cur = ChunkRef{blocks.size(), 0, 0};
+            }
+            blocks.push_back(BlockRef{nullptr, pos, static_cast<uint32_t>(len), static_cast<uint32_t>(len), cur.bytes,
+                                      static_cast<uint32_t>(chunks.size())});
+            cur.bytes += padded;
+        }
+        cur.b1 = blocks.size();
+        if (cur.b1 > cur.b0) chunks.push_back(cur);
+        uncompressed = bytes;
+    } else {
+        rc = index_blocks(img, fd, bytes, chunk_cap, blocks, chunks, uncompressed);
+    }
     if (rc) return rc;
     if (map)  // file mode with a mapping: headers were pread (no fault per block), payloads are decoded in place
         for (BlockRef& b : blocks) b.src = map + b.file_off;
@@ -304,6 +330,22 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
                     const uintptr_t a1 = (reinterpret_cast<uintptr_t>(src) + br.csize + 4095) & ~static_cast<uintptr_t>(4095);
                     (void)madvise(reinterpret_cast<void*>(a0), a1 - a0, 22 /* MADV_POPULATE_READ */);
                 }
+                if (raw) {
+                    size_t have = 0;
+                    while (have < br.usize) {
+                        const ssize_t r = pread(fd, dst + have, br.usize - have, static_cast<off_t>(br.file_off + have));
+                        if (r <= 0) break;
+                        have += static_cast<size_t>(r);
+                    }
+                    if (have != br.usize) {
+                        bad = true;
+                        break;
+                    }
+                    const uint64_t keep = br.usize & ~1ull;   // a trailing odd byte of the file is dropped (:450 `read >> 1`)
+                    std::memset(dst + keep, 0, padded - keep);
+                    ++mine;
+                    continue;
+                }
                 if (!src) {
                     if (local.size() < br.csize) local.resize(br.csize + (br.csize >> 2) + 64);
                     size_t have = 0;
@@ -361,7 +403,7 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
             std::unique_lock<std::mutex> ul(pipe.m);
             pipe.cv_main.wait(ul, [&] { return pipe.done[c] == chunks[c].b1 - chunks[c].b0 || pipe.failed; });
             if (pipe.failed) {
-                err = fsint::fail_text("block file: a block failed to decode to its declared size");
+                err = fsint::fail_text(raw ? "raw file: short read" : "block file: a block failed to decode to its declared size");
                 break;
             }
             wait_decode += now_s() - w0;
@@ -574,22 +616,39 @@ int FLAGSTATS_hip_zstd_available(void) { return zstd_load() ? 1 : 0; }
 int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
 {
     if (!out) return fsint::fail_text("NULL out");
-    const double t0 = now_s();
-    Mapped m;
-    int rc = map_file(path, m);
-    if (rc) return rc;
-    const uint64_t n = m.bytes / 2;  // a trailing odd byte is dropped, as `read >> 1` at benchmark/flagstats.cpp:450
-    fsint::Engine* eng = fsint::default_engine();
-    if (!eng) return -1;
-    rc = fsint::count_host(*eng, reinterpret_cast<const uint16_t*>(m.p), n, out);
-    if (rc) return rc;
-    if (stats) {
-        std::memset(stats, 0, sizeof *stats);
-        stats->n_flags = n;
-        stats->compressed_bytes = stats->uncompressed_bytes = m.bytes;
-        stats->wall_s = now_s() - t0;
+    if (!path) return fsint::fail_text("NULL path");
+    const char* io = std::getenv("FLAGSTATS_HIP_RAW_IO");
+    if (io && !std::strcmp(io, "mmap")) {
+        // the r01 form: mmap + the host-array path (one thread faults and copies: ~25 GB/s)
+        const double t0 = now_s();
+        Mapped m;
+        int rc = map_file(path, m);
+        if (rc) return rc;
+        const uint64_t n = m.bytes / 2;  // a trailing odd byte is dropped, as `read >> 1` at benchmark/flagstats.cpp:450
+        fsint::Engine* eng = fsint::default_engine();
+        if (!eng) return -1;
+        rc = fsint::count_host(*eng, reinterpret_cast<const uint16_t*>(m.p), n, out);
+        if (rc) return rc;
+        if (stats) {
+            std::memset(stats, 0, sizeof *stats);
+            stats->n_flags = n;
+            stats->compressed_bytes = stats->uncompressed_bytes = m.bytes;
+            stats->wall_s = now_s() - t0;
+        }
+        return 0;
     }
-    return 0;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return fsint::fail_text("cannot open file");
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) {
+        close(fd);
+        return fsint::fail_text("cannot stat file");
+    }
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    fsint::Engine* eng = fsint::default_engine();
+    const int rc = eng ? run_pipeline(*eng, nullptr, fd, static_cast<uint64_t>(sb.st_size), 0, out, stats, nullptr, nullptr, true) : -1;
+    close(fd);
+    return rc;
 }
 
 }  // extern "C"

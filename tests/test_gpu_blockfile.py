@@ -87,11 +87,30 @@ def test_empty_and_damaged_files(hip, tmp_path):
     assert np.array_equal(got, expect(flags, bt.BLOCK_BYTES)[0])
 
 
-def test_raw_file(hip, tmp_path):
+@pytest.mark.parametrize("n,odd", [(0, False), (1, True), (524288, False), (524289, True), (3_000_001, True),
+                                   (40_000_003, False)])
+def test_raw_file(hip, tmp_path, n, odd):
+    """`bench decompress -D` (benchmark/flagstats.cpp:415-468): a raw uint16 file, read by the pipeline's
+    workers in 1 MiB slices straight into pinned chunks.  Sizes around the slice (2^19 flags) and chunk
+    boundaries, the empty file, a trailing odd byte (ignored: `read >> 1`, :450), small chunks; the r01
+    mmap form (FLAGSTATS_HIP_RAW_IO=mmap) must agree."""
     import oracle
     from libflagstats_amd import blockfile
-    flags = oracle.generate(oracle.GEN_UNIFORM, 12, 0xFFFF, 0, 3_000_001)
+    flags = oracle.generate(oracle.GEN_UNIFORM, 12, 0xFFFF, 0, n)
     p = tmp_path / "flags.bin"
-    p.write_bytes(flags.tobytes() + b"\x7f")        # trailing odd byte is ignored (read >> 1)
-    got, st = blockfile.flagstat_raw_file(str(p))
-    assert np.array_equal(got, oracle.flagstat_hist(flags)) and st["n_flags"] == flags.size
+    p.write_bytes(flags.tobytes() + (b"\x7f" if odd else b""))
+    want = oracle.flagstat_hist(flags) if n else np.zeros(32, dtype=np.uint64)
+    old = hip.FLAGSTATS_hip_get(b"chunk_flags")
+    try:
+        for chunk in (old, 3_000_000):
+            hip.FLAGSTATS_hip_set(b"chunk_flags", chunk)
+            got, st = blockfile.flagstat_raw_file(str(p))
+            assert np.array_equal(got, want) and st["n_flags"] == flags.size, (n, chunk)
+    finally:
+        hip.FLAGSTATS_hip_set(b"chunk_flags", old)
+    os.environ["FLAGSTATS_HIP_RAW_IO"] = "mmap"
+    try:
+        got, st = blockfile.flagstat_raw_file(str(p))
+    finally:
+        del os.environ["FLAGSTATS_HIP_RAW_IO"]
+    assert np.array_equal(got, want) and st["n_flags"] == flags.size
