@@ -216,6 +216,10 @@ int FLAGSTATS_hip_blockfile(const char* path, int threads, uint64_t* out, FLAGST
 /* raw uint16 file (benchmark/flagstats.cpp:415-468, `-D`): the same threaded pipeline without a codec -- workers
  * pread 1 MiB slices straight into the pinned chunks (env FLAGSTATS_HIP_RAW_IO=mmap: mmap + FLAGSTATS_u16_x64) */
 int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
+/* the file entries with SUPERSET counters (slots 0 / 16 = n_pair_all, slot 9 = pass-QC reads): what the samtools
+ * report of `bench decompress -s` (block file) / `-S` (raw file) needs, benchmark/flagstats.cpp:577-588 */
+int FLAGSTATS_hip_blockfile_superset(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
+int FLAGSTATS_hip_file_raw_superset(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 /* the host LZ4 *block* decoder used above (replaces the reference's call to liblz4's
  * LZ4_decompress_safe, benchmark/flagstats.cpp:316): returns decoded bytes, < 0 on malformed input */
 int64_t FLAGSTATS_lz4_block_decode(const void* src, uint64_t srclen, void* dst, uint64_t dstcap);

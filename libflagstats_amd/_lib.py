@@ -86,6 +86,8 @@ SIGNATURES = {
     "FLAGSTATS_hip_blockfile_zstd": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_blockfile": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_zstd_available": (ctypes.c_int, []),
+    "FLAGSTATS_hip_blockfile_superset": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
+    "FLAGSTATS_hip_file_raw_superset": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_file_raw": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_lz4_block_decode": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]),
     "FLAGSTATS_hip_stream_open": (ctypes.c_void_p, []),

@@ -53,20 +53,21 @@ def flagstat_zstd_image(image: bytes, threads: int = 0):
     return out, _stats(st)
 
 
-def flagstat_file(path: str, threads: int = 0):
-    """Codec by extension (``.lz4`` / ``.zst``), as the reference's ``check_file_extension`` (``:828-839``)."""
+def flagstat_file(path: str, threads: int = 0, superset: bool = False):
+    """Codec by extension (``.lz4`` / ``.zst``), as the reference's ``check_file_extension`` (``:828-839``).
+    ``superset=True``: also slots 0 / 16 (n_pair_all) and 9 (pass-QC reads), for the samtools report."""
     out = np.zeros(32, dtype=np.uint64)
     st = _lib.BlockfileStats()
-    _lib.check(_lib.lib().FLAGSTATS_hip_blockfile(str(path).encode(), threads, out.ctypes.data, ctypes.byref(st)),
-               "FLAGSTATS_hip_blockfile")
+    fn = _lib.lib().FLAGSTATS_hip_blockfile_superset if superset else _lib.lib().FLAGSTATS_hip_blockfile
+    _lib.check(fn(str(path).encode(), threads, out.ctypes.data, ctypes.byref(st)), "FLAGSTATS_hip_blockfile")
     return out, _stats(st)
 
 
-def flagstat_raw_file(path: str):
+def flagstat_raw_file(path: str, superset: bool = False):
     out = np.zeros(32, dtype=np.uint64)
     st = _lib.BlockfileStats()
-    _lib.check(_lib.lib().FLAGSTATS_hip_file_raw(str(path).encode(), out.ctypes.data, ctypes.byref(st)),
-               "FLAGSTATS_hip_file_raw")
+    fn = _lib.lib().FLAGSTATS_hip_file_raw_superset if superset else _lib.lib().FLAGSTATS_hip_file_raw
+    _lib.check(fn(str(path).encode(), out.ctypes.data, ctypes.byref(st)), "FLAGSTATS_hip_file_raw")
     return out, _stats(st)
 
 

@@ -215,7 +215,7 @@ constexpr int kPinned = 3;
 // count and was measured to cost more than the extra copy.)
 int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, int threads, uint64_t* out,
                  FLAGSTATS_blockfile_stats* st, const uint8_t* map = nullptr, block_decode_fn decode = lz4_block_decode,
-                 bool raw = false)
+                 bool raw = false, bool superset = false)
 {
     const double t0 = now_s();
     uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
@@ -416,7 +416,8 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
             err = fsint::fail_hip("hipMemcpyAsync(chunk)", e);
             break;
         }
-        err = fsint::count_device_async(eng, eng.stage[sl], chunks[c].bytes / 2, eng.d_out[sl], eng.stream[sl], eng.ws[sl]);
+        err = fsint::count_device_async(eng, eng.stage[sl], chunks[c].bytes / 2, eng.d_out[sl], eng.stream[sl], eng.ws[sl],
+                                        fsint::OP_FLAGSTAT | (superset ? fsint::OP_SUPERSET : 0));
         if (err) break;
         if (c >= 1 && (c - 1) + kPinned < chunks.size()) {
             // The pinned buffer of chunk c-1 is reusable once ITS copy has left the host.  Waiting for
@@ -455,6 +456,13 @@ int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes,
     if (getenv("FLAGSTATS_HIP_TRACE"))
         fprintf(stderr, "blocks: spawn %.4f loop %.4f join %.4f sync %.4f\n", t_b - t_a, t_c - t_b, t_d - t_c, now_s() - t_d);
     if (err) return err;
+    if (superset) {
+        // slot 9 = pass-QC reads = flags - fail-QC reads is taken per launch over the whole chunk, and a chunk
+        // carries zero flags between its blocks (16-byte slots, dropped odd bytes): those are not reads
+        uint64_t counted = 0;
+        for (const ChunkRef& c : chunks) counted += c.bytes / 2;
+        eng.h_out[9] -= counted - n_flags;
+    }
     for (int s = 0; s < 2; ++s)
         for (int k = 0; k < 32; ++k) out[k] += eng.h_out[32 * s + k];
     if (st) {
@@ -530,7 +538,8 @@ int pick_decoder(int codec, block_decode_fn* fn)
     return 0;
 }
 
-int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec)
+int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec,
+               bool superset = false)
 {
     if (!out) return fsint::fail_text("NULL out");
     if (!image && bytes) return fsint::fail_text("NULL image");
@@ -539,10 +548,11 @@ int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FL
     static const uint8_t empty = 0;
     fsint::Engine* eng = fsint::default_engine();
     if (!eng) return -1;
-    return run_pipeline(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, out, stats, nullptr, fn);
+    return run_pipeline(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, out, stats, nullptr, fn,
+                        false, superset);
 }
 
-int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec)
+int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec, bool superset = false)
 {
     if (!out) return fsint::fail_text("NULL out");
     if (!path) return fsint::fail_text("NULL path");
@@ -567,7 +577,7 @@ int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_
     if (bytes && io && !std::strcmp(io, "mmap")) map = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
     fsint::Engine* eng = fsint::default_engine();
     const int rc = eng ? run_pipeline(*eng, nullptr, fd, bytes, threads, out, stats,
-                                      map == MAP_FAILED ? nullptr : static_cast<const uint8_t*>(map), fn)
+                                      map == MAP_FAILED ? nullptr : static_cast<const uint8_t*>(map), fn, false, superset)
                        : -1;
     if (map != MAP_FAILED) munmap(map, bytes);
     close(fd);
@@ -611,9 +621,23 @@ int FLAGSTATS_hip_blockfile(const char* path, int threads, uint64_t* out, FLAGST
     return fsint::fail_text("block file: unknown extension (expected .lz4 or .zst)");
 }
 
+// the same with SUPERSET counters (slots 0 / 16 = primary paired reads, slot 9 = pass-QC reads): everything the
+// samtools report of `bench decompress -s` / `-S` needs (benchmark/flagstats.cpp:577-588)
+int FLAGSTATS_hip_blockfile_superset(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    if (!path) return fsint::fail_text("NULL path");
+    const char* dot = std::strrchr(path, '.');
+    if (dot && !std::strcmp(dot + 1, "zst")) return blockfile(path, threads, out, stats, 1, true);
+    if (dot && !std::strcmp(dot + 1, "lz4")) return blockfile(path, threads, out, stats, 0, true);
+    return fsint::fail_text("block file: unknown extension (expected .lz4 or .zst)");
+}
+
 int FLAGSTATS_hip_zstd_available(void) { return zstd_load() ? 1 : 0; }
 
-int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+}  // extern "C"
+
+namespace {
+int file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats, bool superset)
 {
     if (!out) return fsint::fail_text("NULL out");
     if (!path) return fsint::fail_text("NULL path");
@@ -627,7 +651,8 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
         const uint64_t n = m.bytes / 2;  // a trailing odd byte is dropped, as `read >> 1` at benchmark/flagstats.cpp:450
         fsint::Engine* eng = fsint::default_engine();
         if (!eng) return -1;
-        rc = fsint::count_host(*eng, reinterpret_cast<const uint16_t*>(m.p), n, out);
+        rc = fsint::count_host(*eng, reinterpret_cast<const uint16_t*>(m.p), n, out,
+                               fsint::OP_FLAGSTAT | (superset ? fsint::OP_SUPERSET : 0));
         if (rc) return rc;
         if (stats) {
             std::memset(stats, 0, sizeof *stats);
@@ -646,9 +671,24 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
     }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
     fsint::Engine* eng = fsint::default_engine();
-    const int rc = eng ? run_pipeline(*eng, nullptr, fd, static_cast<uint64_t>(sb.st_size), 0, out, stats, nullptr, nullptr, true) : -1;
+    const int rc = eng ? run_pipeline(*eng, nullptr, fd, static_cast<uint64_t>(sb.st_size), 0, out, stats, nullptr, nullptr, true,
+                                      superset)
+                       : -1;
     close(fd);
     return rc;
+}
+}  // namespace
+
+extern "C" {
+
+int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    return file_raw(path, out, stats, false);
+}
+
+int FLAGSTATS_hip_file_raw_superset(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    return file_raw(path, out, stats, true);
 }
 
 }  // extern "C"

@@ -86,3 +86,15 @@ def flagstat_report(values) -> str:
     _lib.check(_lib.lib().FLAGSTATS_u16_x64_superset(v.ctypes.data if v.size else None, v.size, out.ctypes.data),
                "FLAGSTATS_u16_x64_superset")
     return samtools_flagstat_text(out, v.size)
+
+
+def flagstat_report_file(path: str, threads: int = 0) -> str:
+    """samtools-flagstat text of a file, as ``bench decompress -i FILE -s`` (``.lz4`` / ``.zst`` block files,
+    ``benchmark/flagstats.cpp:360-413,684-736``) or ``-S`` (any other name: a raw ``uint16`` file, ``:470-531``)
+    prints it: decode + superset count on the GPU engine, then the mapping above."""
+    from . import blockfile
+    if str(path).endswith((".lz4", ".zst")):
+        c, st = blockfile.flagstat_file(path, threads, superset=True)
+    else:
+        c, st = blockfile.flagstat_raw_file(path, superset=True)
+    return samtools_flagstat_text(c, st["n_flags"])

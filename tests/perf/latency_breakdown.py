@@ -1,5 +1,5 @@
 import sys, time, ctypes
-sys.path.insert(0, '.')
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from libflagstats_amd import _lib, device
 lib = _lib.lib(); _lib.check(lib.FLAGSTATS_hip_init(0), "init")

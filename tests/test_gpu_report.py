@@ -93,3 +93,35 @@ def test_text_equals_reference_stdout_on_golden_blockfiles(hip):
             assert flagstat_report(recipe_input(e["n_flags"], e["seed"])) == e["reference_decompress_s_stdout"], name
             seen += 1
     assert seen >= 3
+
+
+def test_file_to_text_is_the_reference_binarys_stdout(hip, tmp_path):
+    """`bench decompress -i FILE -s` end to end on this engine: the reference-written golden block file is
+    decoded and counted by the pipeline with SUPERSET counters (n_pair_all counted by K1; the zero flags the
+    pipeline pads chunks with must not count as pass-QC reads) and the text must be byte-identical to what the
+    reference binary printed for that very file.  `-S`: the same flags as a raw uint16 file."""
+    sys.path.insert(0, GOLDEN)
+    import oracle
+    from make_blockfiles import recipe_input
+    from libflagstats_amd import blockfile
+    from libflagstats_amd.report import flagstat_report_file
+    man = json.load(open(os.path.join(GOLDEN, "blockfiles", "manifest.json")))
+    seen = 0
+    for name, e in man["files"].items():
+        path = os.path.join(GOLDEN, "blockfiles", name)
+        flags = recipe_input(e["n_flags"], e["seed"])
+        want_counts = want_superset(oracle, flags)
+        for threads in (1, 5):
+            got, st = blockfile.flagstat_file(path, threads, superset=True)
+            assert np.array_equal(got, want_counts), (name, threads)
+        text = flagstat_report_file(path)
+        assert text == oracle.samtools_text(oracle.samtools_counts(flags)), name
+        if e["reference_decompress_s_stdout"]:
+            assert text == e["reference_decompress_s_stdout"], name
+            seen += 1
+        raw = tmp_path / (name + ".bin")
+        raw.write_bytes(flags.tobytes() + b"\x01")          # odd trailing byte: dropped, and not a read either
+        got, st = blockfile.flagstat_raw_file(str(raw), superset=True)
+        assert np.array_equal(got, want_counts) and st["n_flags"] == flags.size, name
+        assert flagstat_report_file(str(raw)) == text
+    assert seen >= 3
