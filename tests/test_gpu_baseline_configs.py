@@ -79,3 +79,30 @@ def test_8gib_na12878_pinned_host_double_buffered_vs_oracle(hip):
         assert np.array_equal(out2, oracle.flagstat_generated(oracle.GEN_NA12878, 77, 1, off, m))
     finally:
         hip.FLAGSTATS_hip_host_free(p)
+
+
+def test_64gib_as_eight_device_shards_counted_in_one_call(hip):
+    """BASELINE config 3's data volume -- 64 GiB = 8 shards of 2^32 flags, seed + rank as bench.py --gpus 8
+    makes them -- resident in ONE MI355X's 288 GB and counted through the C multi-shard entry
+    (FLAGSTATS_hip_multi_device_u16: every shard where it lives, host-side sum of the 8 x 256 bytes).  The 8-GPU
+    placement itself is the driver's SCALE run; this pins what a box with one GPU can: 2^35 flags in one
+    query, per-slot totals beyond 2^34, bit-exact vs the oracle's sum over the shards."""
+    import oracle
+    from libflagstats_amd import _lib, device
+    n = 2 ** 32
+    shards = []
+    try:
+        for r in range(8):
+            shards.append(device.DeviceFlags(n).generate(device.GEN_UNIFORM, seed=2026 + r, mask=0xFFFF))
+        ptrs = (ctypes.c_void_p * 8)(*[s.ptr for s in shards])
+        ns = (ctypes.c_uint64 * 8)(*([n] * 8))
+        out = np.zeros(32, dtype=U64)
+        _lib.check(hip.FLAGSTATS_hip_multi_device_u16(ptrs, ns, 8, out.ctypes.data), "multi device, 64 GiB")
+    finally:
+        for s in shards:
+            s.free()
+    want = np.zeros(32, dtype=U64)
+    for r in range(8):
+        want += oracle.flagstat_generated(oracle.GEN_UNIFORM, 2026 + r, 0xFFFF, 0, n)
+    assert np.array_equal(out, want)
+    assert int(out[25]) > 2 ** 34 - 2 ** 24      # ~half of 2^35 reads fail QC
