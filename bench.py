@@ -360,9 +360,8 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
-    barrier()
     if not multi:
-        counters.zero_()
+        counters.zero_()      # stream-ordered behind the warm-up steps: ONE sync gap before the timed region, not two
     barrier()
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
