@@ -43,6 +43,12 @@ inline void cp8(uint8_t* d, const uint8_t* s)
     std::memcpy(&v, s, 8);
     std::memcpy(d, &v, 8);
 }
+inline void cp2(uint8_t* d, const uint8_t* s)
+{
+    uint16_t v;
+    std::memcpy(&v, s, 2);
+    std::memcpy(d, &v, 2);
+}
 inline void cp16(uint8_t* d, const uint8_t* s)
 {
     struct V16 { uint64_t a, b; } v;   // one 16-byte (SSE) load and store
@@ -62,11 +68,15 @@ inline void short_match(uint8_t* op, size_t off, size_t ml)
     const uint8_t* m = op - off;
     if (WIDE && off >= 16) {
         cp16(op, m);
-        if (ml > 16) cp8(op + 16, m + 16);
+        if (ml > 16) cp2(op + 16, m + 16);
     } else if (off >= 8) {
         cp8(op, m);
         cp8(op + 8, m + 8);
+#ifdef FSLZ4_TAIL8
         cp8(op + 16, m + 16);
+#else
+        cp2(op + 16, m + 16);   // bytes 16, 17 only: every surplus byte stored is one more pending store a later match may straddle
+#endif
     } else if (off == 2 || off == 4) {
         uint64_t pat;
         if (off == 2) {

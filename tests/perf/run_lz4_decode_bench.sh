@@ -25,11 +25,11 @@ PY
 CXX=/opt/rocm/lib/llvm/bin/clang++
 $CXX -O3 -std=c++17 -o /tmp/lz4_bench_pairs tests/perf/lz4_decode_bench.cpp -ldl
 $CXX -O3 -std=c++17 -DFSLZ4_NO_PAIR_LOOP -o /tmp/lz4_bench_nopairs tests/perf/lz4_decode_bench.cpp -ldl
-$CXX -O3 -std=c++17 -DFSLZ4_B_WIDE -o /tmp/lz4_bench_bwide tests/perf/lz4_decode_bench.cpp -ldl
+$CXX -O3 -std=c++17 -DFSLZ4_TAIL8 -o /tmp/lz4_bench_bwide tests/perf/lz4_decode_bench.cpp -ldl
 for rep in 1 2; do
   for f in na_fast1 na_fast2 na_hc1 na_hc9 u12_fast2; do
     echo -n "pair-loop    "; /tmp/lz4_bench_pairs /tmp/$f.lz4 30
     echo -n "no pair-loop "; /tmp/lz4_bench_nopairs /tmp/$f.lz4 30
-    echo -n "loop B wide  "; /tmp/lz4_bench_bwide /tmp/$f.lz4 30
+    echo -n "8-byte tail  "; /tmp/lz4_bench_bwide /tmp/$f.lz4 30
   done
 done
