@@ -1,5 +1,7 @@
 """GPU: randomized parity sweep -- random lengths, 2-byte offsets, input makers and launch
 geometries through the device entry, each checked bit-exactly against the oracle."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,7 +20,7 @@ def test_random_lengths_offsets_geometries(hip):
     tuning = bool(hip.FLAGSTATS_hip_get(b"tuning_build"))
     variants = [9, 25] + ([0, 1, 13, 27, 41, 89] if tuning else [])
     try:
-        for it in range(150):
+        for it in range(int(os.environ.get("FLAGSTATS_FUZZ_ITERS", "150"))):   # a soak run sets thousands
             kind = int(rs.randint(0, 3))
             mask = [0xFFFF, 0x0FFF, 0x00FF][rs.randint(0, 3)] if kind == 0 else int(rs.randint(0, 2))
             seed = int(rs.randint(0, 2 ** 31))
