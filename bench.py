@@ -301,8 +301,9 @@ def main():
     overlap = multi and not args.no_overlap
     main_stream = torch.cuda.current_stream(dev)
     comm_stream = torch.cuda.Stream(device=dev) if overlap else None
-    bufs = [counters, torch.zeros(32, dtype=torch.int64, device=dev)]
-    reduced = [None, None]     # event: the all-reduce that last used bufs[k] has finished
+    RING = 8                   # counter buffers in flight between the launch stream and the all-reduce stream
+    bufs = [counters] + [torch.zeros(32, dtype=torch.int64, device=dev) for _ in range(RING - 1)]
+    reduced = [None] * RING    # event: the all-reduce that last used bufs[k] has finished
     state = {"i": 0}
 
     def allreduce(buf, stream):
@@ -317,18 +318,34 @@ def main():
         # bench accumulates across blocks, benchmark/flagstats.cpp:304,328-329), so a step is
         # exactly one K1 launch (its workgroups add their totals to the counters).  N > 1: a step is one whole query: count (K2 stores), all-reduce of the
         # 32 counters.  The all-reduce of query i runs on a side stream while K1 of query i+1 streams
-        # its shard (two counter buffers), so the collective's latency is off the critical path;
+        # its shard (a ring of counter buffers), so the collective's latency is off the critical path;
         # every query's all-reduce still completes inside the timed region (drain() below).
         if not overlap:
             device.count_torch(flags, counters, store=multi)   # K1 + K2 on torch's current stream
             if multi:
                 allreduce(counters, main_stream)  # the path's only exchange: 256 B over xGMI
             return
-        k = state["i"] & 1
+        k = state["i"] % RING
         state["i"] += 1
         buf = bufs[k]
-        if reduced[k] is not None:
-            main_stream.wait_event(reduced[k])    # K2 may overwrite buf only after its last all-reduce
+        if comm:
+            # the library orders the collective behind the kernels with device-scope events (no system fence);
+            # once per ring the launch stream waits (on the device) for the all-reduce stream to catch up, which
+            # makes every counter buffer of the ring reusable
+            if k == 0 and state["i"] > 1:
+                _lib.check(lib.FLAGSTATS_hip_stream_wait_stream(ctypes.c_void_p(main_stream.cuda_stream),
+                                                                ctypes.c_void_p(comm_stream.cuda_stream), local_rank),
+                           "FLAGSTATS_hip_stream_wait_stream")
+            _lib.check(lib.FLAGSTATS_hip_device_u16_allreduce_overlapped(
+                flags.data_ptr(), n, buf.data_ptr(), comm, ctypes.c_void_p(main_stream.cuda_stream),
+                ctypes.c_void_p(comm_stream.cuda_stream)), "FLAGSTATS_hip_device_u16_allreduce_overlapped")
+            return
+        # torch.distributed carries the collective: torch events order the two streams
+        if reduced[k] is not None and not reduced[k].query():
+            # K2 may overwrite buf only after the all-reduce that last used it (RING steps ago) has finished.
+            # The HOST waits (it runs steps ahead of the GPU, so practically never); a wait_event on the launch
+            # stream instead stalls the queue on this runtime (profiles/r02/dist_step_overhead.log)
+            reduced[k].synchronize()
         device.count_torch(flags, buf, store=True)
         counted = torch.cuda.Event()
         counted.record(main_stream)
@@ -390,7 +407,7 @@ def main():
 
     result = None
     if rank == 0:
-        last = bufs[(state["i"] - 1) & 1] if overlap else counters
+        last = bufs[(state["i"] - 1) % RING] if overlap else counters
         got = last.cpu().numpy().view(np.uint64)
         passes = 1 if multi else args.steps   # N = 1 accumulated `steps` identical passes
         assert not (got % np.uint64(passes)).any(), "accumulated counters are not a multiple of the step count"

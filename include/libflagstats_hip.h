@@ -137,6 +137,15 @@ void* FLAGSTATS_hip_comm_init_rank(const void* id128, int nranks, int rank, int 
 int FLAGSTATS_hip_comm_destroy(void* comm);
 int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* stream);
 int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream);
+/* the same query with the collective OFF the launch stream: K1 + K2 (store) on `stream`, the all-reduce on
+ * `comm_stream`, ordered behind the kernels by a device-scope event (no timing, no system fence: a plain event
+ * record costs the launch stream ~10 us of cache write-back here), so it overlaps whatever `stream` runs next.
+ * d_out may be rewritten once `comm_stream` has passed the all-reduce: FLAGSTATS_hip_stream_wait_stream(stream,
+ * comm_stream, device) makes `stream` wait on the device (cheap, e.g. once per ring of counter buffers); a host
+ * sync of comm_stream works too. */
+int FLAGSTATS_hip_device_u16_allreduce_overlapped(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream,
+                                                  void* comm_stream);
+int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
 
 /* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _EPILOGUE / _CHUNK_FLAGS / _ON_ERROR / _NUMA).  key =
  *   "blocks_per_cu"  workgroups per CU of K1's grid (default 1)

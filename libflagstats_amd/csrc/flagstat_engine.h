@@ -59,7 +59,10 @@ struct Engine {
     uint64_t host_overlapped = 0;                  // ... and how many were submitted while the previous one was still in flight
     void* pinned[3] = {nullptr, nullptr, nullptr}; // block-file chunk buffers, kept across calls
     uint64_t pinned_bytes = 0;
-    std::mutex user_mu;                            // guards user_ws
+    static constexpr int kOrderEvents = 16;        // device-scope ordering events (no timing, no system fence), used round robin
+    hipEvent_t order_ev[kOrderEvents] = {};
+    unsigned order_next = 0;                       // guarded by user_mu
+    std::mutex user_mu;                            // guards user_ws and the ordering events
     std::list<std::pair<void*, Workspace>> user_ws;  // caller-owned streams, most recently used first (bounded)
 };
 
@@ -99,6 +102,9 @@ int select_default_device(int device);             // FLAGSTATS_hip_init
 int device_of_pointer(const void* p, const char* what, int* device, bool* plain_device_memory = nullptr);
 // a caller's stream must belong to `device` (NULL = that device's null stream)
 int check_stream_device(hipStream_t s, int device);
+// `waiter` waits (on the device; the host does not) for everything queued on `on` so far.  The event carries no
+// system-scope fence: a plain hipEventRecord costs the launch stream ~10 us of cache write-back per record here.
+int stream_wait_stream(Engine& e, hipStream_t waiter, hipStream_t on);
 
 uint32_t grid_for(const Engine& e);
 int ensure_ws(Workspace& w, uint32_t grid);

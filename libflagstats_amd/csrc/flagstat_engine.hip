@@ -85,6 +85,10 @@ void release_engine_resources(Engine& e)
     for (auto& kv : e.user_ws)
         if (kv.second.partials) (void)hipFree(kv.second.partials);
     e.user_ws.clear();
+    for (hipEvent_t& ev : e.order_ev) {
+        if (ev) (void)hipEventDestroy(ev);
+        ev = nullptr;
+    }
     if (e.h_out) (void)hipHostFree(e.h_out);
     for (int i = 0; i < 2; ++i)
         if (e.chunk_done[i]) (void)hipEventDestroy(e.chunk_done[i]);
@@ -322,6 +326,23 @@ int check_stream_device(hipStream_t s, int device)
                       device);
         return fail_text(buf);
     }
+    return 0;
+}
+
+int stream_wait_stream(Engine& e, hipStream_t waiter, hipStream_t on)
+{
+    if (waiter == on) return 0;
+    hipEvent_t ev;
+    {
+        std::lock_guard<std::mutex> lk(e.user_mu);
+        hipEvent_t& slot = e.order_ev[e.order_next++ % Engine::kOrderEvents];
+        if (!slot) HIP_TRY(hipEventCreateWithFlags(&slot, hipEventDisableTiming | hipEventDisableSystemFence));
+        ev = slot;
+    }
+    // re-recording an event that an earlier hipStreamWaitEvent still refers to is fine: a wait binds to the
+    // record that was current when it was queued
+    HIP_TRY(hipEventRecord(ev, on));
+    HIP_TRY(hipStreamWaitEvent(waiter, ev, 0));
     return 0;
 }
 

@@ -270,6 +270,40 @@ int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* str
     return e == ncclSuccess ? 0 : fail_nccl(r, "ncclAllReduce", e);
 }
 
+int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device)
+{
+    Engine* e = fsint::engine_for_device(device);
+    if (!e) return -1;
+    DeviceGuard guard(e->device);
+    if (!guard.ok()) return -1;
+    int rc = fsint::check_stream_device(static_cast<hipStream_t>(waiter), e->device);
+    if (!rc) rc = fsint::check_stream_device(static_cast<hipStream_t>(on), e->device);
+    if (rc) return rc;
+    return fsint::stream_wait_stream(*e, static_cast<hipStream_t>(waiter), static_cast<hipStream_t>(on));
+}
+
+int FLAGSTATS_hip_device_u16_allreduce_overlapped(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream,
+                                                  void* comm_stream)
+{
+    int rc = FLAGSTATS_hip_device_u16_store(d_array, n, d_out, stream);  // K1 + K2 on the launch stream
+    if (rc) return rc;
+    int dev = -1;
+    rc = fsint::device_of_pointer(d_out, "d_out", &dev);
+    if (rc) return rc;
+    Engine* e = fsint::engine_for_device(dev);
+    if (!e) return -1;
+    {
+        DeviceGuard guard(e->device);
+        if (!guard.ok()) return -1;
+        rc = fsint::check_stream_device(static_cast<hipStream_t>(comm_stream), e->device);
+        if (rc) return rc;
+        // the collective waits for the kernels on the device; the launch stream is not held up and pays no cache flush
+        rc = fsint::stream_wait_stream(*e, static_cast<hipStream_t>(comm_stream), static_cast<hipStream_t>(stream));
+        if (rc) return rc;
+    }
+    return FLAGSTATS_hip_allreduce_counters(d_out, comm, comm_stream);
+}
+
 int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream)
 {
     int rc = FLAGSTATS_hip_device_u16_store(d_array, n, d_out, stream);  // K1 + K2, d_out = this shard's counters

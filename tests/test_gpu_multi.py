@@ -162,5 +162,23 @@ def test_rccl_allreduce_world_of_one(hip):
         torch.cuda.synchronize()
         want = oracle.flagstat_generated(oracle.GEN_UNIFORM, 8, 0xFFFF, 0, n)
         assert np.array_equal(out.cpu().numpy().view(U64), want)
+        # the overlapped form: the collective on a second stream, ordered on the device behind the kernels; a ring
+        # of counter buffers, the launch stream waiting for the collective stream once per ring (as bench.py does)
+        side = torch.cuda.Stream()
+        side_p = ctypes.c_void_p(side.cuda_stream)
+        ring = [torch.full((32,), 7, dtype=torch.int64, device="cuda:0") for _ in range(3)]
+        lens = [n, n - 12345, 1_000_001, 5, n // 3, 16384 * 7, n - 1]
+        for i, m in enumerate(lens):
+            if i and i % len(ring) == 0:
+                _lib.check(hip.FLAGSTATS_hip_stream_wait_stream(stream, side_p, 0), "stream_wait_stream")
+            _lib.check(hip.FLAGSTATS_hip_device_u16_allreduce_overlapped(t.data_ptr(), m, ring[i % len(ring)].data_ptr(), comm,
+                                                                         stream, side_p), "allreduce overlapped")
+        torch.cuda.synchronize()
+        for j in range(len(ring)):
+            last = max(i for i in range(len(lens)) if i % len(ring) == j)
+            want = oracle.flagstat_generated(oracle.GEN_UNIFORM, 8, 0xFFFF, 0, lens[last])
+            assert np.array_equal(ring[j].cpu().numpy().view(U64), want), j
+        # a stream of another kind of object is refused loudly
+        assert hip.FLAGSTATS_hip_stream_wait_stream(stream, ctypes.c_void_p(0x1234), 0) != 0
     finally:
         _lib.check(hip.FLAGSTATS_hip_comm_destroy(comm), "comm destroy")
