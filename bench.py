@@ -248,6 +248,7 @@ def main():
     lib = _lib.lib()
     _lib.check(lib.FLAGSTATS_hip_init(local_rank), "FLAGSTATS_hip_init")
     multi = world > 1 or args.force_dist
+    comm_init_hung = False
     comm = None
     ar_impl = None
     if multi:
@@ -270,9 +271,25 @@ def main():
                     ident = ident.to(dev)
                 dist.broadcast(ident, src=0)
                 raw = bytes(ident.cpu().numpy().tobytes())
-                comm = lib.FLAGSTATS_hip_comm_init_rank(raw, world, rank, local_rank)
+                # ncclCommInitRank is itself a collective: if it never returns on some rank (first time this path
+                # meets a real multi-GPU node), do not hang the run -- give it a bounded time on a helper thread,
+                # then let every rank agree (below) to carry the all-reduce with torch.distributed instead
+                import threading
+                box = {}
+
+                def init_comm():
+                    box["comm"] = lib.FLAGSTATS_hip_comm_init_rank(raw, world, rank, local_rank)
+                    box["err"] = lib.FLAGSTATS_hip_last_error().decode(errors="replace")
+
+                th = threading.Thread(target=init_comm, daemon=True)
+                th.start()
+                th.join(timeout=float(os.environ.get("FLAGSTATS_BENCH_COMM_TIMEOUT", "120")))
+                if th.is_alive():
+                    comm_init_hung = True
+                    raise _lib.FlagstatsHipError("FLAGSTATS_hip_comm_init_rank did not return within the time limit")
+                comm = box.get("comm")
                 if not comm:
-                    raise _lib.FlagstatsHipError(lib.FLAGSTATS_hip_last_error().decode(errors="replace"))
+                    raise _lib.FlagstatsHipError(box.get("err", "communicator creation failed"))
                 ar_impl = "FLAGSTATS_hip_allreduce_counters (C ABI, ncclAllReduce uint64[32])"
             except Exception as e:  # noqa: BLE001 -- a scaling run must not die on the communicator; say so instead
                 print("bench.py: C-ABI RCCL communicator unavailable (%r); using torch.distributed all_reduce" % (e,),
@@ -481,6 +498,9 @@ def main():
         if comm:
             lib.FLAGSTATS_hip_comm_destroy(comm)
         dist.destroy_process_group()
+        if comm_init_hung:
+            sys.stdout.flush()
+            os._exit(0)   # a helper thread is still inside ncclCommInitRank: do not wait for it at interpreter exit
     return result
 
 
