@@ -199,6 +199,9 @@ def main():
     ap.add_argument("--same-device", action="store_true",
                     help="TEST ONLY: put every rank on GPU 0 (use with --backend gloo --allreduce torch) to exercise the "
                          "multi-rank launch contract on a single-GPU box; the number it prints is not a scaling result")
+    ap.add_argument("--overlap", action="store_true",
+                    help="N > 1: always run the all-reduce of step i on a side stream, overlapping K1 of step i+1 "
+                         "(default: measured against the in-line form before the warm-up, the faster one is used)")
     ap.add_argument("--no-overlap", action="store_true",
                     help="N > 1: wait for each step's all-reduce before the next step's K1 (default: the all-reduce "
                          "of step i overlaps K1 of step i+1)")
@@ -315,13 +318,13 @@ def main():
     counters = torch.zeros(32, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
-    overlap = multi and not args.no_overlap
+    overlap = multi and not args.no_overlap     # may be switched off by the calibration below
     main_stream = torch.cuda.current_stream(dev)
     comm_stream = torch.cuda.Stream(device=dev) if overlap else None
     RING = 8                   # counter buffers in flight between the launch stream and the all-reduce stream
     bufs = [counters] + [torch.zeros(32, dtype=torch.int64, device=dev) for _ in range(RING - 1)]
     reduced = [None] * RING    # event: the all-reduce that last used bufs[k] has finished
-    state = {"i": 0}
+    state = {"i": 0, "overlap": overlap}
 
     def allreduce(buf, stream):
         if comm:
@@ -337,7 +340,7 @@ def main():
         # 32 counters.  The all-reduce of query i runs on a side stream while K1 of query i+1 streams
         # its shard (a ring of counter buffers), so the collective's latency is off the critical path;
         # every query's all-reduce still completes inside the timed region (drain() below).
-        if not overlap:
+        if not state["overlap"]:
             device.count_torch(flags, counters, store=multi)   # K1 + K2 on torch's current stream
             if multi:
                 allreduce(counters, main_stream)  # the path's only exchange: 256 B over xGMI
@@ -374,7 +377,7 @@ def main():
         reduced[k] = ev
 
     def drain():
-        if overlap:
+        if state["overlap"]:
             main_stream.wait_stream(comm_stream)
 
     def barrier():
@@ -390,6 +393,35 @@ def main():
         _lib.check(lib.FLAGSTATS_hip_read_probe(flags.data_ptr(), 2 * n, 1, args.probe_reps, args.probe_reps,
                                                 ctypes.byref(ms)), "FLAGSTATS_hip_read_probe")
         probe_gbs = 2.0 * n * args.probe_reps / (ms.value * 1e-3) / 1e9
+
+    # N > 1, untimed: which form of the step is faster HERE?  Overlapping hides the collective's latency but lets its
+    # kernel share CUs with the next K1 (whose grid ends with its slowest workgroup); in line exposes the latency
+    # instead.  On one GPU in line wins by ~12 us per step; on an 8-GPU node the all-reduce is slower and the answer
+    # may flip, so both are run for a few steps and every rank takes the form with the smaller max-over-ranks time.
+    calib_note = ""
+    if multi and overlap and not args.overlap:
+        times = [0.0, 0.0]
+        state["overlap"] = False
+        for _ in range(20):           # the chip settles first (the first launches after idle run long)
+            step()
+        drain()
+        for seg in range(6):          # in line / overlapped alternately, 3 segments of 15 steps each
+            form = seg & 1
+            state["overlap"] = bool(form)
+            step()
+            drain()
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(15):
+                step()
+            drain()
+            torch.cuda.synchronize()
+            times[form] += time.perf_counter() - t0
+        tt = torch.tensor(times, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        state["overlap"] = bool(float(tt[1]) < float(tt[0]))
+        calib_note = " (calibrated: in-line %.1f us/step, overlapped %.1f us/step)" % (float(tt[0]) / 45 * 1e6, float(tt[1]) / 45 * 1e6)
+        state["i"] = 0
 
     for _ in range(args.warmup):
         step()
@@ -424,7 +456,7 @@ def main():
 
     result = None
     if rank == 0:
-        last = bufs[(state["i"] - 1) % RING] if overlap else counters
+        last = bufs[(state["i"] - 1) % RING] if state["overlap"] else counters
         got = last.cpu().numpy().view(np.uint64)
         passes = 1 if multi else args.steps   # N = 1 accumulated `steps` identical passes
         assert not (got % np.uint64(passes)).any(), "accumulated counters are not a multiple of the step count"
@@ -473,7 +505,7 @@ def main():
                                       else ("K1 flagstat_count accumulating into the 32 counters (atomic epilogue, one launch)"
                                             if lib.FLAGSTATS_hip_get(b"epilogue") else "K1 flagstat_count + K2 flagstat_finalize")),
                        "flags_per_gpu": n, "global_flags": total_flags, "parallelism": "shard%d" % world,
-                       "allreduce": ("overlapped" if overlap else "in-line") if multi else None,
+                       "allreduce": (("overlapped" if state["overlap"] else "in-line") + calib_note) if multi else None,
                        "allreduce_impl": ar_impl,
                        "kernel_variant": int(lib.FLAGSTATS_hip_get(b"variant")),
                        "grid_blocks": int(lib.FLAGSTATS_hip_get(b"grid")),
