@@ -213,10 +213,25 @@ constexpr int kPinned = 3;
 // preads the compressed payload of its block into a private buffer.  (mmap-ing the file instead
 // makes all decode threads fault on one address space; the contention grows with the thread
 // count and was measured to cost more than the extra copy.)
-int run_pipeline(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, int threads, uint64_t* out,
-                 FLAGSTATS_blockfile_stats* st, const uint8_t* map = nullptr, block_decode_fn decode = lz4_block_decode,
-                 bool raw = false, bool superset = false)
+// where the bytes come from and what they are
+struct Source {
+    const uint8_t* img = nullptr;              // whole file image in memory (image mode), else nullptr
+    int fd = -1;                               // file mode: every worker preads its block
+    uint64_t bytes = 0;
+    const uint8_t* map = nullptr;              // file mode, opt-in: read-only mapping the payloads are decoded out of
+    block_decode_fn decode = lz4_block_decode; // block codec (ignored for raw)
+    bool raw = false;                          // headerless uint16 file: 1 MiB slices pread straight into the chunks
+    bool superset = false;                     // also count slots 0 / 16 (n_pair_all) and 9 (pass-QC reads)
+};
+
+int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* st)
 {
+    const uint8_t* const img = in.img;
+    const int fd = in.fd;
+    const uint64_t bytes = in.bytes;
+    const uint8_t* const map = in.map;
+    const block_decode_fn decode = in.decode;
+    const bool raw = in.raw, superset = in.superset;
     const double t0 = now_s();
     uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
     if (chunk_cap < (4ull << 20)) chunk_cap = 4ull << 20;
@@ -548,8 +563,12 @@ int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FL
     static const uint8_t empty = 0;
     fsint::Engine* eng = fsint::default_engine();
     if (!eng) return -1;
-    return run_pipeline(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, out, stats, nullptr, fn,
-                        false, superset);
+    Source in;
+    in.img = image ? static_cast<const uint8_t*>(image) : &empty;
+    in.bytes = bytes;
+    in.decode = fn;
+    in.superset = superset;
+    return run_pipeline(*eng, in, threads, out, stats);
 }
 
 int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec, bool superset = false)
@@ -576,9 +595,13 @@ int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_
     void* map = MAP_FAILED;
     if (bytes && io && !std::strcmp(io, "mmap")) map = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);
     fsint::Engine* eng = fsint::default_engine();
-    const int rc = eng ? run_pipeline(*eng, nullptr, fd, bytes, threads, out, stats,
-                                      map == MAP_FAILED ? nullptr : static_cast<const uint8_t*>(map), fn, false, superset)
-                       : -1;
+    Source in;
+    in.fd = fd;
+    in.bytes = bytes;
+    in.map = map == MAP_FAILED ? nullptr : static_cast<const uint8_t*>(map);
+    in.decode = fn;
+    in.superset = superset;
+    const int rc = eng ? run_pipeline(*eng, in, threads, out, stats) : -1;
     if (map != MAP_FAILED) munmap(map, bytes);
     close(fd);
     return rc;
@@ -671,9 +694,12 @@ int file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats, 
     }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
     fsint::Engine* eng = fsint::default_engine();
-    const int rc = eng ? run_pipeline(*eng, nullptr, fd, static_cast<uint64_t>(sb.st_size), 0, out, stats, nullptr, nullptr, true,
-                                      superset)
-                       : -1;
+    Source in;
+    in.fd = fd;
+    in.bytes = static_cast<uint64_t>(sb.st_size);
+    in.raw = true;
+    in.superset = superset;
+    const int rc = eng ? run_pipeline(*eng, in, 0, out, stats) : -1;
     close(fd);
     return rc;
 }
