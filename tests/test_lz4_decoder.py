@@ -98,3 +98,42 @@ def test_fast_loops_are_memory_safe_under_asan(tmp_path):
     r = subprocess.run([str(exe), "120"], capture_output=True, text=True, env=env, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert r.stdout.startswith("OK") or r.stdout.startswith("SKIP"), r.stdout
+
+
+def test_property_roundtrip_against_liblz4():
+    """Property test (hypothesis): byte strings assembled from random literal runs, repeats of earlier
+    material at random distances (the match structure LZ4 finds) and flag-like 2-byte symbols, compressed by
+    liblz4 at a random mode / level, must decode to the original -- also when the output starts 64 KiB deep, where
+    the decoder's unchecked fast loops take over."""
+    hyp = pytest.importorskip("hypothesis")
+    from hypothesis import given, settings, strategies as st
+
+    piece = st.one_of(
+        st.tuples(st.just("lit"), st.binary(min_size=0, max_size=40)),
+        st.tuples(st.just("rep"), st.integers(1, 70000), st.integers(1, 300)),       # (distance back, length)
+        st.tuples(st.just("sym"), st.lists(st.sampled_from([99, 147, 83, 163, 1123, 2113]), min_size=1, max_size=60)),
+    )
+
+    @settings(max_examples=150, deadline=None)
+    @given(st.lists(piece, min_size=0, max_size=120), st.sampled_from([("fast", 1), ("fast", 2), ("fast", 7), ("hc", 1), ("hc", 9)]),
+           st.booleans())
+    def run(pieces, how, deep):
+        out = bytearray(os.urandom(1) * 0)
+        if deep:   # 66 KiB of compressible preamble: the body is then decoded by the unchecked loops
+            out += (np.random.RandomState(1).choice([99, 147, 83, 163], 33800).astype(np.uint16).tobytes())
+        for p in pieces:
+            if p[0] == "lit":
+                out += p[1]
+            elif p[0] == "sym":
+                out += np.array(p[1], dtype=np.uint16).tobytes()
+            elif out:
+                dist, ln = min(p[1], len(out)), p[2]
+                start = len(out) - dist
+                for i in range(ln):                      # overlapping copies allowed, as in LZ77
+                    out.append(out[start + i])
+        raw = bytes(out)
+        comp = bt.compress_block(raw, *how)
+        assert blockfile.lz4_block_decode(comp, len(raw)) == raw
+        assert blockfile.lz4_block_decode(comp, len(raw) + 17) == raw
+
+    run()
