@@ -428,8 +428,12 @@ def main():
     drain()
     if not multi:
         counters.zero_()      # stream-ordered behind the warm-up steps: ONE sync gap before the timed region, not two
-    barrier()
+    # the per-step events exist (torch creates the HIP event at the first record) BEFORE the barrier: the GPU idles
+    # between the synchronize and the first timed launch, and every extra 100 us of that gap shows in the first steps
     evs = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
+    for e in evs:
+        e.record()
+    barrier()
     t0 = time.perf_counter()
     evs[0].record()
     for i in range(args.steps):
