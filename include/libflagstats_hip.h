@@ -191,7 +191,7 @@ int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t
 int64_t FLAGSTATS_text_to_u16(const char* text, uint64_t len, uint16_t* out, uint64_t cap);
 uint64_t FLAGSTATS_text_count_lines(const char* text, uint64_t len);
 
-/* ---- measurement: `reps` back-to-back K1+K2 launches between two hipEvents on
+/* ---- measurement: `reps` back-to-back launches of the hot path (K1; + K2 if knob "epilogue" is 0) between two hipEvents on
  * the library's stream, after `warmup` untimed ones.  *ms_total = elapsed ms of
  * the timed region; out[32] += counters of ONE pass.  Returns 0 on success. */
 int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmup, int reps, float* ms_total,

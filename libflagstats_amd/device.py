@@ -62,7 +62,7 @@ class DeviceFlags:
 
     # -- counting ----------------------------------------------------------
     def count(self, offset: int = 0, n: int | None = None) -> np.ndarray:
-        """uint64[32] counters of [offset, offset+n): K1+K2 on device, synchronous."""
+        """uint64[32] counters of [offset, offset+n): one K1 launch on device (atomic epilogue), synchronous."""
         n = self.n - offset if n is None else n
         return count_device_ptr(self.ptr + 2 * offset, n)
 
@@ -134,7 +134,7 @@ def generate_torch(t, kind: int, seed: int, mask: int = 0xFFFF, first_index: int
 
 
 def time_device_ptr(ptr: int, n: int, warmup: int, reps: int):
-    """(ms_total, counters-of-one-pass) for `reps` K1+K2 launches between hipEvents."""
+    """(ms_total, counters-of-one-pass) for `reps` back-to-back launches of the hot path between hipEvents."""
     ms = ctypes.c_float(0.0)
     out = np.zeros(32, dtype=np.uint64)
     _lib.check(_lib.lib().FLAGSTATS_hip_time_device_u16(ptr, n, warmup, reps, ctypes.byref(ms), out.ctypes.data),
