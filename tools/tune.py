@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Measurement helper (GPU box): sweep K1 variants x grid sizes on the headline workload and
-measure the read-only probe ceiling.  Interleaved rounds in ONE process, median and min."""
+measure the read-only probe ceiling.  Interleaved rounds in ONE process, median and min.
+The product library carries schedules 9 and 25; the others (and --fuse 1) need the tuning build:
+FLAGSTATS_HIP_LIB=libflagstats_amd/libflagstats_hip_tuning.so (make -C libflagstats_amd/csrc tuning)."""
 import argparse
 import ctypes
 import json
@@ -36,11 +38,13 @@ def main():
     fuses = [int(f) for f in args.fuse.split(",")]
     for r in range(args.rounds):
       for fz in fuses:
-        lib.FLAGSTATS_hip_set(b"fuse", fz)
+        if lib.FLAGSTATS_hip_set(b"fuse", fz) != 0:
+            continue
         for v in variants:
             for b in bpcs:
                 v = v % 1000 + 1000 * fz
-                lib.FLAGSTATS_hip_set(b"variant", v % 1000)
+                if lib.FLAGSTATS_hip_set(b"variant", v % 1000) != 0:
+                    continue   # a schedule (or the ticket form) this build does not carry: needs the tuning build
                 lib.FLAGSTATS_hip_set(b"blocks_per_cu", b)
                 ms, _ = device.time_device_ptr(d.ptr, n, 1, args.reps)
                 res.setdefault((v, b), []).append(ms / args.reps)
