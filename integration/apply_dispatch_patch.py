@@ -28,7 +28,7 @@ int FLAGSTAT_hip(const uint16_t* array, uint32_t len, uint32_t* flags); /* same 
 int FLAGSTATS_hip_available(void);
 #ifndef FLAGSTATS_HIP_MIN_LEN
 #define FLAGSTATS_HIP_MIN_LEN (1u << 18) /* break-even of a host-pointer call vs FLAGSTAT_avx512 on 2x EPYC 9575F:
-                                          * ~2.5e5 flags (profiles/r01/small_calls.log) */
+                                          * ~2.5e5 flags (23 us call floor; 512,000 flags: 63 vs 94 us; profiles/r02/small_calls.log) */
 #endif
 static int FLAGSTATS_hip_wanted(uint32_t n_len)
 {
