@@ -1,0 +1,53 @@
+"""GPU: bench.py's output contract (the driver parses ONE JSON line from rank 0): a small end-to-end run
+must print exactly one JSON object with the agreed keys, the roofline and cpu_baseline objects, a
+bit-exact parity verdict, and numbers that are consistent with each other."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def run_bench(*extra):
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--flags-per-gpu", str(2 ** 27), "--steps", "6",
+                        "--warmup", "2", "--cpu-seconds", "0.5", "--cpu-sample", str(2 ** 22), "--probe-reps", "3", *extra],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stdout + r.stderr
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0])
+
+
+def test_single_gpu_line(hip):
+    d = run_bench()
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "parity"):
+        assert k in d, k
+    assert d["unit"] == "Gflags/s" and d["n_gpus"] == 1 and d["steps"] == 6 and d["warmup"] == 2
+    assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "u16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    r = d["roofline"]
+    assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert r["algorithmic_bytes_per_launch"] == 2 * 2 ** 27
+    # value = flags / wall time; achieved = 2 B/flag over the event time: the two clocks must agree
+    assert abs(d["value"] * 2.0 / r["achieved"] - 1.0) < 0.1
+    assert abs(d["ms_per_step"] / r["event_ms_per_launch"] - 1.0) < 0.1
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    assert d["parity"].startswith("bit-exact")
+
+
+def test_multi_gpu_step_at_world_size_one(hip):
+    """--force-dist: the N > 1 step (store form + the library's RCCL all-reduce, calibrated in-line vs overlapped)
+    on one GPU; the line must say which form ran and the counters must still be the oracle's."""
+    d = run_bench("--force-dist", "--cpu-seconds", "0")
+    assert d["n_gpus"] == 1 and d["config"]["allreduce"].split()[0] in ("in-line", "overlapped")
+    assert "calibrated" in d["config"]["allreduce"]
+    assert d["config"]["allreduce_impl"]
+    assert d["parity"].startswith("bit-exact") and d["cpu_baseline"] is None
