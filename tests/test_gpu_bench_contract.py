@@ -14,9 +14,14 @@ pytestmark = pytest.mark.gpu
 
 
 def run_bench(*extra):
+    import socket
+    with socket.socket() as sk:            # a free rendezvous port for the --force-dist run
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--flags-per-gpu", str(2 ** 27), "--steps", "6",
                         "--warmup", "2", "--cpu-seconds", "0.5", "--cpu-sample", str(2 ** 22), "--probe-reps", "3", *extra],
-                       capture_output=True, text=True, timeout=600, cwd=ROOT)
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
