@@ -336,7 +336,11 @@ int stream_wait_stream(Engine& e, hipStream_t waiter, hipStream_t on)
     {
         std::lock_guard<std::mutex> lk(e.user_mu);
         hipEvent_t& slot = e.order_ev[e.order_next++ % Engine::kOrderEvents];
-        if (!slot) HIP_TRY(hipEventCreateWithFlags(&slot, hipEventDisableTiming | hipEventDisableSystemFence));
+        if (!slot && hipEventCreateWithFlags(&slot, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+            (void)hipGetLastError();  // a runtime without the fence-free flavour: an ordinary ordering event does the same job
+            slot = nullptr;
+            HIP_TRY(hipEventCreateWithFlags(&slot, hipEventDisableTiming));
+        }
         ev = slot;
     }
     // re-recording an event that an earlier hipStreamWaitEvent still refers to is fine: a wait binds to the
