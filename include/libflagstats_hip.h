@@ -196,6 +196,12 @@ uint64_t FLAGSTATS_text_count_lines(const char* text, uint64_t len);
  * the timed region; out[32] += counters of ONE pass.  Returns 0 on success. */
 int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmup, int reps, float* ms_total,
                                   uint64_t* out);
+/* The same over ROTATING slices: launch i counts d_array[slot_i * stride_flags, + n) with slot_i = (i * 7919) % slots,
+ * so an array that fits the 256 MiB Infinity Cache is never re-read from it (slots * stride_flags flags must be
+ * allocated; stride_flags >= n, even).  *ms_total = elapsed ms of the `reps` timed launches; out[32] += the counters
+ * of ALL timed launches.  Returns 0 on success. */
+int FLAGSTATS_hip_time_device_u16_rotating(const uint16_t* d_array, uint64_t n, uint64_t stride_flags, uint32_t slots,
+                                           int warmup, int reps, float* ms_total, uint64_t* out);
 
 /* ---- block files: the reference's `bench decompress -d` / `-D` callers ----
  * File format written by benchmark/flagstats.cpp:119-138 and read at :311-316: a sequence of

@@ -141,9 +141,9 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         if (value > 16) return fail_text("blocks_per_cu must be 0 (auto) .. 16");
         k.blocks_per_cu = static_cast<uint32_t>(value);
     } else if (!std::strcmp(key, "variant")) {
-        if (value > 127) return fail_text("variant must be 0..127");
+        if (value > 255) return fail_text("variant must be 0..255");
         if (!fsk_variant_supported(static_cast<int>(value)))
-            return fail_text("this build carries K1 schedules 9 and 25 only (the r01 sweep's losers need make TUNING=1)");
+            return fail_text("this build carries K1 schedules 9 and 25 only (the sweeps' losers need make TUNING=1)");
         k.variant = static_cast<int>(value);
     } else if (!std::strcmp(key, "fuse")) {
         if (value > 1) return fail_text("fuse must be 0 or 1");
@@ -156,6 +156,23 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
     } else if (!std::strcmp(key, "epilogue")) {
         if (value > 1) return fail_text("epilogue must be 0 (partials + K2) or 1 (atomic adds from K1)");
         k.epilogue = static_cast<int>(value);
+    } else if (!std::strcmp(key, "group_min_grid")) {
+        if (value > 0xFFFFFFFFull) return fail_text("group_min_grid must fit 32 bits");
+        k.group_min_grid = static_cast<uint32_t>(value);
+        fsk_set_group_min_grid(k.group_min_grid.load());
+    } else if (!std::strcmp(key, "dyn_lg_queues")) {
+        if (value > 4) return fail_text("dyn_lg_queues must be 0..4");
+        k.dyn_lgq = static_cast<uint32_t>(value);
+        fsk_set_dyn_queues(k.dyn_lgq.load());
+    } else if (!std::strcmp(key, "dyn_first_pct") || !std::strcmp(key, "dyn_div") || !std::strcmp(key, "dyn_cmax") ||
+               !std::strcmp(key, "dyn_min_steps")) {
+        // K1's dynamic schedule (variant bit 7, flagstat_kernels.h DynSched)
+        std::atomic<uint32_t>& slot = key[4] == 'f' ? k.dyn_first_pct : key[4] == 'd' ? k.dyn_div : key[4] == 'c' ? k.dyn_cmax : k.dyn_min_steps;
+        if ((key[4] == 'f' && value > 100) || (key[4] == 'd' && (value < 1 || value > 64)) || (key[4] == 'c' && (value < 1 || value > 65535)) ||
+            value > 0xFFFFFFFFull)
+            return fail_text("dyn_first_pct 0..100, dyn_div 1..64, dyn_cmax 1..65535");
+        slot = static_cast<uint32_t>(value);
+        fsk_set_dyn(k.dyn_first_pct.load(), k.dyn_div.load(), k.dyn_cmax.load(), k.dyn_min_steps.load());
     } else if (!std::strcmp(key, "chunk_flags")) {
         if (value < 8) return fail_text("chunk_flags must be >= 8");
         k.chunk_flags = value;
@@ -178,6 +195,12 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "blocks_per_cu")) return k.blocks_per_cu ? k.blocks_per_cu.load() : 1;
     if (!std::strcmp(key, "variant")) return static_cast<uint64_t>(k.variant.load());
     if (!std::strcmp(key, "chunk_flags")) return k.chunk_flags.load();
+    if (!std::strcmp(key, "dyn_first_pct")) return k.dyn_first_pct.load();
+    if (!std::strcmp(key, "dyn_div")) return k.dyn_div.load();
+    if (!std::strcmp(key, "dyn_cmax")) return k.dyn_cmax.load();
+    if (!std::strcmp(key, "dyn_min_steps")) return k.dyn_min_steps.load();
+    if (!std::strcmp(key, "dyn_lg_queues")) return k.dyn_lgq.load();
+    if (!std::strcmp(key, "group_min_grid")) return k.group_min_grid.load();
     if (!std::strcmp(key, "fuse")) return static_cast<uint64_t>(k.fuse.load());
     if (!std::strcmp(key, "epilogue")) return static_cast<uint64_t>(k.epilogue.load());
     if (!std::strcmp(key, "tuning_build")) return static_cast<uint64_t>(fsk_tuning_build());
@@ -443,6 +466,40 @@ int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmu
     return 0;
 }
 
+int FLAGSTATS_hip_time_device_u16_rotating(const uint16_t* d_array, uint64_t n, uint64_t stride_flags, uint32_t slots,
+                                           int warmup, int reps, float* ms_total, uint64_t* out)
+{
+    if (!ms_total || reps < 1 || warmup < 0 || slots < 1 || stride_flags < n || (stride_flags & 1)) return fail_text("bad timing arguments");
+    Engine* ep = engine_of_array(d_array, n);
+    if (!ep) return -1;
+    Engine& e = *ep;
+    std::lock_guard<std::mutex> lk(e.mu);
+    DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    hipStream_t s = e.stream[0];
+    EventPair ev;
+    int rc = ev.create();
+    if (rc) return rc;
+    auto slice = [&](int i) { return d_array + (static_cast<uint64_t>(i) * 7919u % slots) * stride_flags; };
+    for (int i = 0; i < warmup; ++i) {
+        rc = fsint::count_device_async(e, slice(reps + i), n, e.d_out[0], s, e.ws[0]);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), s));
+    HIP_TRY(hipEventRecord(ev.e0, s));
+    for (int i = 0; i < reps; ++i) {
+        rc = fsint::count_device_async(e, slice(i), n, e.d_out[0], s, e.ws[0]);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(ev.e1, s));
+    HIP_TRY(hipMemcpyAsync(e.h_out, e.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipEventElapsedTime(ms_total, ev.e0, ev.e1));
+    if (out)
+        for (int k = 0; k < 32; ++k) out[k] += e.h_out[k];
+    return 0;
+}
+
 /* ---- row f4: plain positional popcount (python/libalgebra.h:3496-3551) ---- */
 int FLAGSTATS_hip_pospopcnt_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
 {
@@ -489,7 +546,7 @@ static int probe_common(const void* d_buf, int warmup, int reps, float* ms_total
     if (!guard.ok()) return -1;
     hipStream_t s = e.stream[0];
     const uint32_t grid = grid_override ? grid_override : fsint::grid_for(e);
-    rc = fsint::ensure_ws(e.ws[0], fsint::grid_for(e));  // reuse the partials buffer as the (never written) sink
+    rc = fsint::ensure_ws(e.ws[0], fsint::grid_for(e), s);  // reuse the partials buffer as the (never written) sink
     if (rc) return rc;
     uint32_t* sink = reinterpret_cast<uint32_t*>(e.ws[0].partials);
     EventPair ev;

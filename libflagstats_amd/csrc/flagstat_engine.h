@@ -30,6 +30,8 @@ struct Workspace {
 struct Knobs {
     std::atomic<uint32_t> blocks_per_cu{0};       // 0 = auto (1)
     std::atomic<int> variant{25};                 // K1 schedule, see flagstat_kernels.hip
+    std::atomic<uint32_t> dyn_first_pct{75}, dyn_div{4}, dyn_cmax{32}, dyn_min_steps{32}, dyn_lgq{3};  // dynamic schedule (variant bit 7)
+    std::atomic<uint32_t> group_min_grid{64};     // K1's atomic epilogue goes through per-XCD copies from this many workgroups on
     std::atomic<int> fuse{0};                     // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
     std::atomic<int> epilogue{1};                 // accumulate form into device memory: 1 = K1 adds its workgroup totals to
                                                   // out[] with atomics (one launch), 0 = partials + K2
@@ -107,7 +109,7 @@ int check_stream_device(hipStream_t s, int device);
 int stream_wait_stream(Engine& e, hipStream_t waiter, hipStream_t on);
 
 uint32_t grid_for(const Engine& e);
-int ensure_ws(Workspace& w, uint32_t grid);
+int ensure_ws(Workspace& w, uint32_t grid, hipStream_t s);  // zeroed (stream-ordered on s) at creation
 // K1 + K2 on `s`: d_out += (or =, OP_FLAGSTAT_STORE) counters of d_array[0..n).  Device must be current.
 int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w,
                        int op = OP_FLAGSTAT);

@@ -42,6 +42,15 @@ void read_env_knobs()
         g_knobs.blocks_per_cu = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_BLOCKS_PER_CU", g_knobs.blocks_per_cu));
         g_knobs.variant = static_cast<int>(env_u64("FLAGSTATS_HIP_VARIANT", static_cast<uint64_t>(g_knobs.variant)));
         g_knobs.chunk_flags = env_u64("FLAGSTATS_HIP_CHUNK_FLAGS", g_knobs.chunk_flags);
+        g_knobs.dyn_first_pct = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_FIRST_PCT", g_knobs.dyn_first_pct));
+        g_knobs.dyn_div = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_DIV", g_knobs.dyn_div));
+        g_knobs.dyn_cmax = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_CMAX", g_knobs.dyn_cmax));
+        g_knobs.dyn_min_steps = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_MIN_STEPS", g_knobs.dyn_min_steps));
+        g_knobs.group_min_grid = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_GROUP_MIN_GRID", g_knobs.group_min_grid));
+        fsk_set_group_min_grid(g_knobs.group_min_grid.load());
+        g_knobs.dyn_lgq = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_LG_QUEUES", g_knobs.dyn_lgq));
+        fsk_set_dyn_queues(g_knobs.dyn_lgq.load());
+        fsk_set_dyn(g_knobs.dyn_first_pct.load(), g_knobs.dyn_div.load(), g_knobs.dyn_cmax.load(), g_knobs.dyn_min_steps.load());
         g_knobs.fuse = fsk_tuning_build() ? static_cast<int>(env_u64("FLAGSTATS_HIP_FUSE", static_cast<uint64_t>(g_knobs.fuse))) : 0;
         g_knobs.epilogue = static_cast<int>(env_u64("FLAGSTATS_HIP_EPILOGUE", static_cast<uint64_t>(g_knobs.epilogue)));
         g_knobs.numa = static_cast<int>(env_u64("FLAGSTATS_HIP_NUMA", static_cast<uint64_t>(g_knobs.numa)));
@@ -119,7 +128,7 @@ int engine_setup(Engine& e, int device)
     e.numa_node = numa_node_of_device(device);
     for (int i = 0; i < 2; ++i) {
         HIP_TRY(hipStreamCreateWithFlags(&e.stream[i], hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&e.d_out[i], 32 * sizeof(uint64_t)));
+        HIP_TRY(hipMalloc(&e.d_out[i], 4096));  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
         HIP_TRY(hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming));
     }
     HIP_TRY(hipHostMalloc(&e.h_out, 2 * 32 * sizeof(uint64_t), hipHostMallocDefault));
@@ -356,22 +365,24 @@ uint32_t grid_for(const Engine& e)
     return static_cast<uint32_t>(e.cus) * (bpc ? bpc : 1);
 }
 
-int ensure_ws(Workspace& w, uint32_t grid)
+int ensure_ws(Workspace& w, uint32_t grid, hipStream_t s)
 {
     if (w.grid_cap >= grid) return 0;
-    if (w.partials) {
-        HIP_TRY(hipDeviceSynchronize());  // launches that still use the old workspace
-        HIP_TRY(hipFree(w.partials));
-    }
+    if (w.partials) HIP_TRY(hipFree(w.partials));  // (grid knob raised) hipFree waits for the launches that still use it
     w.partials = nullptr;
     w.grid_cap = 0;
-    HIP_TRY(hipMalloc(&w.partials, fsk_partials_bytes(grid)));
-    HIP_TRY(hipMemset(w.partials, 0, fsk_partials_bytes(grid)));  // the ticket word must start at 0
-    // hipMemset on device memory runs on the NULL stream and may return before it has run; the engines'
-    // streams are non-blocking (they do not order against the NULL stream), so without this wait the
-    // memset could land AFTER the first K1 had stored its partials -- whole 4 KiB pages of them read back
-    // as zero by K2 (seen once in tests/test_gpu_multi.py on a freshly created engine).
-    HIP_TRY(hipDeviceSynchronize());
+    // a first call may arrive while its stream is being captured into a graph: an allocation is legal there only
+    // in the relaxed capture mode (it is not a stream operation; the memset below becomes a node of the graph)
+    hipStreamCaptureMode mode = hipStreamCaptureModeRelaxed;
+    const bool swapped = hipThreadExchangeStreamCaptureMode(&mode) == hipSuccess;
+    const hipError_t err = hipMalloc(&w.partials, fsk_partials_bytes(grid));
+    if (swapped) (void)hipThreadExchangeStreamCaptureMode(&mode);
+    if (err != hipSuccess) return fail_hip("hipMalloc(workspace)", err);
+    // The block behind the partials (K1's schedule counter, the tuning build's ticket) must be zero before the
+    // first launch.  Stream-ordered on the LAUNCHING stream: no device-wide wait, other streams keep running.
+    // (r02 used hipMemset + two hipDeviceSynchronize here: the NULL-stream memset is not ordered against the
+    // engines' non-blocking streams, and the waits stalled every other stream on a caller's first call.)
+    HIP_TRY(hipMemsetAsync(w.partials, 0, fsk_partials_bytes(grid), s));
     w.grid_cap = grid;
     return 0;
 }
@@ -386,7 +397,7 @@ int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t*
     if (!d_array) return fail_text("NULL array with n > 0");
     if (reinterpret_cast<uintptr_t>(d_array) & 1u) return fail_text("array must be 2-byte aligned");
     const uint32_t grid = grid_for(e);
-    int rc = ensure_ws(w, grid);
+    int rc = ensure_ws(w, grid, s);
     if (rc) return rc;
     if (base == OP_POSPOPCNT) {
         HIP_TRY(fsk_launch_pospopcnt(d_array, n, grid, w.partials, d_out, s, (!(op & OP_HOST_OUT) && g_knobs.epilogue.load()) ? 1 : 0));

@@ -11,7 +11,22 @@ namespace fsk {
 constexpr int kThreads = 256;                       // 4 waves per workgroup
 constexpr int kUnroll = 8;                          // 16-B vectors per lane per step
 constexpr int kVecPerStep = kThreads * kUnroll;     // 2048 vectors = 32 KiB = 16384 flags
+constexpr int kGroupTicketWord = 288;               // workspace block (u64 words): 8 group tickets, 16 words apart
+constexpr int kGroupCopyWord = 512;                 // ... and 8 copies of the 32 slots (flagstat_kernels.hip: grouped_epilogue)
 constexpr int kInternal = 21;                       // 19 live counters (libflagstats.h:118-142) + primary-paired reads x {pass, fail}
+
+// K1's dynamic schedule (STAGE 4): round 0 = c0 grid-stride steps per workgroup; the rest is cut into 2^lgq queues,
+// each handed out in contiguous chunks of remaining / (workgroups per queue * div) steps (inv = 2^32 / that divisor),
+// clamped to [1, cmax].  block = the workspace's 4 KiB block: u64 word 8 counts retired workgroups, word 16 * (i + 1)
+// is queue i's counter (the last workgroup to retire zeroes them).  c0 * grid >= the number of full steps: fully
+// static, block untouched.
+struct DynSched {
+    uint64_t* block;
+    uint32_t c0;
+    uint32_t inv;
+    uint32_t cmax;
+    uint32_t lgq;
+};
 
 struct CountArgs {
     const void* a0;        // 16-B aligned-down base of the array
@@ -23,8 +38,10 @@ struct CountArgs {
     uint64_t* partials;    // [kInternal][grid]
     uint32_t* ticket;      // non-null: fused finalise by the last-arriving workgroup (must be 0 at launch)
     uint64_t* out;         // device uint64[32]
+    DynSched dyn;
     int mode;              // bit 0: out = counters instead of +=; bit 1: superset slots (0/16 n_pair_all, 9 pass-QC reads);
-                           // bit 2: direct epilogue -- every workgroup adds its totals to out[] with atomics, no K2
+                           // bit 2: direct epilogue -- every workgroup adds its totals to out[] with atomics, no K2;
+                           // bit 3 (with bit 2): through the workspace's per-XCD copies (grouped_epilogue)
 };
 
 }  // namespace fsk
@@ -33,11 +50,17 @@ extern "C" {
 // bytes of workspace K1 needs for `grid` workgroups
 size_t fsk_partials_bytes(uint32_t grid);
 // K1 + K2 on `stream`: d_out32[32] += counters of d_array[0..n).  Asynchronous.
-// variant bits 0-6: K1 schedule; bit 8: store instead of accumulate; bit 9: fused finalise (needs d_ticket);
+// variant bits 0-7: K1 schedule; bit 8: store instead of accumulate; bit 9: fused finalise (needs d_ticket);
 // bit 10: superset slots; bit 11: direct atomic epilogue (accumulate form only; K1 alone, no K2)
 hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
                       uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream);
 int fsk_variant_supported(int variant);   // K1 schedule compiled into this build?
+// dynamic schedule policy (variant bit 7): first_pct = share of the steps in the static round 0 (0..100), div and cmax
+// as in DynSched; arrays of fewer than min_steps_per_wg full steps per workgroup stay fully static
+void fsk_set_dyn(uint32_t first_pct, uint32_t div, uint32_t cmax, uint32_t min_steps_per_wg);
+void fsk_set_dyn_queues(uint32_t lg_queues);
+// K1's direct epilogue adds to per-XCD copies first when the grid has at least this many workgroups (0: always)
+void fsk_set_group_min_grid(uint32_t min_grid);   // 2^lg_queues (<= 16) counters
 void fsk_set_anatomy(int bits);           // tuning builds only: skip parts of K1 to time the rest (results wrong)
 int fsk_tuning_build(void);               // 1: built with -DFLAGSTAT_TUNING_VARIANTS (make TUNING=1)
 // positional popcount (flagstat_pospopcnt.hip): d_out16[16] += bit counts.  d_partials as for fsk_launch.

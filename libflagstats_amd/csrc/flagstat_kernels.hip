@@ -45,6 +45,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "flagstat_device.h"
 #include "flagstat_kernels.h"
 
@@ -237,63 +239,92 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
     chain_push<0, DEPTH>(s, blk, ct, cf, cs);
 }
 
-// Flush: fold every plane into the 21 u32 lane counters and clear them.  `pushed` = steps pushed
-// since the last flush (wave-uniform): chain level j can hold a carry only after 2^j steps, so a
-// short run (a mid-size array leaves each workgroup a few dozen steps) skips the empty upper levels
-// with scalar branches -- the flush is ~1300 VALU ops at full depth, paid once per kernel, and is
-// part of the fixed cost that keeps sub-GiB launches off the roofline.
+// Flush: fold every plane into the 21 u32 lane counters and clear them.  `pushed` = steps pushed since the last
+// flush (wave-uniform): chain level j can hold something only after 2^j steps, so a short run (a mid-size array
+// leaves each workgroup a few dozen steps) skips the empty upper levels with scalar branches.  The flush is paid once
+// per epoch and once at the end of the kernel, where nothing hides it (every wave of the chip flushes at the same
+// time with HBM idle: tools/timeline.py), so it is built to be short:
+//   1. carry-propagate: level j holds TWO planes of weight 16 << j (accumulator, pending); one CSA per level with the
+//      carry from below turns the chain into plain binary -- ONE plane per weight, 12 planes instead of 20 (a column
+//      holds at most 16 * 255 + 15 = 4095, so nothing is carried out of the top level);
+//   2. per (plane, counter) two VALU ops: v_and_b32 selects the counter's bit in each of the 4 flag bytes and
+//      v_dot4_u32_u8 adds the 4 bytes times the plane's weight to the counter's accumulator -- the multiply-add does
+//      the weighting, there is no Horner doubling (r02: and + shift + bcnt = 3 ops on 20 planes, 1260 ops; now 594).
+//      A selected byte is 0 or 2^c, so counter c accumulates 2^c times its count (shifted out at the end); weights
+//      256..2048 enter with weights 1..8 before the accumulator is shifted left by 8.
+__device__ __forceinline__ uint32_t wdot(uint32_t acc, uint32_t plane, uint32_t mask, uint32_t weight_bytes)
+{
+    return __builtin_amdgcn_udot4(plane & mask, weight_bytes, acc, false);
+}
+
 template <int DEPTH>
 __device__ __forceinline__ void flush(Lane<DEPTH>& s, uint32_t pushed)
 {
+    static_assert(DEPTH >= 5 && DEPTH <= 8, "weights 16 << j are split at j = 4 (256) and must stay below 4096");
     constexpr int NS = kInternal - 16;
+    // 1. chain -> binary: tA[j] becomes THE plane of weight 16 << j
+    {
+        uint32_t ct = 0, cf = 0, cs = 0;
+#pragma unroll
+        for (int j = 0; j < DEPTH; ++j) {
+            if (pushed >> j) {
+                csa(ct, s.tA[j], s.tA[j], s.tB[j], ct);
+                csa(cf, s.fA[j], s.fA[j], s.fB[j], cf);
+                csa(cs, s.sA[j], s.sA[j], s.sB[j], cs);
+                s.tB[j] = s.fB[j] = s.sB[j] = 0;
+            }
+        }
+    }
+    // 2. planes -> counters
     uint32_t at[8], af[8], as[NS];
 #pragma unroll
     for (int c = 0; c < 8; ++c) at[c] = af[c] = 0;
 #pragma unroll
     for (int c = 0; c < NS; ++c) as[c] = 0;
+    auto fold = [&](uint32_t pt, uint32_t pf, uint32_t ps, uint32_t w) {
+        const uint32_t wb = w * 0x01010101u;
 #pragma unroll
-    for (int j = DEPTH - 1; j >= 0; --j) {
-        if (pushed >= (1u << j)) {
+        for (int c = 0; c < 8; ++c) {
+            at[c] = wdot(at[c], pt, 0x01010101u << c, wb);
+            af[c] = wdot(af[c], pf, 0x01010101u << c, wb);
+        }
 #pragma unroll
-            for (int c = 0; c < 8; ++c) {
-                const uint32_t mk = 0x01010101u << c;
-                at[c] = hstep(at[c], s.tA[j], mk, true);
-                at[c] = hstep(at[c], s.tB[j], mk, false);
-                af[c] = hstep(af[c], s.fA[j], mk, true);
-                af[c] = hstep(af[c], s.fB[j], mk, false);
-            }
+        for (int c = 0; c < NS; ++c) as[c] = wdot(as[c], ps, 0x01010101u << (c < 3 ? c : c + 3), wb);  // S bits 0,1,2 and 6,7
+    };
 #pragma unroll
-            for (int c = 0; c < NS; ++c) {
-                const uint32_t mk = 0x01010101u << (c < 3 ? c : c + 3);  // S bits 0,1,2 and 6,7
-                as[c] = hstep(as[c], s.sA[j], mk, true);
-                as[c] = hstep(as[c], s.sB[j], mk, false);
-            }
-            s.tA[j] = s.tB[j] = s.fA[j] = s.fB[j] = s.sA[j] = s.sB[j] = 0;
+    for (int j = DEPTH - 1; j >= 4; --j) {  // weights 256 << (j - 4), entered as 1 << (j - 4)
+        if (pushed >> j) {
+            fold(s.tA[j], s.fA[j], s.sA[j], 1u << (j - 4));
+            s.tA[j] = s.fA[j] = s.sA[j] = 0;
         }
     }
+    if (pushed >> 4) {
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            at[c] <<= 8;
+            af[c] <<= 8;
+        }
+#pragma unroll
+        for (int c = 0; c < NS; ++c) as[c] <<= 8;
+    }
+#pragma unroll
+    for (int j = 3; j >= 0; --j) {  // weights 16 << j
+        if (pushed >> j) {
+            fold(s.tA[j], s.fA[j], s.sA[j], 16u << j);
+            s.tA[j] = s.fA[j] = s.sA[j] = 0;
+        }
+    }
+    fold(s.t8, s.f8, s.s8, 8u);
+    fold(s.t4, s.f4, s.s4, 4u);
+    fold(s.t2, s.f2, s.s2, 2u);
+    fold(s.t1, s.f1, s.s1, 1u);
 #pragma unroll
     for (int c = 0; c < 8; ++c) {
-        const uint32_t mk = 0x01010101u << c;
-        at[c] = hstep(at[c], s.t8, mk, true);
-        at[c] = hstep(at[c], s.t4, mk, true);
-        at[c] = hstep(at[c], s.t2, mk, true);
-        at[c] = hstep(at[c], s.t1, mk, true);
-        af[c] = hstep(af[c], s.f8, mk, true);
-        af[c] = hstep(af[c], s.f4, mk, true);
-        af[c] = hstep(af[c], s.f2, mk, true);
-        af[c] = hstep(af[c], s.f1, mk, true);
-        s.acc[c] += at[c];
-        s.acc[8 + c] += af[c];
+        s.acc[c] += at[c] >> c;
+        s.acc[8 + c] += af[c] >> c;
     }
 #pragma unroll
-    for (int c = 0; c < NS; ++c) {
-        const uint32_t mk = 0x01010101u << (c < 3 ? c : c + 3);
-        as[c] = hstep(as[c], s.s8, mk, true);
-        as[c] = hstep(as[c], s.s4, mk, true);
-        as[c] = hstep(as[c], s.s2, mk, true);
-        as[c] = hstep(as[c], s.s1, mk, true);
-        s.acc[16 + c] += as[c];
-    }
+    for (int c = 0; c < NS; ++c) s.acc[16 + c] += as[c] >> (c < 3 ? c : c + 3);
     s.t1 = s.t2 = s.t4 = s.t8 = 0;
     s.f1 = s.f2 = s.f4 = s.f8 = 0;
     s.s1 = s.s2 = s.s4 = s.s8 = 0;
@@ -309,26 +340,33 @@ __device__ __forceinline__ void flush(Lane<DEPTH>& s, uint32_t pushed)
 // Without bit 1 the 32 slots are exactly FLAGSTAT_scalar's (libflagstats.h:118-142).
 // ATOMIC (K1's direct epilogue): tot[] are ONE workgroup's totals, added with relaxed agent-scope
 // atomics -- any number of launches, on any streams, may target the same out[32].
+// what thread t < 32 contributes to slot t
+__device__ __forceinline__ uint64_t slot_value(const uint64_t* tot, int mode, uint64_t n_flags)
+{
+    // reference slot -> internal T index (secondary, n_pair_good, unmap, supplementary,
+    // n_sgltn, n_pair_map, read1, read2), -1 = slot has no T/F counter
+    const int t_of_slot[16] = {-1, -1, 2, -1, -1, -1, 6, 7, 0, -1, -1, 3, 1, 4, 5, -1};
+    const uint32_t slot = threadIdx.x & 15u;
+    const bool fail = threadIdx.x >= 16;
+    uint64_t add = 0;
+    const int t = t_of_slot[slot];
+    if (t >= 0) add = fail ? tot[8 + t] : tot[t] - tot[8 + t];  // pass-QC = all - fail
+    if (slot == 10) add = fail ? tot[18] : tot[17];              // DUP: fail / pass
+    if (slot == 9 && fail) add = tot[16] + tot[18];              // fail-QC read count (slot 25)
+    if (mode & 2) {
+        if (slot == 0) add = fail ? tot[20] : tot[19];
+        // ATOMIC: n_flags is the launch's flag count in workgroup 0 and 0 elsewhere; the partial
+        // sums wrap modulo 2^64 and the total over all workgroups is len - fail-QC reads
+        if (slot == 9 && !fail) add = n_flags - (tot[16] + tot[18]);
+    }
+    return add;
+}
+
 template <bool ATOMIC = false>
 __device__ __forceinline__ void finalize_slots(const uint64_t* tot, uint64_t* __restrict__ out, int mode, uint64_t n_flags)
 {
     if (threadIdx.x < 32) {
-        // reference slot -> internal T index (secondary, n_pair_good, unmap, supplementary,
-        // n_sgltn, n_pair_map, read1, read2), -1 = slot has no T/F counter
-        const int t_of_slot[16] = {-1, -1, 2, -1, -1, -1, 6, 7, 0, -1, -1, 3, 1, 4, 5, -1};
-        const uint32_t slot = threadIdx.x & 15u;
-        const bool fail = threadIdx.x >= 16;
-        uint64_t add = 0;
-        const int t = t_of_slot[slot];
-        if (t >= 0) add = fail ? tot[8 + t] : tot[t] - tot[8 + t];  // pass-QC = all - fail
-        if (slot == 10) add = fail ? tot[18] : tot[17];              // DUP: fail / pass
-        if (slot == 9 && fail) add = tot[16] + tot[18];              // fail-QC read count (slot 25)
-        if (mode & 2) {
-            if (slot == 0) add = fail ? tot[20] : tot[19];
-            // ATOMIC: n_flags is the launch's flag count in workgroup 0 and 0 elsewhere; the partial
-            // sums wrap modulo 2^64 and the total over all workgroups is len - fail-QC reads
-            if (slot == 9 && !fail) add = n_flags - (tot[16] + tot[18]);
-        }
+        const uint64_t add = slot_value(tot, mode, n_flags);
         if constexpr (ATOMIC) {
             if (add) (void)__hip_atomic_fetch_add(&out[threadIdx.x], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
@@ -338,6 +376,39 @@ __device__ __forceinline__ void finalize_slots(const uint64_t* tot, uint64_t* __
                 out[threadIdx.x] += add;       // reference contract: accumulate, never touch dead slots
         }
     }
+}
+
+// K1's direct epilogue for grids of many workgroups.  256 workgroups adding to the caller's two cache lines at the
+// same moment is what a mid-size launch ends with, and those lines then bounce between the 8 XCDs' L2s once per
+// request: ~10 ns each, 3.4-4.6 us of every launch with HBM idle (profiles/r03/launch_anatomy_*.log: the same adds
+// spread over 8 per-XCD copies cost nothing measurable).  So the adds go in two levels: workgroup b adds its slots to
+// copy b % 8 of the workspace (blockIdx.x % 8 is the XCD a workgroup runs on, so a copy's lines stay in ONE L2), waits
+// until those adds have been performed (vmcnt counts an atomic until the L2 has done it), then draws a ticket of its
+// group; the group's last workgroup swaps the copy's 32 words for zero -- which leaves the workspace ready for the
+// next launch -- and adds them to the caller's out[32]: 8 x 2 contended requests per launch instead of 256 x 2.
+// Every access to the copies and tickets is a device-scope atomic, so the result does not depend on the
+// blockIdx -> XCD mapping, only the speed does.
+__device__ __forceinline__ void grouped_epilogue(const uint64_t* tot, uint64_t* __restrict__ out, int mode, uint64_t n_flags,
+                                                 uint64_t* __restrict__ block)
+{
+    if (threadIdx.x >= 64) return;  // wave 0 (every lane of it, so the scalar branches below are wave-uniform)
+    const uint32_t g = blockIdx.x & 7u;
+    const uint32_t members = (gridDim.x - g + 7u) >> 3;  // workgroups b < gridDim.x with b % 8 == g
+    uint64_t* copy = block + kGroupCopyWord + 32 * g;
+    uint64_t* ticket = block + kGroupTicketWord + 16 * g;
+    const uint64_t add = threadIdx.x < 32 ? slot_value(tot, mode, n_flags) : 0;
+    if (add) (void)__hip_atomic_fetch_add(&copy[threadIdx.x], add, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this workgroup's adds are in the copy
+    uint32_t t = 0;
+    if (threadIdx.x == 0) t = static_cast<uint32_t>(__hip_atomic_fetch_add(ticket, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    t = __builtin_amdgcn_readfirstlane(t);
+    if (t != members - 1) return;
+    // last of the group: every member's adds were performed before its ticket add, and all of those before this one
+    if (threadIdx.x < 32) {
+        const uint64_t v = __hip_atomic_exchange(&copy[threadIdx.x], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (v) (void)__hip_atomic_fetch_add(&out[threadIdx.x], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x == 0) __hip_atomic_store(ticket, 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // ------------------------------------------------------------------ K1
@@ -375,11 +446,22 @@ __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnrol
 // step k+1 are in flight while step k is computed (one more 8 KiB per wave in
 // flight, +32 VGPRs).
 template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE>
-__global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
+__global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
                                                            uint64_t* __restrict__ partials, uint32_t* ticket,
-                                                           uint64_t* out, int mode)
+                                                           uint64_t* out, int mode, DynSched dyn)
 {
+#ifdef FLAGSTAT_TUNING_VARIANTS
+    // workgroup timeline (tools/timeline.py; mode bit 11): wave 0 stamps the 100 MHz wall clock at entry, after its
+    // first step, after its last step, after the final flush, after the workgroup reduction and at exit
+    uint64_t tl[6] = {0, 0, 0, 0, 0, 0};
+#define FSK_TL(i) do { if (mode & 2048) tl[i] = wall_clock64(); } while (0)
+#define FSK_TL_ONCE(i) do { if ((mode & 2048) && tl[i] == 0) tl[i] = wall_clock64(); } while (0)
+#else
+#define FSK_TL(i) do { } while (0)
+#define FSK_TL_ONCE(i) do { } while (0)
+#endif
+    FSK_TL(0);
     Lane<DEPTH> s;
     lane_init(s);
     const uint32_t lane = threadIdx.x & 63u;
@@ -395,12 +477,12 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
     if constexpr (ROLL) {
         // ragged edge steps (at most the first and the last of the whole array) go through the
         // guarded loader, outside the pipelined loop
-        if (fast_begin != 0 && blockIdx.x == 0) {
+        if (fast_begin != 0 && blockIdx.x == 0 && wave < kThreads / 64) {
             uint4 v[kUnroll];
             load_step<NT, US>(v, a0, 0, lane_off, lo, hi, fast_begin, fast_end);
             step_and_count(s, v, blk);
         }
-        if (nsteps > fast_end && nsteps - 1 >= fast_begin && (nsteps - 1) % G == blockIdx.x) {
+        if (nsteps > fast_end && nsteps - 1 >= fast_begin && (nsteps - 1) % G == blockIdx.x && wave < kThreads / 64) {
             uint4 v[kUnroll];
             load_step<NT, US>(v, a0, nsteps - 1, lane_off, lo, hi, fast_begin, fast_end);
             step_and_count(s, v, blk);
@@ -421,8 +503,128 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
                 for (; st + G < fast_end; st += G) {
                     p += G * kVecPerStep;
                     step_and_count<DEPTH, 1, NT, US>(s, v, blk, p);
+                    FSK_TL_ONCE(1);
                 }
                 step_and_count(s, v, blk);
+                FSK_TL_ONCE(1);
+            }
+        } else if constexpr (STAGE == 4) {
+            // Rolling registers + GUIDED SELF-SCHEDULING of the fully in-range steps (q-space [0, N), step = fast_begin + q).
+            // Why: the XCDs do not read HBM equally fast, and which one is slow changes from launch to launch
+            // (tools/timeline.py, profiles/r03/timeline_*.log: with the static grid-stride split the last workgroup
+            // finishes 3-11 % after the median one while the early finishers' share of the bandwidth goes unused).
+            // Round 0 is static and grid-stride like STAGE 1 (workgroup b: q = b, b+G, ... c0 steps, no atomics, no
+            // barrier); the rest is handed out in contiguous chunks through ONE device counter, chunk size =
+            // remaining / (G * div) clamped to [1, cmax], so the grabs get finer towards the end and every
+            // workgroup stops within about one step of the others.
+            // The grabs are made by a FIFTH wave (threads 256..319) that does nothing else: a returning atomic in a
+            // worker wave either drains that wave's 8 loads in flight (the compiler waits for the result with
+            // vmcnt(0), at the loop header of every step once the value is carried around the loop) or, issued behind
+            // the compiler's back, has its result register copied while the atomic is still in flight (both seen in
+            // the ISA).  The scheduler wave stays two chunks ahead: slot k & 3 of an LDS ring holds chunk k (start,
+            // length), written before barrier k-1; at a chunk boundary every wave of the workgroup meets in ONE
+            // s_barrier (LDS-only wait on the worker side: their loads in flight are not drained) and the workers
+            // read slot k.  The counters reset themselves: the scheduler retires with an add to a "retired" word
+            // after its last grab has returned, and the last workgroup to retire zeroes every word (launches sharing
+            // a workspace are stream-ordered).
+            const uint64_t N = fast_end - fast_begin;
+            const uint64_t c0 = dyn.c0;
+            const uint64_t D0 = G * c0;
+            const bool dynamic = N > D0;  // grid-uniform
+            __shared__ uint64_t tix[4];
+            if (wave == kThreads / 64) {
+                if (dynamic) {
+                    // The dynamic region [D0, N) is cut into Q = 2^lgq equal queues, each with its own counter on its
+                    // own cache line: same-address atomics retire at ~10 ns each, and 256 workgroups asking once per
+                    // step (one step of the whole chip = 4.6 ns) would be bound by that.  Workgroup b is served by
+                    // queue (b / 8) % Q: blockIdx.x % 8 is the XCD, so every queue serves the same mix of fast and
+                    // slow XCDs, the queues drain at the same rate, and a workgroup whose queue is empty is done.
+                    const uint32_t lgq = dyn.lgq;
+                    const uint64_t M = N - D0;
+                    const uint32_t qi = (blockIdx.x >> 3) & ((1u << lgq) - 1u);
+                    const uint64_t qb = D0 + ((M * qi) >> lgq), qe = D0 + ((M * (qi + 1)) >> lgq);
+                    uint64_t* ctr = dyn.block + 16 * (qi + 1);
+                    uint64_t start[4] = {0, 0, 0, 0};  // what slot k & 3 holds (uniform: read back through readfirstlane)
+                    uint64_t pos = qb;                 // latest known position of the queue
+                    auto grab = [&](uint32_t k) {
+                        const uint64_t rem = pos < qe ? qe - pos : 0;
+                        const uint32_t r32 = rem > 0xFFFFFFFFull ? 0xFFFFFFFFu : static_cast<uint32_t>(rem);
+                        uint32_t c = __umulhi(r32, dyn.inv);  // rem / (workgroups per queue * div)
+                        c = c < 1u ? 1u : c;
+                        c = c > dyn.cmax ? dyn.cmax : c;
+                        uint64_t r = 0;
+                        if (lane == 0) r = __hip_atomic_fetch_add(ctr, static_cast<uint64_t>(c), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        const uint32_t rl = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(r));
+                        const uint32_t rh = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(r >> 32));
+                        uint64_t st = qb + ((static_cast<uint64_t>(rh) << 32) | rl);
+                        uint64_t len = c;
+                        if (st >= qe) {
+                            st = N;  // the queue is empty: tells the workers (and this wave) to stop
+                            len = 0;
+                        } else if (len > qe - st) {
+                            len = qe - st;
+                        }
+                        if (lane == 0) tix[k & 3u] = st | (len << 48);
+                        start[k & 3u] = st;
+                        pos = st + c;
+                    };
+                    grab(1);
+                    grab(2);
+                    for (uint32_t k = 1;; ++k) {
+                        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // barrier k: slot k is readable
+                        if (start[k & 3u] >= N) break;
+                        grab(k + 2);
+                    }
+                    if (lane == 0) {
+                        const uint64_t d = __hip_atomic_fetch_add(&dyn.block[8], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if (d == G - 1) {
+                            for (uint32_t i = 0; i < (1u << lgq); ++i)
+                                __hip_atomic_store(&dyn.block[16 * (i + 1)], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&dyn.block[8], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        }
+                    }
+                }
+            } else {
+                uint64_t q = blockIdx.x;
+                uint64_t left = q < N ? (N - q + G - 1) / G : 0;  // steps of round 0 for this workgroup
+                if (left > c0) left = c0;
+                uint64_t stride = G;
+                if (left) {
+                    uint4 v[kUnroll];
+                    const uint4* p = a0 + (fast_begin + q) * kVecPerStep + lane_off;
+#pragma unroll
+                    for (int u = 0; u < kUnroll; ++u) {
+                        v[u] = load_vec<NT>(p + u * US);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    uint32_t k = 1;
+                    for (;;) {
+                        uint64_t nq;
+                        if (left > 1) {
+                            nq = q + stride;
+                            --left;
+                        } else {
+                            if (!dynamic) break;
+                            asm volatile("s_barrier" ::: "memory");  // barrier k
+                            const uint64_t t = tix[k & 3u];
+                            ++k;
+                            const uint32_t tl_ = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(t));
+                            const uint32_t th_ = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(t >> 32));
+                            const uint64_t ns = (static_cast<uint64_t>(th_ & 0xFFFFu) << 32) | tl_;
+                            if (ns >= N) break;
+                            nq = ns;
+                            left = th_ >> 16;
+                            if (left > N - ns) left = N - ns;
+                            stride = 1;
+                        }
+                        p = a0 + (fast_begin + nq) * kVecPerStep + lane_off;
+                        step_and_count<DEPTH, 1, NT, US>(s, v, blk, p);
+                        FSK_TL_ONCE(1);
+                        q = nq;
+                    }
+                    step_and_count(s, v, blk);
+                    FSK_TL_ONCE(1);
+                }
             }
         } else if constexpr (STAGE == 3) {
             // Rolling at distance 2: two register buffers, each vector's re-issue targets the lane's
@@ -504,6 +706,7 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
             st += G;
         }
     }
+    FSK_TL(2);
 #ifdef FLAGSTAT_TUNING_VARIANTS
     // launch anatomy (tools/launch_anatomy.py; timing only, results are wrong): bit 9 skips the final
     // flush, bit 10 everything after it
@@ -518,13 +721,14 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
 #else
     flush(s, blk);
 #endif
+    FSK_TL(3);
 
     // wave sums on the VALU (DPP), then the 4 waves through LDS
     __shared__ uint32_t red[kThreads / 64][kInternal];
     uint32_t wsum[kInternal];
 #pragma unroll
     for (int c = 0; c < kInternal; ++c) wsum[c] = wave_sum_lane63(s.acc[c]);
-    if (lane == 63) {
+    if (lane == 63 && wave < kThreads / 64) {  // (the dynamic schedule's scheduler wave counts nothing)
 #pragma unroll
         for (int c = 0; c < kInternal; ++c) red[wave][c] = wsum[c];
     }
@@ -542,7 +746,25 @@ __global__ __launch_bounds__(kThreads) void flagstat_count(const uint4* __restri
         __shared__ uint64_t wg_tot[32];
         if (threadIdx.x < kInternal) wg_tot[threadIdx.x] = sum;
         __syncthreads();
-        finalize_slots<true>(wg_tot, out, mode, blockIdx.x == 0 ? hi - lo : 0);
+        FSK_TL(4);
+#ifdef FLAGSTAT_TUNING_VARIANTS
+        // anatomy bit 3 (timing only, results land in 8 copies): workgroup b adds to copy b % 8 -- its XCD's own -- of
+        // out[8][32]: how much of the epilogue is the same two cache lines bouncing between the 8 L2s?
+        if (mode & 4096) out += 32 * (blockIdx.x & 7u);
+#endif
+        if (mode & 8)
+            grouped_epilogue(wg_tot, out, mode, blockIdx.x == 0 ? hi - lo : 0, dyn.block);
+        else
+            finalize_slots<true>(wg_tot, out, mode, blockIdx.x == 0 ? hi - lo : 0);
+#ifdef FLAGSTAT_TUNING_VARIANTS
+        if ((mode & 2048) && threadIdx.x == 0) {
+            uint64_t* row = reinterpret_cast<uint64_t*>(ticket) + static_cast<uint64_t>(blockIdx.x) * 8;
+            for (int i = 0; i < 5; ++i) row[i] = tl[i];
+            row[5] = wall_clock64();
+            row[6] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 20);  // XCC_ID
+            row[7] = __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);   // HW_ID
+        }
+#endif
         return;
     }
     if (threadIdx.x < kInternal) {
@@ -644,19 +866,40 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
 }  // namespace fsk
 
 // ------------------------------------------------------------------ launchers
-// partials[19][grid] followed by a 256-byte block holding the hand-off ticket
-extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 256; }
+// partials[21][grid] followed by an 8 KiB block (u64 words): word 0 the hand-off ticket of the tuning build's fused
+// finalise, 8 the dynamic schedule's "retired workgroups" word, 16 * (i + 1) the counter of its queue i (up to 16, one
+// cache line each), kGroupTicketWord + 16 * g the ticket of epilogue group g, kGroupCopyWord + 32 * g that group's
+// copy of the 32 slots.  The block must be zero before the first launch and is left zero by every launch.
+extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 8192; }
+
+static std::atomic<uint32_t> g_group_min_grid{64};  // grids below this add straight to out[] (one level)
+
+extern "C" void fsk_set_group_min_grid(uint32_t min_grid) { g_group_min_grid = min_grid; }
+
+static std::atomic<uint32_t> g_dyn_first_pct{75}, g_dyn_div{4}, g_dyn_cmax{32}, g_dyn_min_steps{32}, g_dyn_lgq{3};
+
+extern "C" void fsk_set_dyn_queues(uint32_t lg_queues) { g_dyn_lgq = lg_queues > 4 ? 4 : lg_queues; }
+
+extern "C" void fsk_set_dyn(uint32_t first_pct, uint32_t div, uint32_t cmax, uint32_t min_steps_per_wg)
+{
+    g_dyn_first_pct = first_pct > 100 ? 100 : first_pct;
+    g_dyn_div = div < 1 ? 1 : (div > 64 ? 64 : div);
+    g_dyn_cmax = cmax < 1 ? 1 : (cmax > 65535 ? 65535 : cmax);
+    g_dyn_min_steps = min_steps_per_wg;
+}
 
 #ifdef FLAGSTAT_TUNING_VARIANTS
 static int g_anatomy = 0;  // bit 0: no steps, bit 1: no final flush, bit 2: nothing after the flush (timing only)
+static uint64_t* g_timeline = nullptr;  // fsk_timeline_run: device rows [grid][8] the direct-epilogue K1 stamps
 #endif
 
 template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE = 0>
 static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
-    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, STAGE>), dim3(a.grid), dim3(fsk::kThreads), 0, stream,
+    hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, STAGE>), dim3(a.grid),
+                       dim3(STAGE == 4 ? fsk::kThreads + 64 : fsk::kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials,
-                       a.ticket, a.out, a.mode);
+                       a.ticket, a.out, a.mode, a.dyn);
     return hipGetLastError();
 }
 
@@ -667,6 +910,7 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
 {
     if (n == 0) return hipSuccess;
     if (grid == 0 || d_array == nullptr || d_partials == nullptr || d_out32 == nullptr) return hipErrorInvalidValue;
+    if ((variant & 128) && d_ticket == nullptr) return hipErrorInvalidValue;  // the dynamic schedule's counter block
     const uintptr_t addr = reinterpret_cast<uintptr_t>(d_array);
     if (addr & 1u) return hipErrorInvalidValue;  // uint16_t* must be 2-byte aligned
     fsk::CountArgs a;
@@ -688,13 +932,43 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     if ((a.mode & 4) && ((a.mode & 1) || ((variant >> 9) & 1))) return hipErrorInvalidValue;  // accumulate form only
 #ifdef FLAGSTAT_TUNING_VARIANTS
     a.mode |= (g_anatomy & 6) << 8;
+    if ((g_anatomy & 8) && (a.mode & 4)) a.mode |= 4096;
     if (g_anatomy & 1) a.nsteps = a.fast_begin = a.fast_end = 0;  // no steps at all: launch + epilogue only
 #endif
 #ifndef FLAGSTAT_TUNING_VARIANTS
     if ((variant >> 9) & 1) return hipErrorInvalidValue;  // the ticket-fused finalise exists in the tuning build only
 #endif
     a.ticket = ((variant >> 9) & 1) ? d_ticket : nullptr;  // bit 9: fused finalise inside K1
+#ifdef FLAGSTAT_TUNING_VARIANTS
+    if (g_timeline && (a.mode & 4)) {
+        a.mode |= 2048;
+        a.ticket = reinterpret_cast<uint32_t*>(g_timeline);
+    }
+#endif
     a.out = d_out32;
+    a.dyn = fsk::DynSched{reinterpret_cast<uint64_t*>(d_ticket), 0xFFFFFFFFu, 0, 1, 0};
+    // direct epilogue: many workgroups add to per-XCD copies first (grouped_epilogue); few add straight to out[]
+    if ((a.mode & 4) && grid >= g_group_min_grid.load() && d_ticket != nullptr && !(a.mode & 4096)) a.mode |= 8;
+    if (variant & 128) {
+        // round 0 takes first_pct of the full steps; too few steps per workgroup to be worth balancing: all of them
+        const uint64_t full = a.fast_end - a.fast_begin;
+        const uint64_t per_wg = (full + grid - 1) / grid;
+        uint64_t c0 = per_wg;
+        if (per_wg >= g_dyn_min_steps.load() && per_wg >= 2) {
+            c0 = full * g_dyn_first_pct.load() / (100ull * grid);
+            if (c0 < 1) c0 = 1;
+        }
+        if (c0 > 0xFFFFFFFFull) c0 = 0xFFFFFFFFull;
+        uint32_t lgq = g_dyn_lgq.load();
+        while (lgq && (grid >> (3 + lgq)) == 0) --lgq;  // every queue serves at least 8 workgroups
+        uint64_t per_queue = (static_cast<uint64_t>(grid) >> lgq) * g_dyn_div.load();
+        if (per_queue < 2) per_queue = 2;                 // keeps 2^32 / per_queue inside 32 bits
+        a.dyn.block = reinterpret_cast<uint64_t*>(d_ticket);
+        a.dyn.c0 = static_cast<uint32_t>(c0);
+        a.dyn.inv = static_cast<uint32_t>((1ull << 32) / per_queue);
+        a.dyn.cmax = g_dyn_cmax.load();
+        a.dyn.lgq = lgq;
+    }
     if (((variant >> 9) & 1) && d_ticket == nullptr) return hipErrorInvalidValue;
     hipError_t e;
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
@@ -703,10 +977,13 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     // The shipped library carries the default schedule (25) and the plain loop it is measured against (9).
     // The schedules that lost the r01 sweeps stay in the source as evidence and are compiled only into a
     // tuning build (make TUNING=1 -> -DFLAGSTAT_TUNING_VARIANTS; tools/tune.py, profiles/r01/tune_*.log).
-    switch (variant & 127) {
+    switch (variant & 255) {
     case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
     case 25: e = launch_count_t<8, true, false, true, 1>(a, stream); break;
 #ifdef FLAGSTAT_TUNING_VARIANTS
+    // bit 7: 25 + guided self-scheduling.  Balances the XCDs to within 2 us of each other and is NOT faster (HBM, not the
+    // split between XCDs, sets the time: profiles/r03/dyn_sweep*.log, timeline_153.log) -- evidence, tuning build only
+    case 153: e = launch_count_t<8, true, false, true, 4>(a, stream); break;
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
     case 13: e = launch_count_t<8, true, true, true>(a, stream); break;
@@ -725,6 +1002,42 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
 
 #ifdef FLAGSTAT_TUNING_VARIANTS
 extern "C" void fsk_set_anatomy(int bits) { g_anatomy = bits; }
+
+// Workgroup timeline of ONE direct-epilogue K1 launch (after `warm` untimed ones): h_rows[grid][8] =
+// wall-clock stamps (100 MHz) at entry / first step done / last step done / flushed / reduced / exit, XCC_ID, HW_ID.
+// Returns the grid used, 0 on failure.  Measurement only (tools/timeline.py).
+extern "C" uint32_t fsk_timeline_run(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, int warm,
+                                     uint64_t* h_rows, uint32_t cap_rows)
+{
+    if (grid == 0 || grid > cap_rows) return 0;
+    uint64_t *rows = nullptr, *partials = nullptr, *out = nullptr;
+    hipStream_t s = nullptr;
+    uint32_t used = 0;
+    if (hipMalloc(&rows, static_cast<size_t>(grid) * 64) == hipSuccess && hipMalloc(&partials, fsk_partials_bytes(grid)) == hipSuccess &&
+        hipMalloc(&out, 256) == hipSuccess && hipStreamCreateWithFlags(&s, hipStreamNonBlocking) == hipSuccess &&
+        hipMemsetAsync(out, 0, 256, s) == hipSuccess && hipMemsetAsync(rows, 0, static_cast<size_t>(grid) * 64, s) == hipSuccess &&
+        hipMemsetAsync(partials, 0, fsk_partials_bytes(grid), s) == hipSuccess) {
+        bool ok = true;
+        uint32_t* block = reinterpret_cast<uint32_t*>(partials + static_cast<size_t>(grid) * fsk::kInternal);
+        for (int i = 0; i < warm && ok; ++i)
+            ok = fsk_launch(d_array, n, grid, (variant & 255) | 2048, partials, block, out, s) == hipSuccess;
+        g_timeline = rows;
+        ok = ok && fsk_launch(d_array, n, grid, (variant & 255) | 2048, partials, block, out, s) == hipSuccess;
+        g_timeline = nullptr;
+        ok = ok && hipStreamSynchronize(s) == hipSuccess;
+        const uint64_t nvec = (n + 7 + 7) / 8;  // upper bound on the steps (a ragged head adds at most one)
+        used = grid;
+        const uint64_t nsteps = (nvec + fsk::kVecPerStep - 1) / fsk::kVecPerStep;
+        if (nsteps < used) used = static_cast<uint32_t>(nsteps);
+        ok = ok && hipMemcpy(h_rows, rows, static_cast<size_t>(used) * 64, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) used = 0;
+    }
+    if (s) (void)hipStreamDestroy(s);
+    if (rows) (void)hipFree(rows);
+    if (partials) (void)hipFree(partials);
+    if (out) (void)hipFree(out);
+    return used;
+}
 #else
 extern "C" void fsk_set_anatomy(int) {}
 #endif
@@ -732,10 +1045,11 @@ extern "C" void fsk_set_anatomy(int) {}
 // which K1 schedules this build of the library carries (bits 0-6 of `variant`)
 extern "C" int fsk_variant_supported(int variant)
 {
-    switch (variant & 127) {
+    switch (variant & 255) {
     case 9:
     case 25: return 1;
 #ifdef FLAGSTAT_TUNING_VARIANTS
+    case 153:
     case 0:
     case 1:
     case 13:

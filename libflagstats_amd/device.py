@@ -140,3 +140,12 @@ def time_device_ptr(ptr: int, n: int, warmup: int, reps: int):
     _lib.check(_lib.lib().FLAGSTATS_hip_time_device_u16(ptr, n, warmup, reps, ctypes.byref(ms), out.ctypes.data),
                "FLAGSTATS_hip_time_device_u16")
     return float(ms.value), out
+
+
+def time_device_rotating(ptr: int, n: int, stride_flags: int, slots: int, warmup: int, reps: int):
+    """(ms_total, counters summed over the timed launches): back-to-back launches, launch i on slice (i * 7919) % slots."""
+    ms = ctypes.c_float(0.0)
+    out = np.zeros(32, dtype=np.uint64)
+    _lib.check(_lib.lib().FLAGSTATS_hip_time_device_u16_rotating(ptr, n, stride_flags, slots, warmup, reps, ctypes.byref(ms),
+                                                               out.ctypes.data), "FLAGSTATS_hip_time_device_u16_rotating")
+    return float(ms.value), out

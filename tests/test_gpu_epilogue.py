@@ -144,3 +144,61 @@ def test_flag_array_in_pinned_host_memory_is_read_in_place(hip, knob):
         assert np.array_equal(out.cpu().numpy().view(np.uint64), oracle.flagstat_hist(host[1:]))
     finally:
         hip.FLAGSTATS_hip_host_free(hp)
+
+
+@pytest.fixture()
+def group_knob(hip):
+    old = hip.FLAGSTATS_hip_get(b"group_min_grid")
+    yield lambda v: hip.FLAGSTATS_hip_set(b"group_min_grid", v)
+    hip.FLAGSTATS_hip_set(b"group_min_grid", old)
+
+
+@pytest.mark.parametrize("min_grid", [0, 64, 2 ** 31])
+@pytest.mark.parametrize("n", [1, 16384 * 3 + 5, 16384 * 9, 16384 * 67 + 1, 5_000_011, 16384 * 256 * 3 + 77])
+def test_two_level_atomic_epilogue(hip, knob, group_knob, min_grid, n):
+    """K1's adds through the workspace's per-XCD copies (grids >= group_min_grid; 0 = even a grid of one workgroup)
+    or straight to out[32]: same counters, dead slots untouched, and the copies are left zero for the next launch
+    (three launches in a row on one stream and workspace)."""
+    import torch
+
+    import oracle
+    from libflagstats_amd import device
+    assert knob(1) == 0 and group_knob(min_grid) == 0
+    t = torch.empty(n, dtype=torch.int16, device="cuda:0")
+    device.generate_torch(t, device.GEN_UNIFORM, seed=91 + n % 7, mask=0xFFFF)
+    start = torch.arange(1000, 1032, dtype=torch.int64, device="cuda:0")
+    out = start.clone()
+    for _ in range(3):
+        device.count_torch(t, out)
+    torch.cuda.synchronize()
+    want = oracle.flagstat_generated(oracle.GEN_UNIFORM, 91 + n % 7, 0xFFFF, 0, n).astype(np.int64)
+    got = out.cpu().numpy() - start.cpu().numpy()
+    assert np.array_equal(got, 3 * want), (min_grid, n)
+    assert not got[[i for i in range(32) if i not in LIVE]].any()
+
+
+def test_two_level_epilogue_two_streams_one_counter_array(hip, knob, group_knob):
+    """Each stream has its own workspace (copies, tickets); both add to ONE out[32] through their group leaders."""
+    import torch
+
+    import oracle
+    from libflagstats_amd import device
+    assert knob(1) == 0 and group_knob(0) == 0
+    n = 16384 * 256 * 2 + 333
+    a = torch.empty(n, dtype=torch.int16, device="cuda:0")
+    b = torch.empty(n, dtype=torch.int16, device="cuda:0")
+    device.generate_torch(a, device.GEN_UNIFORM, seed=11, mask=0xFFFF)
+    device.generate_torch(b, device.GEN_NA12878, seed=12, mask=1)
+    out = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+    torch.cuda.synchronize()
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    reps = 30
+    for _ in range(reps):
+        with torch.cuda.stream(s1):
+            device.count_torch(a, out)
+        with torch.cuda.stream(s2):
+            device.count_torch(b, out)
+    torch.cuda.synchronize()
+    want = reps * (oracle.flagstat_generated(oracle.GEN_UNIFORM, 11, 0xFFFF, 0, n) +
+                   oracle.flagstat_generated(oracle.GEN_NA12878, 12, 1, 0, n))
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)

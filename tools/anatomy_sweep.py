@@ -15,8 +15,8 @@ _lib.check(lib.FLAGSTATS_hip_init(0), "init")
 assert lib.FLAGSTATS_hip_get(b"tuning_build"), "needs the tuning build"
 total = 2 ** 30
 d = device.DeviceFlags(total).generate(0, seed=5, mask=0xFFFF)
-rows = (("full", 0), ("no final flush", 2), ("no flush, nothing after", 6), ("nothing after the flush", 4),
-        ("no steps", 1), ("no steps, no flush, nothing after", 7))
+rows = (("full", 0), ("full, adds to 8 per-XCD copies", 8), ("no final flush", 2), ("no flush, nothing after", 6),
+        ("nothing after the flush", 4), ("no steps", 1), ("no steps, no flush, nothing after", 7))
 sizes = [int(s) for s in (sys.argv[1] if len(sys.argv) > 1 else "1000000,4194304,16777216,67108864,536870912").split(",")]
 print("%-36s" % "us per launch" + "".join("%12d" % n for n in sizes))
 for ep in (1, 0):
