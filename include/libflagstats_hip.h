@@ -135,11 +135,12 @@ int FLAGSTATS_hip_multi_device_u16(const uint16_t* const* d_arrays, const uint64
 int FLAGSTATS_hip_comm_unique_id(void* id128);
 void* FLAGSTATS_hip_comm_init_rank(const void* id128, int nranks, int rank, int device); /* NULL on failure */
 int FLAGSTATS_hip_comm_destroy(void* comm);
+int FLAGSTATS_hip_comm_count(void* comm);   /* ranks RCCL sees in the communicator (ncclCommCount); < 0 on failure */
 int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* stream);
 int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream);
 /* the same query with the collective OFF the launch stream: K1 + K2 (store) on `stream`, the all-reduce on
- * `comm_stream`, ordered behind the kernels by a device-scope event (no timing, no system fence: a plain event
- * record costs the launch stream ~10 us of cache write-back here), so it overlaps whatever `stream` runs next.
+ * `comm_stream`, ordered behind the kernels by an event without timing (knob "fence_free_events": also without the
+ * system-scope fence, ~10 us cheaper per record here; opt-in), so it overlaps whatever `stream` runs next.
  * d_out may be rewritten once `comm_stream` has passed the all-reduce: FLAGSTATS_hip_stream_wait_stream(stream,
  * comm_stream, device) makes `stream` wait on the device (cheap, e.g. once per ring of counter buffers); a host
  * sync of comm_stream works too. */
@@ -147,11 +148,13 @@ int FLAGSTATS_hip_device_u16_allreduce_overlapped(const uint16_t* d_array, uint6
                                                   void* comm_stream);
 int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
 
-/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _EPILOGUE / _CHUNK_FLAGS / _ON_ERROR / _NUMA).  key =
+/* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _EPILOGUE / _CHUNK_FLAGS / _ON_ERROR / _NUMA /
+ * _GROUP_MIN_GRID / _FENCE_FREE_EVENTS).  key =
  *   "blocks_per_cu"  workgroups per CU of K1's grid (default 1)
  *   "variant"        K1 schedule: bit0 non-temporal loads, bit1 chain depth 7, bit2 register
  *                    prefetch, bit3 interleaved waves, bit4 rolling re-issue, bit5 LDS-DMA ring, bit6
- *                    rolling at distance 2 (default 25; shipped: 9 and 25; the others only in a `make TUNING=1` build)
+ *                    rolling at distance 2, bit7 dynamic schedule (default 25; shipped: 9 and 25; the others -- incl. 153 and
+                    its "dyn_*" policy keys -- only in a `make TUNING=1` build)
  *   "epilogue"       accumulate (+=) forms into device memory: 1 (default) = K1's workgroups add their totals to the
  *                    counters with atomics, ONE launch per call, any number of streams may share a counter array;
  *                    0 = partials + K2 (then one counter array must be targeted from one stream at a time).
@@ -160,6 +163,11 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB)
  *   "on_error"       reference-shaped entry points on failure: 1 abort() after the message (default), 0 return non-zero
  *   "numa"           1 (default): pinned buffers and block-decoder threads are placed on the GPU's host NUMA node
+ *   "group_min_grid" K1's atomic epilogue goes through the workspace's 8 per-XCD copies (8 x 2 contended adds on the
+ *                    caller's counters per launch instead of one pair per workgroup) from this many workgroups on
+ *                    (default 64; 0 = always)
+ *   "fence_free_events" FLAGSTATS_hip_stream_wait_stream / the overlapped all-reduce: 1 = ordering events without the
+ *                    system-scope fence (default 0)
  * Read-only keys of FLAGSTATS_hip_get: "grid" (K1 workgroups), "numa_node" (of the default device),
  * "host_chunks" / "host_overlapped" (last multi-chunk host-pointer call on the default engine: chunks
  * submitted / chunks handed over while the previous chunk's copy + kernel were still in flight).

@@ -179,6 +179,9 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
     } else if (!std::strcmp(key, "on_error")) {
         if (value > 1) return fail_text("on_error must be 0 (return) or 1 (abort)");
         k.on_error = static_cast<int>(value);
+    } else if (!std::strcmp(key, "fence_free_events")) {
+        if (value > 1) return fail_text("fence_free_events must be 0 or 1");
+        k.fence_free_events = static_cast<int>(value);
     } else if (!std::strcmp(key, "numa")) {
         if (value > 1) return fail_text("numa must be 0 or 1");
         k.numa = static_cast<int>(value);
@@ -206,6 +209,7 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "tuning_build")) return static_cast<uint64_t>(fsk_tuning_build());
     if (!std::strcmp(key, "on_error")) return static_cast<uint64_t>(k.on_error.load());
     if (!std::strcmp(key, "numa")) return static_cast<uint64_t>(k.numa.load());
+    if (!std::strcmp(key, "fence_free_events")) return static_cast<uint64_t>(k.fence_free_events.load());
     if (!std::strcmp(key, "grid")) {
         if (fsint::default_device() < 0) return 0;
         Engine* e = fsint::default_engine();

@@ -37,6 +37,7 @@ struct Knobs {
                                                   // out[] with atomics (one launch), 0 = partials + K2
     std::atomic<uint64_t> chunk_flags{32ull << 20};  // host streaming chunk: 32 Mi flags = 64 MiB
     std::atomic<int> on_error{1};                 // legacy uint32 entry points: 1 = abort after the message, 0 = return non-zero
+    std::atomic<int> fence_free_events{0};        // stream_wait_stream: 1 = ordering events without the system-scope fence (opt-in)
     std::atomic<int> numa{1};                     // block pipeline: 1 = pinned chunks + decoders on the GPU's NUMA node
 };
 Knobs& knobs();
@@ -64,6 +65,7 @@ struct Engine {
     static constexpr int kOrderEvents = 16;        // device-scope ordering events (no timing, no system fence), used round robin
     hipEvent_t order_ev[kOrderEvents] = {};
     unsigned order_next = 0;                       // guarded by user_mu
+    bool order_ev_fence_free = false;              // flavour of the events currently in order_ev[] (guarded by user_mu)
     std::mutex user_mu;                            // guards user_ws and the ordering events
     std::list<std::pair<void*, Workspace>> user_ws;  // caller-owned streams, most recently used first (bounded)
 };
@@ -104,8 +106,9 @@ int select_default_device(int device);             // FLAGSTATS_hip_init
 int device_of_pointer(const void* p, const char* what, int* device, bool* plain_device_memory = nullptr);
 // a caller's stream must belong to `device` (NULL = that device's null stream)
 int check_stream_device(hipStream_t s, int device);
-// `waiter` waits (on the device; the host does not) for everything queued on `on` so far.  The event carries no
-// system-scope fence: a plain hipEventRecord costs the launch stream ~10 us of cache write-back per record here.
+// `waiter` waits (on the device; the host does not) for everything queued on `on` so far.  Knob "fence_free_events":
+// the event carries no system-scope fence (a plain hipEventRecord costs the launch stream ~10 us of cache write-back
+// per record here); off by default.
 int stream_wait_stream(Engine& e, hipStream_t waiter, hipStream_t on);
 
 uint32_t grid_for(const Engine& e);

@@ -54,6 +54,7 @@ void read_env_knobs()
         g_knobs.fuse = fsk_tuning_build() ? static_cast<int>(env_u64("FLAGSTATS_HIP_FUSE", static_cast<uint64_t>(g_knobs.fuse))) : 0;
         g_knobs.epilogue = static_cast<int>(env_u64("FLAGSTATS_HIP_EPILOGUE", static_cast<uint64_t>(g_knobs.epilogue)));
         g_knobs.numa = static_cast<int>(env_u64("FLAGSTATS_HIP_NUMA", static_cast<uint64_t>(g_knobs.numa)));
+        g_knobs.fence_free_events = static_cast<int>(env_u64("FLAGSTATS_HIP_FENCE_FREE_EVENTS", static_cast<uint64_t>(g_knobs.fence_free_events)));
         const char* oe = std::getenv("FLAGSTATS_HIP_ON_ERROR");
         if (oe && *oe) g_knobs.on_error = (!std::strcmp(oe, "return") || !std::strcmp(oe, "0")) ? 0 : 1;
     });
@@ -341,21 +342,32 @@ int check_stream_device(hipStream_t s, int device)
 int stream_wait_stream(Engine& e, hipStream_t waiter, hipStream_t on)
 {
     if (waiter == on) return 0;
-    hipEvent_t ev;
-    {
-        std::lock_guard<std::mutex> lk(e.user_mu);
-        hipEvent_t& slot = e.order_ev[e.order_next++ % Engine::kOrderEvents];
-        if (!slot && hipEventCreateWithFlags(&slot, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
-            (void)hipGetLastError();  // a runtime without the fence-free flavour: an ordinary ordering event does the same job
+    // Record and wait while holding the lock: the ring has 16 slots, and a slot re-recorded by another caller between
+    // this caller's record and its wait would bind the wait to the wrong record (two cheap runtime calls).
+    std::lock_guard<std::mutex> lk(e.user_mu);
+    const bool fence_free = g_knobs.fence_free_events.load() != 0;
+    if (fence_free != e.order_ev_fence_free) {  // the knob changed: events of the other flavour are dropped
+        for (hipEvent_t& ev : e.order_ev) {
+            if (ev) (void)hipEventDestroy(ev);
+            ev = nullptr;
+        }
+        e.order_ev_fence_free = fence_free;
+    }
+    hipEvent_t& slot = e.order_ev[e.order_next++ % Engine::kOrderEvents];
+    if (!slot) {
+        // default: an ordinary ordering event.  Knob "fence_free_events" = 1: without the system-scope fence -- enough to
+        // order two streams of ONE device, ~10 us cheaper per record on the launch stream, but only ever exercised at
+        // world size 1 (profiles/r02/dist_step_overhead.log): opt-in until it has met a second GPU.
+        if (!fence_free || hipEventCreateWithFlags(&slot, hipEventDisableTiming | hipEventDisableSystemFence) != hipSuccess) {
+            if (fence_free) (void)hipGetLastError();
             slot = nullptr;
             HIP_TRY(hipEventCreateWithFlags(&slot, hipEventDisableTiming));
         }
-        ev = slot;
     }
     // re-recording an event that an earlier hipStreamWaitEvent still refers to is fine: a wait binds to the
     // record that was current when it was queued
-    HIP_TRY(hipEventRecord(ev, on));
-    HIP_TRY(hipStreamWaitEvent(waiter, ev, 0));
+    HIP_TRY(hipEventRecord(slot, on));
+    HIP_TRY(hipStreamWaitEvent(waiter, slot, 0));
     return 0;
 }
 

@@ -197,6 +197,10 @@ int FLAGSTATS_hip_multi_device_u16(const uint16_t* const* d_arrays, const uint64
     // all devices are running by now: wait for each and add its 256 bytes
     for (Engine* e : uniq) {
         DeviceGuard guard(e->device);
+        if (!guard.ok()) {
+            if (!rc) rc = -1;
+            continue;
+        }
         hipError_t err = hipStreamSynchronize(e->stream[0]);
         if (err != hipSuccess && !rc) rc = fail_hip("hipStreamSynchronize", err);
     }
@@ -250,6 +254,17 @@ int FLAGSTATS_hip_comm_destroy(void* comm)
     if (!r) return -1;
     const ncclResult_t e = r->CommDestroy(static_cast<ncclComm_t>(comm));
     return e == ncclSuccess ? 0 : fail_nccl(r, "ncclCommDestroy", e);
+}
+
+int FLAGSTATS_hip_comm_count(void* comm)
+{
+    if (!comm) return fail_text("NULL communicator");
+    const Rccl* r = rccl();
+    if (!r) return -1;
+    int n = -1;
+    const ncclResult_t e = r->CommCount(static_cast<ncclComm_t>(comm), &n);
+    if (e != ncclSuccess) return fail_nccl(r, "ncclCommCount", e);
+    return n;
 }
 
 int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* stream)
