@@ -166,6 +166,8 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *   "group_min_grid" K1's atomic epilogue goes through the workspace's 8 per-XCD copies (8 x 2 contended adds on the
  *                    caller's counters per launch instead of one pair per workgroup) from this many workgroups on
  *                    (default 64; 0 = always)
+ *   "epoch_stagger"  1 (default): the four waves of a K1 workgroup fold their bit-sliced counters (every 255 steps)
+ *                    at different steps, so HBM never idles for it chip-wide; 0 = all at the same step (r02)
  *   "fence_free_events" FLAGSTATS_hip_stream_wait_stream / the overlapped all-reduce: 1 = ordering events without the
  *                    system-scope fence (default 0)
  * Read-only keys of FLAGSTATS_hip_get: "grid" (K1 workgroups), "numa_node" (of the default device),

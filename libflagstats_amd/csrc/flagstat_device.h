@@ -12,6 +12,21 @@ __device__ __forceinline__ uint32_t perm(uint32_t hi, uint32_t lo, uint32_t sel)
     return __builtin_amdgcn_perm(hi, lo, sel);  // v_perm_b32: bytes 0-3 = lo, 4-7 = hi
 }
 
+// (a << 1) | b and (a & mask) | c as the single VALU instructions they are on gfx950
+__device__ __forceinline__ uint32_t lshl1_or(uint32_t a, uint32_t b)
+{
+    uint32_t r;
+    asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+
+__device__ __forceinline__ uint32_t and_or(uint32_t a, uint32_t mask, uint32_t c)
+{
+    uint32_t r;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "s"(mask), "v"(c));
+    return r;
+}
+
 // carry-save adder on 32 one-bit columns: 2 VALU ops on gfx950 (v_bitop3_b32)
 __device__ __forceinline__ void csa(uint32_t& carry, uint32_t& sum, uint32_t a, uint32_t b, uint32_t c)
 {

@@ -31,6 +31,7 @@ struct Knobs {
     std::atomic<uint32_t> blocks_per_cu{0};       // 0 = auto (1)
     std::atomic<int> variant{25};                 // K1 schedule, see flagstat_kernels.hip
     std::atomic<uint32_t> dyn_first_pct{75}, dyn_div{4}, dyn_cmax{32}, dyn_min_steps{32}, dyn_lgq{3};  // dynamic schedule (variant bit 7)
+    std::atomic<int> epoch_stagger{1};            // K1: waves of a workgroup flush their epochs at different steps
     std::atomic<uint32_t> group_min_grid{64};     // K1's atomic epilogue goes through per-XCD copies from this many workgroups on
     std::atomic<int> fuse{0};                     // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
     std::atomic<int> epilogue{1};                 // accumulate form into device memory: 1 = K1 adds its workgroup totals to

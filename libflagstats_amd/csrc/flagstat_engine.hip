@@ -46,6 +46,8 @@ void read_env_knobs()
         g_knobs.dyn_div = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_DIV", g_knobs.dyn_div));
         g_knobs.dyn_cmax = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_CMAX", g_knobs.dyn_cmax));
         g_knobs.dyn_min_steps = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_MIN_STEPS", g_knobs.dyn_min_steps));
+        g_knobs.epoch_stagger = static_cast<int>(env_u64("FLAGSTATS_HIP_EPOCH_STAGGER", static_cast<uint64_t>(g_knobs.epoch_stagger)));
+        fsk_set_epoch_stagger(g_knobs.epoch_stagger.load());
         g_knobs.group_min_grid = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_GROUP_MIN_GRID", g_knobs.group_min_grid));
         fsk_set_group_min_grid(g_knobs.group_min_grid.load());
         g_knobs.dyn_lgq = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_LG_QUEUES", g_knobs.dyn_lgq));

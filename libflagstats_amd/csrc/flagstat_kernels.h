@@ -41,7 +41,8 @@ struct CountArgs {
     DynSched dyn;
     int mode;              // bit 0: out = counters instead of +=; bit 1: superset slots (0/16 n_pair_all, 9 pass-QC reads);
                            // bit 2: direct epilogue -- every workgroup adds its totals to out[] with atomics, no K2;
-                           // bit 3 (with bit 2): through the workspace's per-XCD copies (grouped_epilogue)
+                           // bit 3 (with bit 2): through the workspace's per-XCD copies (grouped_epilogue);
+                           // bit 4: the waves of a workgroup start their first epoch at different counts
 };
 
 }  // namespace fsk
@@ -60,7 +61,8 @@ int fsk_variant_supported(int variant);   // K1 schedule compiled into this buil
 void fsk_set_dyn(uint32_t first_pct, uint32_t div, uint32_t cmax, uint32_t min_steps_per_wg);
 void fsk_set_dyn_queues(uint32_t lg_queues);
 // K1's direct epilogue adds to per-XCD copies first when the grid has at least this many workgroups (0: always)
-void fsk_set_group_min_grid(uint32_t min_grid);   // 2^lg_queues (<= 16) counters
+void fsk_set_group_min_grid(uint32_t min_grid);
+void fsk_set_epoch_stagger(int on);            // 1 (default): wave w of a workgroup starts its first epoch at step count 64 * w   // 2^lg_queues (<= 16) counters
 void fsk_set_anatomy(int bits);           // tuning builds only: skip parts of K1 to time the rest (results wrong)
 int fsk_tuning_build(void);               // 1: built with -DFLAGSTAT_TUNING_VARIANTS (make TUNING=1)
 // positional popcount (flagstat_pospopcnt.hip): d_out16[16] += bit counts.  d_partials as for fsk_launch.

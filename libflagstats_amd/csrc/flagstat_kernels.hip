@@ -62,30 +62,40 @@ namespace fsk {
 // where pp = paired & !secondary & !supplementary  (libflagstats.h:129-131).
 // selq: per byte (qcfail | dup<<1), feeds the QC/DUP LUTs.  keep: the category keep-mask, whose
 // bits 6 and 7 are set exactly for primary paired reads (pp).
-__device__ __forceinline__ void front4(uint32_t xa, uint32_t xb, uint32_t& T, uint32_t& selq, uint32_t& keep)
+__device__ __forceinline__ void front4(uint32_t L, uint32_t H, uint32_t& T, uint32_t& selq, uint32_t& keep)
 {
-    const uint32_t L = perm(xb, xa, 0x06040200u);  // FLAG bits 0..7  of 4 flags
-    const uint32_t H = perm(xb, xa, 0x07050301u);  // FLAG bits 8..15 of 4 flags
-
+    // L = FLAG bits 0..7 of 4 flags, H = FLAG bits 8..15 (byte-planar: split4 / perm of the two loaded dwords)
     // LUT 1: idx = (proper, unmap, munmap) = L bits 1..3.  Entry = derived bits
     // at 1/4/5, plus constant ones at bits 0 and 3 (so the AND below passes the
     // secondary / supplementary bits that LUT 2 supplies).
     const uint32_t sel1 = (L >> 1) & 0x07070707u;
     const uint32_t abc = perm(0x09091B19u, 0x09092B29u, sel1);
-    // raw read1/read2 (6,7) and unmapped (2) from L, derived bits from the LUT
-    const uint32_t m = (L & 0xC4C4C4C4u) | abc;
+    // raw read1/read2 (6,7) and unmapped (2) from L, derived bits from the LUT: one v_bfi-shaped v_bitop3_b32
+    const uint32_t m = __builtin_amdgcn_bitop3_b32(L, abc, 0xC4C4C4C4u, 0xE4);  // mask ? L : abc
 
     // LUT 2: idx = (secondary, paired, supplementary).  Entry = keep-mask:
     //   secondary         -> 0x01        supplementary only -> 0x08
     //   primary paired    -> 0xF2        none of them       -> 0x00
     // always | 0x04 so the unconditional UNMAP bit survives.
-    uint32_t idx = (H & 0x01010101u);
-    idx = ((H >> 1) & 0x04040404u) | idx;
-    idx = ((L << 1) & 0x02020202u) | idx;
+    // (4 ops through v_lshl_or_b32 / v_and_or_b32; left to itself hipcc builds it from 5)
+    const uint32_t h1 = H >> 1;  // shared with selq
+    const uint32_t idx = and_or(h1, 0x04040404u, lshl1_or(L & 0x01010101u, H & 0x01010101u));
     keep = perm(0x050C050Cu, 0x05F60504u, idx);
     T = m & keep;
 
-    selq = (H >> 1) & 0x03030303u;  // bit0 = QCFAIL, bit1 = DUP
+    selq = h1 & 0x03030303u;  // bit0 = QCFAIL, bit1 = DUP
+}
+
+// Split a just-loaded vector (8 flags) into its four byte planes with real v_perm_b32s AT THIS POINT of the instruction
+// stream: the registers it was loaded into are dead afterwards and are re-targeted by the load of the lane's next step
+// (K1's ROLL path: a load may land at any moment).  This is the r02 copy_out (4 v_movs per vector) with the copies done
+// by the front end's own first instructions -- 32 VALU ops per step fewer.
+__device__ __forceinline__ void split_out(const uint4& o, uint32_t& L0, uint32_t& H0, uint32_t& L1, uint32_t& H1)
+{
+    const uint32_t lo = 0x06040200u, hi = 0x07050301u;
+    asm volatile("v_perm_b32 %0, %5, %4, %8\n\tv_perm_b32 %1, %5, %4, %9\n\tv_perm_b32 %2, %7, %6, %8\n\tv_perm_b32 %3, %7, %6, %9"
+                 : "=&v"(L0), "=&v"(H0), "=&v"(L1), "=&v"(H1)
+                 : "v"(o.x), "v"(o.y), "v"(o.z), "v"(o.w), "s"(lo), "s"(hi));
 }
 
 // ------------------------------------------------------------------ lane state
@@ -185,29 +195,36 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
             uint32_t T[4], F[4], S[4];
 #pragma unroll
             for (int k = 0; k < 2; ++k) {
-                uint4 x;
+                uint32_t L0, H0, L1, H1;
                 if constexpr (STAGE == 2) {
                     const int u = half * 4 + q * 2 + k;  // a constant after unrolling
                     asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-                    x = lds.lane[(lds.first + u) * 64];
+                    const uint4 x = lds.lane[(lds.first + u) * 64];
                     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the slot has been read: it may be refilled
                     lds_dma16<NT>(next + u * USTRIDE, lds.slot0 + u * 1024);
-                } else {
-                    x = v[half * 4 + q * 2 + k];
-                }
-                if constexpr (ROLL) {
-                    // Copy the vector out with real v_movs HERE (a load may land at any time, so the
-                    // registers it targets must be dead first), then re-issue into the same registers.
-                    // The asm keeps hipcc from turning the copies into loop-top PHI moves (which wait
-                    // for all 8 loads), the sched_barriers from sinking the loads below the arithmetic.
+                    L0 = perm(x.y, x.x, 0x06040200u);
+                    H0 = perm(x.y, x.x, 0x07050301u);
+                    L1 = perm(x.w, x.z, 0x06040200u);
+                    H1 = perm(x.w, x.z, 0x07050301u);
+                } else if constexpr (ROLL) {
+                    // Split the vector out of its registers HERE (a load may land at any time, so the registers it
+                    // targets must be dead first), then re-issue into the same registers.  The asm keeps hipcc from
+                    // turning the reads into loop-top PHI moves (which wait for all 8 loads), the sched_barriers from
+                    // sinking the loads below the arithmetic.
                     __builtin_amdgcn_sched_barrier(0);
-                    x = copy_out(x);
+                    split_out(v[half * 4 + q * 2 + k], L0, H0, L1, H1);
                     v[half * 4 + q * 2 + k] = load_vec<NT>(next + (half * 4 + q * 2 + k) * USTRIDE);
                     __builtin_amdgcn_sched_barrier(0);
+                } else {
+                    const uint4 x = v[half * 4 + q * 2 + k];
+                    L0 = perm(x.y, x.x, 0x06040200u);
+                    H0 = perm(x.y, x.x, 0x07050301u);
+                    L1 = perm(x.w, x.z, 0x06040200u);
+                    H1 = perm(x.w, x.z, 0x07050301u);
                 }
                 uint32_t qa, qb, ka, kb;
-                front4(x.x, x.y, T[2 * k], qa, ka);
-                front4(x.z, x.w, T[2 * k + 1], qb, kb);
+                front4(L0, H0, T[2 * k], qa, ka);
+                front4(L1, H1, T[2 * k + 1], qb, kb);
                 // fail-QC byte masks
                 F[2 * k] = T[2 * k] & perm(0u, 0xFF00FF00u, qa);
                 F[2 * k + 1] = T[2 * k + 1] & perm(0u, 0xFF00FF00u, qb);
@@ -433,6 +450,9 @@ template <int DEPTH, int STAGE = 0, bool NT = false, int USTRIDE = 64>
 __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t& blk,
                                                const uint4* __restrict__ next = nullptr, LdsStage lds = LdsStage{nullptr, 0, 0})
 {
+    // blk is the same in every lane; hipcc keeps it in a VGPR and branches through the exec mask (v_and, v_cmp,
+    // s_and_saveexec per chain level) unless told so
+    blk = __builtin_amdgcn_readfirstlane(blk);
     step<DEPTH, STAGE, NT, USTRIDE>(s, v, blk, next, lds);
     ++blk;
     if (blk == (1u << DEPTH) - 1u) {
@@ -471,7 +491,12 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagsta
     const uint64_t lane_off = INTERLEAVE ? static_cast<uint64_t>(threadIdx.x)
                                          : static_cast<uint64_t>(wave) * (64 * kUnroll) + lane;
     const uint64_t G = gridDim.x;
-    uint32_t blk = 0;
+    // Steps pushed in the current epoch.  An epoch ends at 255 with a flush (~1 us of pure VALU work); started at 0 in
+    // every wave, all 1024 waves of the chip would flush at the same step and HBM would idle meanwhile.  Mode bit 4
+    // starts wave w of a workgroup at 64 * w: its first epoch is that much shorter, so at any time at most one wave of
+    // a CU is flushing while the other three keep their loads in flight.  (Any start is arithmetically fine: the chain
+    // levels are adders; a level whose pending plane is empty while its bit of blk is set just adds a zero.)
+    uint32_t blk = (mode & 16) ? (wave & 3u) * 64u : 0u;
 
     constexpr bool ROLL = (STAGE != 0);
     if constexpr (ROLL) {
@@ -872,6 +897,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
 // copy of the 32 slots.  The block must be zero before the first launch and is left zero by every launch.
 extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 8192; }
 
+static std::atomic<int> g_epoch_stagger{1};          // K1 mode bit 4: waves of a workgroup end their epochs at different steps
+
+extern "C" void fsk_set_epoch_stagger(int on) { g_epoch_stagger = on ? 1 : 0; }
+
 static std::atomic<uint32_t> g_group_min_grid{64};  // grids below this add straight to out[] (one level)
 
 extern "C" void fsk_set_group_min_grid(uint32_t min_grid) { g_group_min_grid = min_grid; }
@@ -948,6 +977,7 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     a.out = d_out32;
     a.dyn = fsk::DynSched{reinterpret_cast<uint64_t*>(d_ticket), 0xFFFFFFFFu, 0, 1, 0};
     // direct epilogue: many workgroups add to per-XCD copies first (grouped_epilogue); few add straight to out[]
+    if (g_epoch_stagger.load()) a.mode |= 16;
     if ((a.mode & 4) && grid >= g_group_min_grid.load() && d_ticket != nullptr && !(a.mode & 4096)) a.mode |= 8;
     if (variant & 128) {
         // round 0 takes first_pct of the full steps; too few steps per workgroup to be worth balancing: all of them
