@@ -16,6 +16,11 @@ first ~20 launches of ANY kernel run 5-40 % slow, tools/step_times.py) -> W warm
 exactly K timed steps, one hipEvent per step on the launch stream -> barrier -> parity of the WHOLE
 array against the oracle -> CPU baseline.
 
+`--gpus N` without a launcher (no RANK in the environment) starts the N ranks itself: N fresh child processes of this
+script with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* set, spawned before anything in the parent has touched the GPU, rank
+0's JSON line relayed.  Under `python -m torch.distributed.run --nproc-per-node N` (the driver's form) the ranks are
+already there and nothing is spawned.
+
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects: "roofline"
 (HBM: algorithmic bytes = 2 B/flag over the event-timed average step on the launch stream) and
 "cpu_baseline" (the reference's own dispatcher kernel, oracle/_ref, timed on this host on a bounded
@@ -175,6 +180,43 @@ def quantiles(ms):
             "min": round(s[0], 5), "max": round(s[-1], 5), "first": round(ms[0], 5)}
 
 
+def spawn_ranks(nproc):
+    """Be our own launcher: `nproc` fresh child processes of this script, one rank each.  The parent never imports
+    torch or the library (nothing here has initialised the GPU), relays rank 0's stdout -- the JSON line -- and the
+    other ranks' output to stderr, and returns the worst exit code.  A rank that dies takes the others with it."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(nproc):
+        env = dict(os.environ)
+        env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
+    out0 = procs[0].stdout
+    rc = 0
+    try:
+        for line in out0:                       # rank 0's stdout, as it comes
+            sys.stdout.write(line.decode(errors="replace"))
+            sys.stdout.flush()
+        deadline = time.time() + 600
+        for pr in procs:
+            pr.wait(timeout=max(1.0, deadline - time.time()))
+            rc = rc or pr.returncode
+    except (KeyboardInterrupt, subprocess.TimeoutExpired):
+        rc = rc or 1
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()                       # exactly the processes started here
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -200,24 +242,24 @@ def main():
                     help="TEST ONLY: put every rank on GPU 0 (use with --backend gloo --allreduce torch) to exercise the "
                          "multi-rank launch contract on a single-GPU box; the number it prints is not a scaling result")
     ap.add_argument("--overlap", action="store_true",
-                    help="N > 1: always run the all-reduce of step i on a side stream, overlapping K1 of step i+1 "
-                         "(default: measured against the in-line form before the warm-up, the faster one is used)")
+                    help="N > 1: run the all-reduce of step i on a side stream, overlapping K1 of step i+1 (every counter "
+                         "buffer of the ring is checked on every rank during the warm-up; a mismatch falls back to in-line)")
+    ap.add_argument("--calibrate", action="store_true",
+                    help="N > 1: time both forms (stream events, max over ranks) before the warm-up and use the faster one")
     ap.add_argument("--no-overlap", action="store_true",
-                    help="N > 1: wait for each step's all-reduce before the next step's K1 (default: the all-reduce "
-                         "of step i overlaps K1 of step i+1)")
+                    help="N > 1: the all-reduce of each step on the launch stream, in line (this is the default: the "
+                         "overlapped form's stream ordering has only ever run at world size 1)")
     ap.add_argument("--force-dist", action="store_true",
                     help="run the N>1 step (store + RCCL all-reduce) even at world size 1: exercises the multi-GPU "
                          "code path on a single-GPU box")
     args = ap.parse_args()
 
+    if "RANK" not in os.environ and (args.gpus > 1 or args.force_dist):
+        sys.exit(spawn_ranks(max(1, args.gpus)))   # no launcher: start the ranks ourselves (before any GPU call)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d"
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+    args.gpus = world
 
     import numpy as np
     import torch
@@ -254,6 +296,7 @@ def main():
     comm_init_hung = False
     comm = None
     ar_impl = None
+    rccl_nranks = None
     if multi:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
@@ -294,6 +337,9 @@ def main():
                 if not comm:
                     raise _lib.FlagstatsHipError(box.get("err", "communicator creation failed"))
                 ar_impl = "FLAGSTATS_hip_allreduce_counters (C ABI, ncclAllReduce uint64[32])"
+                rccl_nranks = int(lib.FLAGSTATS_hip_comm_count(comm))
+                if rccl_nranks != world:
+                    raise _lib.FlagstatsHipError("ncclCommCount says %d ranks, the launcher %d" % (rccl_nranks, world))
             except Exception as e:  # noqa: BLE001 -- a scaling run must not die on the communicator; say so instead
                 print("bench.py: C-ABI RCCL communicator unavailable (%r); using torch.distributed all_reduce" % (e,),
                       file=sys.stderr)
@@ -318,7 +364,7 @@ def main():
     counters = torch.zeros(32, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
-    overlap = multi and not args.no_overlap     # may be switched off by the calibration below
+    overlap = multi and (args.overlap or args.calibrate) and not args.no_overlap   # default: in line
     main_stream = torch.cuda.current_stream(dev)
     comm_stream = torch.cuda.Stream(device=dev) if overlap else None
     RING = 8                   # counter buffers in flight between the launch stream and the all-reduce stream
@@ -399,7 +445,37 @@ def main():
     # instead.  On one GPU in line wins by ~12 us per step; on an 8-GPU node the all-reduce is slower and the answer
     # may flip, so both are run for a few steps and every rank takes the form with the smaller max-over-ranks time.
     calib_note = ""
-    if multi and overlap and not args.overlap:
+
+    def ring_is_right():
+        """Overlapped form only: one in-line step gives the reference counters, then 2 x RING overlapped steps; every
+        buffer of the ring must hold exactly those counters on every rank (the ordering between the launch stream,
+        the all-reduce stream and the ring re-use is the part that has never met a second GPU)."""
+        state["overlap"] = False
+        step()
+        torch.cuda.synchronize()
+        ref = counters.clone()
+        state["overlap"] = True
+        state["i"] = 0
+        for b in bufs:
+            b.fill_(-1)
+        for _ in range(2 * RING):
+            step()
+        drain()
+        torch.cuda.synchronize()
+        ok = all(bool(torch.equal(b, ref)) for b in bufs)
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        state["i"] = 0
+        return int(flag.item()) == 1
+
+    if multi and overlap:
+        if not ring_is_right():
+            print("bench.py: overlapped all-reduce gave wrong counters in some ring buffer on some rank; using the in-line form",
+                  file=sys.stderr)
+            overlap = False
+            state["overlap"] = False
+            calib_note = " (overlapped form failed its ring check)"
+    if multi and overlap and args.calibrate:
         times = [0.0, 0.0]
         state["overlap"] = False
         for _ in range(20):           # the chip settles first (the first launches after idle run long)
@@ -411,17 +487,22 @@ def main():
             step()
             drain()
             barrier()
-            t0 = time.perf_counter()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             for _ in range(15):
                 step()
-            drain()
-            torch.cuda.synchronize()
-            times[form] += time.perf_counter() - t0
+            drain()               # the launch stream waits for the collectives: e1 is behind all of them
+            e1.record()
+            e1.synchronize()
+            times[form] += e0.elapsed_time(e1) * 1e-3
         tt = torch.tensor(times, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         state["overlap"] = bool(float(tt[1]) < float(tt[0]))
-        calib_note = " (calibrated: in-line %.1f us/step, overlapped %.1f us/step)" % (float(tt[0]) / 45 * 1e6, float(tt[1]) / 45 * 1e6)
+        calib_note = " (calibrated with stream events: in-line %.1f us/step, overlapped %.1f us/step)" % (
+            float(tt[0]) / 45 * 1e6, float(tt[1]) / 45 * 1e6)
         state["i"] = 0
+    elif multi:
+        state["overlap"] = overlap
 
     for _ in range(args.warmup):
         step()
@@ -511,6 +592,7 @@ def main():
                        "flags_per_gpu": n, "global_flags": total_flags, "parallelism": "shard%d" % world,
                        "allreduce": (("overlapped" if state["overlap"] else "in-line") + calib_note) if multi else None,
                        "allreduce_impl": ar_impl,
+                       "rccl_nranks": rccl_nranks,
                        "kernel_variant": int(lib.FLAGSTATS_hip_get(b"variant")),
                        "grid_blocks": int(lib.FLAGSTATS_hip_get(b"grid")),
                        "kernel_source_id": kernel_source_id()},

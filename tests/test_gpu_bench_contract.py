@@ -48,11 +48,33 @@ def test_single_gpu_line(hip):
     assert d["parity"].startswith("bit-exact")
 
 
-def test_multi_gpu_step_at_world_size_one(hip):
-    """--force-dist: the N > 1 step (store form + the library's RCCL all-reduce, calibrated in-line vs overlapped)
-    on one GPU; the line must say which form ran and the counters must still be the oracle's."""
+def test_multi_gpu_step_at_world_size_one_self_spawned(hip):
+    """--force-dist with no launcher: bench.py starts its (one) rank itself as a fresh child process and relays its
+    line.  The N > 1 step (store form + the library's own RCCL all-reduce) on one GPU: the line must say which form
+    ran, how many ranks RCCL saw, and the counters must still be the oracle's.  Default form: in line."""
     d = run_bench("--force-dist", "--cpu-seconds", "0")
-    assert d["n_gpus"] == 1 and d["config"]["allreduce"].split()[0] in ("in-line", "overlapped")
-    assert "calibrated" in d["config"]["allreduce"]
-    assert d["config"]["allreduce_impl"]
+    assert d["n_gpus"] == 1 and d["config"]["allreduce"].split()[0] == "in-line"
+    assert d["config"]["allreduce_impl"].startswith("FLAGSTATS_hip_allreduce_counters")
+    assert d["config"]["rccl_nranks"] == 1
     assert d["parity"].startswith("bit-exact") and d["cpu_baseline"] is None
+
+
+def test_overlapped_form_checked_and_calibrated(hip):
+    """--calibrate: the overlapped form first has to reproduce the in-line counters in every buffer of its ring, then
+    both forms are timed with stream events and the faster one runs the timed steps."""
+    d = run_bench("--force-dist", "--calibrate", "--cpu-seconds", "0")
+    assert d["config"]["allreduce"].split()[0] in ("in-line", "overlapped")
+    assert "calibrated with stream events" in d["config"]["allreduce"]
+    assert d["parity"].startswith("bit-exact")
+    d = run_bench("--force-dist", "--overlap", "--cpu-seconds", "0")
+    assert d["config"]["allreduce"].split()[0] == "overlapped" and d["parity"].startswith("bit-exact")
+
+
+def test_two_ranks_self_spawned_on_one_gpu(hip):
+    """`bench.py --gpus 2` with no launcher: two fresh rank processes, rendezvous on 127.0.0.1, both on GPU 0 (test-only
+    --same-device with the gloo backend and torch's all_reduce: a 1-GPU box cannot host two RCCL ranks).  Rank 0's line:
+    2 ranks, weak scaling, the all-reduced counters equal the oracle's sum over both shards."""
+    d = run_bench("--gpus", "2", "--same-device", "--backend", "gloo", "--allreduce", "torch", "--cpu-seconds", "0")
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_flags"] == 2 * 2 ** 27
+    assert d["config"]["parallelism"] == "shard2" and d["config"]["allreduce"].split()[0] == "in-line"
+    assert d["parity"].startswith("bit-exact") and "all 2 shards" in d["parity"]

@@ -182,3 +182,68 @@ def test_rccl_allreduce_world_of_one(hip):
         assert hip.FLAGSTATS_hip_stream_wait_stream(stream, ctypes.c_void_p(0x1234), 0) != 0
     finally:
         _lib.check(hip.FLAGSTATS_hip_comm_destroy(comm), "comm destroy")
+
+
+# --------------------------------------------------------------------------- two DISTINCT devices (skipped on 1-GPU boxes)
+def _need_two(hip):
+    if hip.FLAGSTATS_hip_device_count() < 2:
+        pytest.skip("needs 2 visible GPUs (the round-end box has one; the driver's 8-GPU node runs this)")
+
+
+def test_multi_host_array_over_two_devices(hip):
+    """FLAGSTATS_hip_multi_u16_x64 with devices = {0, 1}: two engines on two GPUs, two PCIe links, host-side sum."""
+    _need_two(hip)
+    import oracle
+    from libflagstats_amd import _lib
+    n = 50_000_003
+    a = oracle.generate(oracle.GEN_UNIFORM, 12, 0xFFFF, 0, n)
+    devs = (ctypes.c_int * 2)(0, 1)
+    out = np.zeros(32, dtype=U64)
+    _lib.check(hip.FLAGSTATS_hip_multi_u16_x64(a.ctypes.data, n, devs, 2, out.ctypes.data), "multi_u16_x64 {0,1}")
+    assert np.array_equal(out, oracle.flagstat_hist(a))
+
+
+def test_multi_device_resident_shards_on_two_devices(hip):
+    """FLAGSTATS_hip_multi_device_u16: shards allocated on GPU 0 and GPU 1, each counted where it lives, concurrently."""
+    _need_two(hip)
+    import oracle
+    from libflagstats_amd import _lib
+    sizes = [30_000_001, 20_000_005, 7, 16384 * 300]
+    ptrs, want = [], np.zeros(32, dtype=U64)
+    try:
+        for i, m in enumerate(sizes):
+            p = hip.FLAGSTATS_hip_device_alloc_on(i % 2, 2 * m)
+            assert p, hip.FLAGSTATS_hip_last_error()
+            ptrs.append(p)
+            _lib.check(hip.FLAGSTATS_hip_generate_u16(p, m, 0, 40 + i, 0xFFFF, 0, None), "generate")
+            want += oracle.flagstat_generated(oracle.GEN_UNIFORM, 40 + i, 0xFFFF, 0, m)
+        for dev in (0, 1):
+            _lib.check(hip.FLAGSTATS_hip_init(dev), "init")
+            _lib.check(hip.FLAGSTATS_hip_synchronize(), "sync")
+        _lib.check(hip.FLAGSTATS_hip_init(0), "init 0")
+        arr = (ctypes.c_void_p * len(sizes))(*ptrs)
+        ns = (ctypes.c_uint64 * len(sizes))(*sizes)
+        out = np.zeros(32, dtype=U64)
+        _lib.check(hip.FLAGSTATS_hip_multi_device_u16(arr, ns, len(sizes), out.ctypes.data), "multi_device_u16")
+        assert np.array_equal(out, want)
+    finally:
+        for p in ptrs:
+            hip.FLAGSTATS_hip_device_free(p)
+
+
+def test_two_rccl_ranks_in_two_processes(hip):
+    """bench.py --gpus 2, self-spawned: one rank per GPU, the library's own RCCL communicator (ncclCommCount == 2), in line
+    and overlapped (the ring check runs on both ranks), counters = oracle sum over both shards."""
+    _need_two(hip)
+    import json
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+    for extra in ((), ("--overlap",)):
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--flags-per-gpu", str(2 ** 28), "--steps", "10",
+                            "--warmup", "3", "--cpu-seconds", "0", "--probe-reps", "3", *extra],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT)
+        assert r.returncode == 0, r.stdout + r.stderr
+        d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][0])
+        assert d["n_gpus"] == 2 and d["config"]["rccl_nranks"] == 2 and d["parity"].startswith("bit-exact"), d
