@@ -166,6 +166,11 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *   "group_min_grid" K1's atomic epilogue goes through the workspace's 8 per-XCD copies (8 x 2 contended adds on the
  *                    caller's counters per launch instead of one pair per workgroup) from this many workgroups on
  *                    (default 64; 0 = always)
+ *   "small_flags"    host-pointer calls of up to this many flags (default and maximum 1048576) are copied by the CPU into a pinned buffer
+ *                    that K1 reads in place over PCIe -- no copy call; larger single-chunk calls use an asynchronous H2D
+ *                    copy into device staging.  0 = always stage
+ *   "poll"           1 (default): single-chunk host-pointer calls wait for a completion word the last kernel writes next to
+ *                    the counters in pinned host memory instead of synchronising the stream; 0 = hipStreamSynchronize
  *   "epoch_stagger"  1 (default): the four waves of a K1 workgroup fold their bit-sliced counters (every 255 steps)
  *                    at different steps, so HBM never idles for it chip-wide; 0 = all at the same step (r02)
  *   "fence_free_events" FLAGSTATS_hip_stream_wait_stream / the overlapped all-reduce: 1 = ordering events without the

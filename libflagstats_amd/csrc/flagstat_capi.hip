@@ -156,6 +156,11 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
     } else if (!std::strcmp(key, "epilogue")) {
         if (value > 1) return fail_text("epilogue must be 0 (partials + K2) or 1 (atomic adds from K1)");
         k.epilogue = static_cast<int>(value);
+    } else if (!std::strcmp(key, "small_flags")) {
+        k.small_flags = value;
+    } else if (!std::strcmp(key, "poll")) {
+        if (value > 1) return fail_text("poll must be 0 or 1");
+        k.poll = static_cast<int>(value);
     } else if (!std::strcmp(key, "epoch_stagger")) {
         if (value > 1) return fail_text("epoch_stagger must be 0 or 1");
         k.epoch_stagger = static_cast<int>(value);
@@ -208,6 +213,8 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "dyn_min_steps")) return k.dyn_min_steps.load();
     if (!std::strcmp(key, "dyn_lg_queues")) return k.dyn_lgq.load();
     if (!std::strcmp(key, "group_min_grid")) return k.group_min_grid.load();
+    if (!std::strcmp(key, "small_flags")) return k.small_flags.load();
+    if (!std::strcmp(key, "poll")) return static_cast<uint64_t>(k.poll.load());
     if (!std::strcmp(key, "epoch_stagger")) return static_cast<uint64_t>(k.epoch_stagger.load());
     if (!std::strcmp(key, "fuse")) return static_cast<uint64_t>(k.fuse.load());
     if (!std::strcmp(key, "epilogue")) return static_cast<uint64_t>(k.epilogue.load());

@@ -31,6 +31,9 @@ struct Knobs {
     std::atomic<uint32_t> blocks_per_cu{0};       // 0 = auto (1)
     std::atomic<int> variant{25};                 // K1 schedule, see flagstat_kernels.hip
     std::atomic<uint32_t> dyn_first_pct{75}, dyn_div{4}, dyn_cmax{32}, dyn_min_steps{32}, dyn_lgq{3};  // dynamic schedule (variant bit 7)
+    std::atomic<uint64_t> small_flags{1ull << 20}; // host arrays up to this many flags: copied into the pinned input buffer and read
+                                                  // in place (no H2D copy call); 0 = always stage through device memory
+    std::atomic<int> poll{1};                     // single-launch host calls wait by polling a completion word the kernel writes
     std::atomic<int> epoch_stagger{1};            // K1: waves of a workgroup flush their epochs at different steps
     std::atomic<uint32_t> group_min_grid{64};     // K1's atomic epilogue goes through per-XCD copies from this many workgroups on
     std::atomic<int> fuse{0};                     // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
@@ -57,7 +60,12 @@ struct Engine {
     uint64_t* d_out[2] = {nullptr, nullptr};       // device uint64[32] per slot
     uint16_t* stage[2] = {nullptr, nullptr};       // device staging for host arrays
     uint64_t stage_flags[2] = {0, 0};
-    uint64_t* h_out = nullptr;                     // pinned 2 x 32 (also mapped into the device)
+    uint64_t* h_out = nullptr;                     // pinned 2 x 32 (also mapped into the device); words 64..127 = the small-call path's {value, seq} pairs
+    uint64_t* h_out_dev = nullptr;                 // the same buffer as the device sees it
+    uint16_t* small_in = nullptr;                  // pinned input buffer of the small-call path, read in place by K1
+    uint16_t* small_in_dev = nullptr;
+    uint64_t small_seq = 0;                        // sequence number of the last small call (what its kernel stores next to each slot)
+    uint32_t small_since_sync = 0;                 // polled calls since the stream was last synchronised
     hipEvent_t chunk_done[2] = {nullptr, nullptr}; // host streaming: chunk in slot i has been counted
     uint64_t host_chunks = 0;                      // last multi-chunk host call: chunks submitted ...
     uint64_t host_overlapped = 0;                  // ... and how many were submitted while the previous one was still in flight
@@ -116,7 +124,7 @@ uint32_t grid_for(const Engine& e);
 int ensure_ws(Workspace& w, uint32_t grid, hipStream_t s);  // zeroed (stream-ordered on s) at creation
 // K1 + K2 on `s`: d_out += (or =, OP_FLAGSTAT_STORE) counters of d_array[0..n).  Device must be current.
 int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w,
-                       int op = OP_FLAGSTAT);
+                       int op = OP_FLAGSTAT, uint64_t* signal_word = nullptr, uint64_t signal_value = 0);
 // the same for a caller-owned stream: validates devices, finds / creates the stream's workspace
 int count_on_user_stream(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream, int op);
 // host array -> counters through the engine's two-stream pipeline; takes e.mu

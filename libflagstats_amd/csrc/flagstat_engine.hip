@@ -4,6 +4,8 @@
 // Replaces the state-free dispatch of the reference (libflagstats.h:2976-3070); see flagstat_engine.h.
 #include "flagstat_engine.h"
 
+#include <emmintrin.h>
+#include <smmintrin.h>
 #include <sys/syscall.h>
 #include <unistd.h>
 
@@ -19,6 +21,9 @@
 namespace fsint {
 
 namespace {
+
+constexpr size_t kHostOutBytes = 1024;             // words 0..63: 2 x 32 counters; words 64..127: the small-call path's 32 {value, seq} pairs
+constexpr size_t kSmallInBytes = 2ull << 20;       // pinned input buffer: up to 1 Mi flags (knob small_flags picks the threshold)
 
 thread_local std::string g_err;
 
@@ -46,6 +51,8 @@ void read_env_knobs()
         g_knobs.dyn_div = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_DIV", g_knobs.dyn_div));
         g_knobs.dyn_cmax = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_CMAX", g_knobs.dyn_cmax));
         g_knobs.dyn_min_steps = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_MIN_STEPS", g_knobs.dyn_min_steps));
+        g_knobs.small_flags = env_u64("FLAGSTATS_HIP_SMALL_FLAGS", g_knobs.small_flags);
+        g_knobs.poll = static_cast<int>(env_u64("FLAGSTATS_HIP_POLL", static_cast<uint64_t>(g_knobs.poll)));
         g_knobs.epoch_stagger = static_cast<int>(env_u64("FLAGSTATS_HIP_EPOCH_STAGGER", static_cast<uint64_t>(g_knobs.epoch_stagger)));
         fsk_set_epoch_stagger(g_knobs.epoch_stagger.load());
         g_knobs.group_min_grid = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_GROUP_MIN_GRID", g_knobs.group_min_grid));
@@ -102,6 +109,7 @@ void release_engine_resources(Engine& e)
         ev = nullptr;
     }
     if (e.h_out) (void)hipHostFree(e.h_out);
+    if (e.small_in) (void)hipHostFree(e.small_in);
     for (int i = 0; i < 2; ++i)
         if (e.chunk_done[i]) (void)hipEventDestroy(e.chunk_done[i]);
     for (int i = 0; i < 3; ++i)
@@ -134,7 +142,11 @@ int engine_setup(Engine& e, int device)
         HIP_TRY(hipMalloc(&e.d_out[i], 4096));  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
         HIP_TRY(hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming));
     }
-    HIP_TRY(hipHostMalloc(&e.h_out, 2 * 32 * sizeof(uint64_t), hipHostMallocDefault));
+    HIP_TRY(hipHostMalloc(&e.h_out, kHostOutBytes, hipHostMallocDefault));
+    std::memset(e.h_out, 0, kHostOutBytes);
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e.h_out_dev), e.h_out, 0));
+    HIP_TRY(hipHostMalloc(&e.small_in, kSmallInBytes, hipHostMallocDefault));
+    HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e.small_in_dev), e.small_in, 0));
     return 0;
 }
 
@@ -401,7 +413,8 @@ int ensure_ws(Workspace& w, uint32_t grid, hipStream_t s)
     return 0;
 }
 
-int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w, int op)
+int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* d_out, hipStream_t s, Workspace& w, int op,
+                       uint64_t* signal_word, uint64_t signal_value)
 {
     const int base = op & OP_BASE_MASK;
     if (n == 0) {
@@ -421,7 +434,8 @@ int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t*
         const int variant = g_knobs.variant.load() | (base == OP_FLAGSTAT_STORE ? 256 : 0) |
                             ((g_knobs.fuse.load() && !direct) ? 512 : 0) | ((op & OP_SUPERSET) ? 1024 : 0) | (direct ? 2048 : 0);
         HIP_TRY(fsk_launch(d_array, n, grid, variant, w.partials,
-                           reinterpret_cast<uint32_t*>(w.partials + static_cast<size_t>(w.grid_cap) * fsk::kInternal), d_out, s));
+                           reinterpret_cast<uint32_t*>(w.partials + static_cast<size_t>(w.grid_cap) * fsk::kInternal), d_out, s,
+                           signal_word, signal_value));
     }
     return 0;
 }
@@ -550,19 +564,68 @@ int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
     const uint64_t chunk = g_knobs.chunk_flags.load() < 8 ? 8 : g_knobs.chunk_flags.load();
     const int slots = (n > chunk) ? 2 : 1;
     int rc = 0;
-    for (int i = 0; i < slots && !rc; ++i) rc = stage_reserve(e, i, n < chunk ? n : chunk);
+    const bool small_in_place = slots == 1 && (op & OP_BASE_MASK) == OP_FLAGSTAT && n <= g_knobs.small_flags.load() &&
+                                n * sizeof(uint16_t) <= kSmallInBytes;
+    for (int i = 0; i < slots && !rc && !small_in_place; ++i) rc = stage_reserve(e, i, n < chunk ? n : chunk);
     if (rc) return rc;
     if (slots == 1 && (op & OP_BASE_MASK) == OP_FLAGSTAT) {
-        // latency path (what an unmodified per-block caller of the reference hits, e.g. 512,000 flags
-        // per call, benchmark/flagstats.cpp:328-329): one copy, K1, and K2 STORING straight into the
-        // pinned host result buffer -- no counter memset, no D2H copy
-        uint64_t* h_out_dev = nullptr;
-        HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&h_out_dev), e.h_out, 0));
-        HIP_TRY(hipMemcpyAsync(e.stage[0], h, n * sizeof(uint16_t), hipMemcpyHostToDevice, e.stream[0]));
-        rc = count_device_async(e, e.stage[0], n, h_out_dev, e.stream[0], e.ws[0], OP_FLAGSTAT_STORE | (op & OP_SUPERSET));
+        // Latency path (what an unmodified per-block or per-read caller of the reference hits, e.g. 512,000 flags per
+        // call, benchmark/flagstats.cpp:328-329).  One launch sequence whose last kernel STORES the 32 slots straight
+        // into the pinned host result buffer (no counter memset, no D2H copy) and then writes this call's sequence
+        // number next to them; the host polls that word instead of synchronising the stream (a synchronous stream
+        // round trip is ~20 us of the r02 path's 23).  Input: up to `small_flags` flags are copied by the CPU into a
+        // pinned buffer that K1 reads in place over PCIe (no copy call, no DMA set-up: a copy call alone is 10-12 us);
+        // above that (measured: between 1 Mi and 2 Mi flags, profiles/r03/small_calls_threshold.log) the runtime's
+        // asynchronous H2D copy into device staging is faster than the CPU's memcpy.
+        const bool in_place = n <= g_knobs.small_flags.load() && n * sizeof(uint16_t) <= kSmallInBytes;
+        const bool poll = g_knobs.poll.load() != 0;
+        const uint16_t* src = e.stage[0];
+        if (in_place) {
+            std::memcpy(e.small_in, h, n * sizeof(uint16_t));
+            src = e.small_in_dev;
+        } else {
+            HIP_TRY(hipMemcpyAsync(e.stage[0], h, n * sizeof(uint16_t), hipMemcpyHostToDevice, e.stream[0]));
+        }
+        const uint64_t seq = ++e.small_seq;
+        // polled: the last kernel writes 32 {value, seq} pairs (16-byte stores) to h_out[64..127]; else plain slots to h_out[0..31]
+        rc = count_device_async(e, src, n, e.h_out_dev, e.stream[0], e.ws[0], OP_FLAGSTAT_STORE | (op & OP_SUPERSET),
+                                poll ? e.h_out_dev + 64 : nullptr, seq);
         if (rc) return rc;
-        HIP_TRY(hipStreamSynchronize(e.stream[0]));
-        for (int s = 0; s < 32; ++s) out[s] += e.h_out[s];
+        if (!poll) {
+            HIP_TRY(hipStreamSynchronize(e.stream[0]));
+            for (int s = 0; s < 32; ++s) out[s] += e.h_out[s];
+            return 0;
+        }
+        // A pair is read with ONE aligned 16-byte load (atomic on every x86 with AVX), so a value is never paired with
+        // another call's sequence number.  The stores are on their way within ~10 us; after ~2 ms of polling (a busy
+        // GPU, a debugger) the stream wait takes over -- it also reports launch failures.
+        const __m128i* pairs = reinterpret_cast<const __m128i*>(e.h_out + 64);
+        uint64_t got[32];
+        uint32_t have = 0;  // bit t: slot t of this call has arrived
+        for (uint32_t spin = 0; have != 0xFFFFFFFFu; ++spin) {
+            for (int t = 0; t < 32; ++t) {
+                if (have & (1u << t)) continue;
+                const __m128i v = _mm_load_si128(pairs + t);
+                if (static_cast<uint64_t>(_mm_extract_epi64(v, 1)) == seq) {
+                    got[t] = static_cast<uint64_t>(_mm_cvtsi128_si64(v));
+                    have |= 1u << t;
+                }
+            }
+            if (have == 0xFFFFFFFFu) break;
+            if (spin == 200000u) {
+                HIP_TRY(hipStreamSynchronize(e.stream[0]));
+                e.small_since_sync = 0;
+            } else if (spin > 200100u) {
+                return fail_text("the kernels finished without writing this call's result pairs");
+            }
+            _mm_pause();
+        }
+        if (++e.small_since_sync >= 256) {
+            // (every 256th polled call also waits on the stream, so the runtime retires its finished commands)
+            HIP_TRY(hipStreamSynchronize(e.stream[0]));
+            e.small_since_sync = 0;
+        }
+        for (int s = 0; s < 32; ++s) out[s] += got[s];
         return 0;
     }
     for (int i = 0; i < slots; ++i) HIP_TRY(hipMemsetAsync(e.d_out[i], 0, 32 * sizeof(uint64_t), e.stream[i]));

@@ -28,6 +28,13 @@ struct DynSched {
     uint32_t lgq;
 };
 
+// result pairs in pinned host memory for a polling host thread: pairs[2 * t] = slot t, pairs[2 * t + 1] = `value`, the
+// sequence number that marks THIS call's result, both written by one 16-byte store (nullptr: none; out[] is used)
+struct HostSignal {
+    uint64_t* pairs;
+    uint64_t value;
+};
+
 struct CountArgs {
     const void* a0;        // 16-B aligned-down base of the array
     uint64_t lo, hi;       // caller's flags occupy positions [lo, hi) of that grid
@@ -39,10 +46,12 @@ struct CountArgs {
     uint32_t* ticket;      // non-null: fused finalise by the last-arriving workgroup (must be 0 at launch)
     uint64_t* out;         // device uint64[32]
     DynSched dyn;
+    HostSignal sig;
     int mode;              // bit 0: out = counters instead of +=; bit 1: superset slots (0/16 n_pair_all, 9 pass-QC reads);
                            // bit 2: direct epilogue -- every workgroup adds its totals to out[] with atomics, no K2;
                            // bit 3 (with bit 2): through the workspace's per-XCD copies (grouped_epilogue);
-                           // bit 4: the waves of a workgroup start their first epoch at different counts
+                           // bit 4: the waves of a workgroup start their first epoch at different counts;
+                           // bit 5: latency form -- a grid of one workgroup stores all 32 slots and signals `sig`, no K2
 };
 
 }  // namespace fsk
@@ -53,8 +62,12 @@ size_t fsk_partials_bytes(uint32_t grid);
 // K1 + K2 on `stream`: d_out32[32] += counters of d_array[0..n).  Asynchronous.
 // variant bits 0-7: K1 schedule; bit 8: store instead of accumulate; bit 9: fused finalise (needs d_ticket);
 // bit 10: superset slots; bit 11: direct atomic epilogue (accumulate form only; K1 alone, no K2)
+// signal_word != nullptr (store form only): the kernel that finishes the counters writes them as 32 {value,
+// signal_value} pairs of 16 bytes to signal_word[0..63] (pinned host memory) instead of d_out32 -- a host thread may
+// poll the pairs instead of synchronising the stream.
 hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
-                      uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream);
+                      uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream, uint64_t* signal_word = nullptr,
+                      uint64_t signal_value = 0);
 int fsk_variant_supported(int variant);   // K1 schedule compiled into this build?
 // dynamic schedule policy (variant bit 7): first_pct = share of the steps in the static round 0 (0..100), div and cmax
 // as in DynSched; arrays of fewer than min_steps_per_wg full steps per workgroup stay fully static

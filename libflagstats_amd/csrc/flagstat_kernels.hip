@@ -357,6 +357,23 @@ __device__ __forceinline__ void flush(Lane<DEPTH>& s, uint32_t pushed)
 // Without bit 1 the 32 slots are exactly FLAGSTAT_scalar's (libflagstats.h:118-142).
 // ATOMIC (K1's direct epilogue): tot[] are ONE workgroup's totals, added with relaxed agent-scope
 // atomics -- any number of launches, on any streams, may target the same out[32].
+// Result hand-over to a host thread that polls instead of waiting on the stream (the small-call path; a synchronous
+// stream round trip is ~20 us here, profiles/r02/latency_breakdown.log).  Thread t < 32 stores {slot value, sequence
+// number of the call} as ONE 16-byte store into pairs[t] (pinned host memory): a slot is complete when its sequence
+// field matches, so no fence, no separate "done" word and no second bus round trip order the two (an aligned 16-byte
+// store is a single write on the bus, and the host reads it back with one aligned 16-byte load).
+__device__ __forceinline__ void store_pair(const HostSignal& sig, uint64_t value)
+{
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 v;
+    v.x = static_cast<uint32_t>(value);
+    v.y = static_cast<uint32_t>(value >> 32);
+    v.z = static_cast<uint32_t>(sig.value);
+    v.w = static_cast<uint32_t>(sig.value >> 32);
+    // sc0 sc1 = system scope: written through to the host now, not at the kernel's end
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1" ::"v"(reinterpret_cast<u32x4*>(sig.pairs) + threadIdx.x), "v"(v) : "memory");
+}
+
 // what thread t < 32 contributes to slot t
 __device__ __forceinline__ uint64_t slot_value(const uint64_t* tot, int mode, uint64_t n_flags)
 {
@@ -469,7 +486,7 @@ template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE>
 __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
                                                            uint64_t* __restrict__ partials, uint32_t* ticket,
-                                                           uint64_t* out, int mode, DynSched dyn)
+                                                           uint64_t* out, int mode, DynSched dyn, HostSignal sig)
 {
 #ifdef FLAGSTAT_TUNING_VARIANTS
     // workgroup timeline (tools/timeline.py; mode bit 11): wave 0 stamps the 100 MHz wall clock at entry, after its
@@ -763,6 +780,16 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagsta
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) sum += red[w][threadIdx.x];
     }
+    if (mode & 32) {
+        // Latency form (a grid of ONE workgroup, result pairs in pinned host memory): this workgroup's totals ARE the
+        // result, so it stores all 32 slots itself ("=" form) -- no partials, no K2 launch -- each with the call's
+        // sequence number for the host thread polling them.
+        __shared__ uint64_t one_tot[32];
+        if (threadIdx.x < kInternal) one_tot[threadIdx.x] = sum;
+        __syncthreads();
+        if (threadIdx.x < 32) store_pair(sig, slot_value(one_tot, mode, hi - lo));
+        return;
+    }
     if (mode & 4) {
         // Direct epilogue (accumulate contract only): this workgroup maps ITS 21 totals to the
         // reference's slots and adds them to out[32] with relaxed agent-scope atomics (no return, no
@@ -873,7 +900,7 @@ constexpr int kFinalizeThreads = 1024;
 
 __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint64_t* __restrict__ partials,
                                                                       uint32_t nblocks, uint64_t* __restrict__ out,
-                                                                      int mode, uint64_t n_flags)
+                                                                      int mode, uint64_t n_flags, HostSignal sig)
 {
     __shared__ uint64_t tot[32];
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
@@ -885,6 +912,10 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
         if (lane == 0) tot[c] = x;
     }
     __syncthreads();
+    if (sig.pairs != nullptr) {
+        if (threadIdx.x < 32) store_pair(sig, slot_value(tot, mode, n_flags));  // "=" form for a polling host thread
+        return;
+    }
     finalize_slots(tot, out, mode, n_flags);
 }
 
@@ -928,14 +959,15 @@ static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
     hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, STAGE>), dim3(a.grid),
                        dim3(STAGE == 4 ? fsk::kThreads + 64 : fsk::kThreads), 0, stream,
                        reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials,
-                       a.ticket, a.out, a.mode, a.dyn);
+                       a.ticket, a.out, a.mode, a.dyn, a.sig);
     return hipGetLastError();
 }
 
 // Host-side geometry: everything the kernel assumes is derived here from
 // (pointer, n) so operand shapes and the grid cannot disagree.
 extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials,
-                                 uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream)
+                                 uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream, uint64_t* signal_word,
+                                 uint64_t signal_value)
 {
     if (n == 0) return hipSuccess;
     if (grid == 0 || d_array == nullptr || d_partials == nullptr || d_out32 == nullptr) return hipErrorInvalidValue;
@@ -978,6 +1010,11 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     a.dyn = fsk::DynSched{reinterpret_cast<uint64_t*>(d_ticket), 0xFFFFFFFFu, 0, 1, 0};
     // direct epilogue: many workgroups add to per-XCD copies first (grouped_epilogue); few add straight to out[]
     if (g_epoch_stagger.load()) a.mode |= 16;
+    // store form with a completion word: a grid of one workgroup stores its totals itself (K1's latency form, no K2);
+    // larger grids go through K2, which signals after its stores
+    a.sig = fsk::HostSignal{signal_word, signal_value};
+    if (signal_word && !(a.mode & 1)) return hipErrorInvalidValue;  // pairs carry "=" results only
+    if (signal_word && (a.mode & 1) && !(a.mode & 4) && grid == 1 && !((variant >> 9) & 1)) a.mode |= 32;
     if ((a.mode & 4) && grid >= g_group_min_grid.load() && d_ticket != nullptr && !(a.mode & 4096)) a.mode |= 8;
     if (variant & 128) {
         // round 0 takes first_pct of the full steps; too few steps per workgroup to be worth balancing: all of them
@@ -1024,9 +1061,9 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     default: return hipErrorInvalidValue;
     }
     if (e != hipSuccess) return e;
-    if (a.ticket || (a.mode & 4)) return hipSuccess;  // K1 finalised by itself
+    if (a.ticket || (a.mode & (4 | 32))) return hipSuccess;  // K1 finalised by itself
     hipLaunchKernelGGL(fsk::flagstat_finalize, dim3(1), dim3(fsk::kFinalizeThreads), 0, stream, d_partials, grid, d_out32,
-                       a.mode, n);
+                       a.mode, n, a.sig);
     return hipGetLastError();
 }
 
@@ -1050,9 +1087,9 @@ extern "C" uint32_t fsk_timeline_run(const uint16_t* d_array, uint64_t n, uint32
         bool ok = true;
         uint32_t* block = reinterpret_cast<uint32_t*>(partials + static_cast<size_t>(grid) * fsk::kInternal);
         for (int i = 0; i < warm && ok; ++i)
-            ok = fsk_launch(d_array, n, grid, (variant & 255) | 2048, partials, block, out, s) == hipSuccess;
+            ok = fsk_launch(d_array, n, grid, (variant & 255) | 2048, partials, block, out, s, nullptr, 0) == hipSuccess;
         g_timeline = rows;
-        ok = ok && fsk_launch(d_array, n, grid, (variant & 255) | 2048, partials, block, out, s) == hipSuccess;
+        ok = ok && fsk_launch(d_array, n, grid, (variant & 255) | 2048, partials, block, out, s, nullptr, 0) == hipSuccess;
         g_timeline = nullptr;
         ok = ok && hipStreamSynchronize(s) == hipSuccess;
         const uint64_t nvec = (n + 7 + 7) / 8;  // upper bound on the steps (a ragged head adds at most one)

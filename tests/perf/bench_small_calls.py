@@ -17,8 +17,13 @@ _lib.check(lib.FLAGSTATS_hip_init(0), "init")
 import oracle  # noqa: E402
 
 ref = oracle.load_ref()
+# `--old`: the r02 path for comparison (device staging for every size, hipStreamSynchronize)
+if "--old" in sys.argv:
+    lib.FLAGSTATS_hip_set(b"small_flags", 0)
+    lib.FLAGSTATS_hip_set(b"poll", 0)
+print("small_flags=%d poll=%d" % (lib.FLAGSTATS_hip_get(b"small_flags"), lib.FLAGSTATS_hip_get(b"poll")))
 print("flags      hip_us/call  hip_Gflags/s   ref_us/call  ref_Gflags/s")
-for n in (1000, 16384, 131072, 512000, 2 ** 21, 2 ** 24, 2 ** 26):
+for n in (1000, 16384, 50000, 100000, 131072, 200000, 512000, 2 ** 21, 2 ** 24, 2 ** 26):
     a = oracle.generate(oracle.GEN_NA12878, 1, 1, 0, n)
     flags = np.zeros(32, dtype=np.uint32)
     reps = max(20, min(2000, 2 ** 28 // n))
