@@ -34,6 +34,31 @@ std::atomic<int> g_default_device{-1};
 Knobs g_knobs;
 std::once_flag g_env_once;
 
+// The small-call path's hand-over: the last kernel of a call stores 32 {value, sequence number} pairs, each with ONE
+// aligned 16-byte store; each is read back here with ONE aligned 16-byte load (atomic on every x86 with AVX), so a
+// value is never paired with another call's sequence number and no fence or second word orders them.  Returns 0 when
+// all 32 slots of call `seq` have arrived, 1 after `spins` rounds without them.
+// (no_sanitize: the protocol is between the bus and the CPU, not between threads; the host-stub build's TSan run would
+// otherwise see 16-byte loads racing with the stub's 8-byte atomic stores.)
+__attribute__((no_sanitize("thread"))) int poll_pairs(const uint64_t* pairs64, uint64_t seq, uint64_t got[32], uint32_t spins)
+{
+    const __m128i* pairs = reinterpret_cast<const __m128i*>(pairs64);
+    uint32_t have = 0;  // bit t: slot t of this call has arrived
+    for (uint32_t spin = 0; spin < spins; ++spin) {
+        for (int t = 0; t < 32; ++t) {
+            if (have & (1u << t)) continue;
+            const __m128i v = _mm_load_si128(pairs + t);
+            if (static_cast<uint64_t>(_mm_extract_epi64(v, 1)) == seq) {
+                got[t] = static_cast<uint64_t>(_mm_cvtsi128_si64(v));
+                have |= 1u << t;
+            }
+        }
+        if (have == 0xFFFFFFFFu) return 0;
+        _mm_pause();
+    }
+    return 1;
+}
+
 uint64_t env_u64(const char* name, uint64_t dflt)
 {
     const char* s = std::getenv(name);
@@ -596,29 +621,14 @@ int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
             for (int s = 0; s < 32; ++s) out[s] += e.h_out[s];
             return 0;
         }
-        // A pair is read with ONE aligned 16-byte load (atomic on every x86 with AVX), so a value is never paired with
-        // another call's sequence number.  The stores are on their way within ~10 us; after ~2 ms of polling (a busy
-        // GPU, a debugger) the stream wait takes over -- it also reports launch failures.
-        const __m128i* pairs = reinterpret_cast<const __m128i*>(e.h_out + 64);
         uint64_t got[32];
-        uint32_t have = 0;  // bit t: slot t of this call has arrived
-        for (uint32_t spin = 0; have != 0xFFFFFFFFu; ++spin) {
-            for (int t = 0; t < 32; ++t) {
-                if (have & (1u << t)) continue;
-                const __m128i v = _mm_load_si128(pairs + t);
-                if (static_cast<uint64_t>(_mm_extract_epi64(v, 1)) == seq) {
-                    got[t] = static_cast<uint64_t>(_mm_cvtsi128_si64(v));
-                    have |= 1u << t;
-                }
-            }
-            if (have == 0xFFFFFFFFu) break;
-            if (spin == 200000u) {
-                HIP_TRY(hipStreamSynchronize(e.stream[0]));
-                e.small_since_sync = 0;
-            } else if (spin > 200100u) {
-                return fail_text("the kernels finished without writing this call's result pairs");
-            }
-            _mm_pause();
+        int prc = poll_pairs(e.h_out + 64, seq, got, 200000u);
+        if (prc == 1) {
+            // ~2 ms of polling (a busy GPU, a debugger): let the stream wait take over -- it also reports launch failures
+            HIP_TRY(hipStreamSynchronize(e.stream[0]));
+            e.small_since_sync = 0;
+            prc = poll_pairs(e.h_out + 64, seq, got, 100u);
+            if (prc) return fail_text("the kernels finished without writing this call's result pairs");
         }
         if (++e.small_since_sync >= 256) {
             // (every 256th polled call also waits on the stream, so the runtime retires its finished commands)

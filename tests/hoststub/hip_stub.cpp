@@ -1,0 +1,457 @@
+// TEST-ONLY HIP runtime stand-in (see hip/hip_runtime.h next to this file): device memory = host memory, one FIFO worker
+// thread per stream, events as generation counters, and the kernels' launchers (fsk_*) replaced by closures that compute
+// the same counters with the ORACLE's scalar rule on the stream's thread.  Purpose: run the product's host code -- engine
+// registry and locks, the block pipeline's decoder threads / condition variables / pinned-buffer rotation, sessions, the
+// multi-device entry -- under ThreadSanitizer.  A buffer that the host re-uses before the "GPU" work on it has been
+// waited for is a data race here, and TSan reports it.
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <deque>
+#include <functional>
+#include <map>
+#include <mutex>
+#include <thread>
+#include <vector>
+
+#include "../../libflagstats_amd/csrc/flagstat_kernels.h"
+
+extern "C" {
+#include "../../oracle/flagstat_oracle.h"
+}
+
+// ------------------------------------------------------------------ streams
+struct StubStream {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    uint64_t submitted = 0, done = 0;
+    bool stop = false;
+    int device = 0;
+
+    void run()
+    {
+        for (;;) {
+            std::function<void()> fn;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !q.empty(); });
+                if (q.empty()) return;
+                fn = std::move(q.front());
+                q.pop_front();
+            }
+            fn();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                ++done;
+            }
+            cv.notify_all();
+        }
+    }
+};
+
+struct StubEvent {
+    std::mutex mu;
+    std::condition_variable cv;
+    uint64_t issued = 0, completed = 0;
+    std::chrono::steady_clock::time_point when;
+};
+
+namespace {
+
+thread_local int t_device = 0;
+std::mutex g_mu;                       // stream registry + allocation map
+std::vector<StubStream*> g_streams;
+std::map<int, StubStream*> g_null;     // per-device NULL stream
+
+struct Alloc {
+    size_t bytes;
+    hipMemoryType type;
+    int device;
+};
+std::map<uintptr_t, Alloc> g_allocs;
+
+int device_count()
+{
+    const char* s = std::getenv("FLAGSTATS_STUB_DEVICES");
+    return s && *s ? std::atoi(s) : 2;
+}
+
+StubStream* make_stream(int device)
+{
+    StubStream* s = new StubStream();
+    s->device = device;
+    s->th = std::thread([s] { s->run(); });
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_streams.push_back(s);
+    return s;
+}
+
+StubStream* resolve(hipStream_t s)
+{
+    if (s) return s;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        auto it = g_null.find(t_device);
+        if (it != g_null.end()) return it->second;
+    }
+    StubStream* n = make_stream(t_device);
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto ins = g_null.emplace(t_device, n);
+    return ins.first->second;
+}
+
+void enqueue(hipStream_t hs, std::function<void()> fn)
+{
+    StubStream* s = resolve(hs);
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->q.push_back(std::move(fn));
+        ++s->submitted;
+    }
+    s->cv.notify_all();
+}
+
+void sync_stream(StubStream* s)
+{
+    std::unique_lock<std::mutex> lk(s->mu);
+    const uint64_t target = s->submitted;
+    s->cv.wait(lk, [&] { return s->done >= target; });
+}
+
+void remember(void* p, size_t bytes, hipMemoryType type)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    g_allocs[reinterpret_cast<uintptr_t>(p)] = Alloc{bytes, type, t_device};
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------ devices
+hipError_t hipGetDeviceCount(int* n)
+{
+    *n = device_count();
+    return *n > 0 ? hipSuccess : hipErrorNoDevice;
+}
+hipError_t hipGetDevice(int* d)
+{
+    *d = t_device;
+    return hipSuccess;
+}
+hipError_t hipSetDevice(int d)
+{
+    if (d < 0 || d >= device_count()) return hipErrorInvalidValue;
+    t_device = d;
+    return hipSuccess;
+}
+hipError_t hipGetDeviceProperties(hipDeviceProp_t* p, int d)
+{
+    if (d < 0 || d >= device_count()) return hipErrorInvalidValue;
+    std::snprintf(p->gcnArchName, sizeof p->gcnArchName, "gfx950:sramecc+:xnack-");
+    p->multiProcessorCount = 8;
+    return hipSuccess;
+}
+hipError_t hipDeviceGetPCIBusId(char* buf, int len, int d)
+{
+    std::snprintf(buf, static_cast<size_t>(len), "ffff:ff:%02x.0", d);
+    return hipSuccess;
+}
+hipError_t hipDeviceSynchronize(void)
+{
+    std::vector<StubStream*> all;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        all = g_streams;
+    }
+    for (StubStream* s : all)
+        if (s->device == t_device) sync_stream(s);
+    return hipSuccess;
+}
+hipError_t hipGetLastError(void) { return hipSuccess; }
+const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "stub error"; }
+
+// ------------------------------------------------------------------ memory
+hipError_t hipMalloc(void** p, size_t bytes)
+{
+    *p = std::aligned_alloc(256, (bytes + 255) & ~static_cast<size_t>(255));
+    if (!*p) return hipErrorInvalidValue;
+    remember(*p, bytes, hipMemoryTypeDevice);
+    return hipSuccess;
+}
+hipError_t hipFree(void* p)
+{
+    if (!p) return hipSuccess;
+    (void)hipDeviceSynchronize();  // like the real one: waits for the device's work
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_allocs.erase(reinterpret_cast<uintptr_t>(p));
+    }
+    std::free(p);
+    return hipSuccess;
+}
+hipError_t hipHostMalloc(void** p, size_t bytes, unsigned)
+{
+    *p = std::aligned_alloc(4096, (bytes + 4095) & ~static_cast<size_t>(4095));
+    if (!*p) return hipErrorInvalidValue;
+    remember(*p, bytes, hipMemoryTypeHost);
+    return hipSuccess;
+}
+hipError_t hipHostFree(void* p)
+{
+    if (!p) return hipSuccess;
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        g_allocs.erase(reinterpret_cast<uintptr_t>(p));
+    }
+    std::free(p);
+    return hipSuccess;
+}
+hipError_t hipHostGetDevicePointer(void** dp, void* hp, unsigned)
+{
+    *dp = hp;
+    return hipSuccess;
+}
+hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    const uintptr_t x = reinterpret_cast<uintptr_t>(p);
+    auto it = g_allocs.upper_bound(x);
+    if (it == g_allocs.begin()) return hipErrorInvalidValue;
+    --it;
+    if (x >= it->first + it->second.bytes) return hipErrorInvalidValue;
+    a->type = it->second.type;
+    a->device = it->second.device;
+    return hipSuccess;
+}
+hipError_t hipMemcpy(void* dst, const void* src, size_t bytes, hipMemcpyKind)
+{
+    std::memcpy(dst, src, bytes);
+    return hipSuccess;
+}
+hipError_t hipMemcpyAsync(void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t s)
+{
+    if (kind == hipMemcpyHostToDevice) {
+        bool pinned = false;
+        hipPointerAttribute_t a;
+        if (hipPointerGetAttributes(&a, src) == hipSuccess) pinned = true;
+        if (!pinned) {
+            // pageable source: the real runtime stages it before the call returns
+            std::vector<unsigned char>* tmp = new std::vector<unsigned char>(static_cast<const unsigned char*>(src),
+                                                                              static_cast<const unsigned char*>(src) + bytes);
+            enqueue(s, [dst, tmp] {
+                std::memcpy(dst, tmp->data(), tmp->size());
+                delete tmp;
+            });
+            return hipSuccess;
+        }
+    }
+    enqueue(s, [dst, src, bytes] { std::memcpy(dst, src, bytes); });
+    return hipSuccess;
+}
+hipError_t hipMemset(void* dst, int value, size_t bytes)
+{
+    // NULL-stream semantics of the real thing: asynchronous, NOT ordered against non-blocking streams
+    enqueue(nullptr, [dst, value, bytes] { std::memset(dst, value, bytes); });
+    return hipSuccess;
+}
+hipError_t hipMemsetAsync(void* dst, int value, size_t bytes, hipStream_t s)
+{
+    enqueue(s, [dst, value, bytes] { std::memset(dst, value, bytes); });
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------ streams and events
+hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned)
+{
+    *s = make_stream(t_device);
+    return hipSuccess;
+}
+hipError_t hipStreamDestroy(hipStream_t s)
+{
+    if (!s) return hipErrorInvalidValue;
+    sync_stream(s);
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->stop = true;
+    }
+    s->cv.notify_all();
+    s->th.join();
+    {
+        std::lock_guard<std::mutex> lk(g_mu);
+        for (size_t i = 0; i < g_streams.size(); ++i)
+            if (g_streams[i] == s) {
+                g_streams.erase(g_streams.begin() + static_cast<long>(i));
+                break;
+            }
+    }
+    delete s;
+    return hipSuccess;
+}
+hipError_t hipStreamSynchronize(hipStream_t s)
+{
+    sync_stream(resolve(s));
+    return hipSuccess;
+}
+hipError_t hipStreamGetDevice(hipStream_t s, hipDevice_t* d)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    for (StubStream* k : g_streams)
+        if (k == s) {
+            *d = s->device;
+            return hipSuccess;
+        }
+    return hipErrorInvalidValue;
+}
+hipError_t hipThreadExchangeStreamCaptureMode(hipStreamCaptureMode*) { return hipSuccess; }
+
+hipError_t hipEventCreate(hipEvent_t* e)
+{
+    *e = new StubEvent();
+    return hipSuccess;
+}
+hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned) { return hipEventCreate(e); }
+hipError_t hipEventDestroy(hipEvent_t e)
+{
+    // the real runtime keeps a destroyed event alive until the work that refers to it has run
+    {
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv.wait(lk, [&] { return e->completed >= e->issued; });
+    }
+    delete e;
+    return hipSuccess;
+}
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t s)
+{
+    uint64_t gen;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        gen = ++e->issued;
+    }
+    enqueue(s, [e, gen] {
+        {
+            std::lock_guard<std::mutex> lk(e->mu);
+            if (e->completed < gen) e->completed = gen;
+            e->when = std::chrono::steady_clock::now();
+        }
+        e->cv.notify_all();
+    });
+    return hipSuccess;
+}
+hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned)
+{
+    uint64_t gen;
+    {
+        std::lock_guard<std::mutex> lk(e->mu);
+        gen = e->issued;  // a wait binds to the record that was current when it was queued
+    }
+    enqueue(s, [e, gen] {
+        std::unique_lock<std::mutex> lk(e->mu);
+        e->cv.wait(lk, [&] { return e->completed >= gen; });
+    });
+    return hipSuccess;
+}
+hipError_t hipEventSynchronize(hipEvent_t e)
+{
+    std::unique_lock<std::mutex> lk(e->mu);
+    const uint64_t gen = e->issued;
+    e->cv.wait(lk, [&] { return e->completed >= gen; });
+    return hipSuccess;
+}
+hipError_t hipEventQuery(hipEvent_t e)
+{
+    std::lock_guard<std::mutex> lk(e->mu);
+    return e->completed >= e->issued ? hipSuccess : hipErrorNotReady;
+}
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
+{
+    std::lock_guard<std::mutex> la(a->mu);
+    std::lock_guard<std::mutex> lb(b->mu);
+    *ms = std::chrono::duration<float, std::milli>(b->when - a->when).count();
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------ the kernels' launchers, computed by the oracle
+extern "C" {
+
+size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 8192; }
+
+hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials, uint32_t*,
+                      uint64_t* d_out32, hipStream_t stream, uint64_t* signal_word, uint64_t signal_value)
+{
+    if (n == 0) return hipSuccess;
+    if (!grid || !d_array || !d_partials || !d_out32) return hipErrorInvalidValue;
+    const bool store = (variant >> 8) & 1, superset = (variant >> 10) & 1, direct = (variant >> 11) & 1;
+    if (signal_word && !store) return hipErrorInvalidValue;
+    enqueue(stream, [=] {
+        uint64_t c[32];
+        std::memset(c, 0, sizeof c);
+        oracle_flagstat_u16(d_array, n, c);
+        if (superset) {
+            for (uint64_t i = 0; i < n; ++i) {
+                const uint16_t x = d_array[i];
+                const bool fail = x & 0x200;
+                if ((x & 1) && !(x & 0x100) && !(x & 0x800)) ++c[fail ? 16 : 0];
+                if (!fail) ++c[9];
+            }
+        }
+        if (!direct) d_partials[0] = n;  // the K2 forms write the stream's workspace
+        if (signal_word) {
+            for (int t = 0; t < 32; ++t) {
+                __atomic_store_n(&signal_word[2 * t], c[t], __ATOMIC_RELAXED);
+                __atomic_store_n(&signal_word[2 * t + 1], signal_value, __ATOMIC_RELEASE);
+            }
+        } else if (store) {
+            for (int t = 0; t < 32; ++t) d_out32[t] = c[t];
+        } else if (direct) {
+            for (int t = 0; t < 32; ++t)
+                if (c[t]) __atomic_fetch_add(&d_out32[t], c[t], __ATOMIC_RELAXED);  // K1's atomic epilogue
+        } else {
+            for (int t = 0; t < 32; ++t)
+                if (c[t]) d_out32[t] += c[t];                                       // K2's plain +=
+        }
+    });
+    return hipSuccess;
+}
+
+hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, uint32_t grid, uint64_t* d_partials, uint64_t* d_out16,
+                                hipStream_t stream, int direct)
+{
+    if (n == 0) return hipSuccess;
+    if (!grid || !d_array || !d_partials || !d_out16) return hipErrorInvalidValue;
+    enqueue(stream, [=] {
+        uint64_t c[16];
+        std::memset(c, 0, sizeof c);
+        oracle_pospopcnt_u16(d_array, n, c);
+        for (int t = 0; t < 16; ++t) {
+            if (direct)
+                __atomic_fetch_add(&d_out16[t], c[t], __ATOMIC_RELAXED);
+            else
+                d_out16[t] += c[t];
+        }
+    });
+    return hipSuccess;
+}
+
+hipError_t fsk_generate(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, uint32_t mask, uint64_t first_index, hipStream_t stream)
+{
+    enqueue(stream, [=] { oracle_generate_u16(kind, seed, mask, first_index, n, d_array); });
+    return hipSuccess;
+}
+
+hipError_t fsk_read_probe(const void*, uint64_t, uint32_t, int, uint32_t*, hipStream_t) { return hipSuccess; }
+hipError_t fsk_read_probe2(const void*, uint64_t, int, int, uint32_t, uint32_t, int, uint32_t*, hipStream_t) { return hipSuccess; }
+int fsk_variant_supported(int variant) { return (variant & 255) == 9 || (variant & 255) == 25; }
+void fsk_set_anatomy(int) {}
+int fsk_tuning_build(void) { return 0; }
+void fsk_set_dyn(uint32_t, uint32_t, uint32_t, uint32_t) {}
+void fsk_set_dyn_queues(uint32_t) {}
+void fsk_set_group_min_grid(uint32_t) {}
+void fsk_set_epoch_stagger(int) {}
+
+}  // extern "C"

@@ -1,0 +1,191 @@
+// TEST-ONLY driver for the host-stub build (make -C libflagstats_amd/csrc hoststub): the product's host code linked against
+// tests/hoststub/hip_stub.cpp, run under ThreadSanitizer.  Every result is checked against the oracle.
+//   tsan_driver <dir with the reference-written golden block files>
+#include <atomic>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/libflagstats_hip.h"
+extern "C" {
+#include "../../oracle/flagstat_oracle.h"
+}
+
+static int g_fail = 0;
+#define CHECK(cond, ...)                          \
+    do {                                          \
+        if (!(cond)) {                            \
+            std::fprintf(stderr, "FAIL %s:%d: ", __FILE__, __LINE__); \
+            std::fprintf(stderr, __VA_ARGS__);    \
+            std::fprintf(stderr, "\n");           \
+            ++g_fail;                             \
+        }                                         \
+    } while (0)
+
+static bool same(const uint64_t* a, const uint64_t* b) { return std::memcmp(a, b, 32 * sizeof(uint64_t)) == 0; }
+
+// a valid LZ4 block that stores `n` bytes as one run of literals (token, length bytes, literals; no match)
+static void lz4_store(const unsigned char* src, size_t n, std::vector<unsigned char>& out)
+{
+    out.push_back(static_cast<unsigned char>((n < 15 ? n : 15) << 4));
+    if (n >= 15) {
+        size_t rest = n - 15;
+        while (rest >= 255) {
+            out.push_back(255);
+            rest -= 255;
+        }
+        out.push_back(static_cast<unsigned char>(rest));
+    }
+    out.insert(out.end(), src, src + n);
+}
+
+// block file image: int32 uncompressed_size, int32 compressed_size, <LZ4 block>, ...  (benchmark/flagstats.cpp:119-138)
+static std::vector<unsigned char> make_image(const std::vector<uint16_t>& flags, const std::vector<size_t>& block_flags)
+{
+    std::vector<unsigned char> img;
+    size_t pos = 0;
+    for (size_t b = 0; pos < flags.size(); ++b) {
+        size_t m = block_flags[b % block_flags.size()];
+        if (m > flags.size() - pos) m = flags.size() - pos;
+        std::vector<unsigned char> blk;
+        lz4_store(reinterpret_cast<const unsigned char*>(flags.data() + pos), m * 2, blk);
+        const int32_t usz = static_cast<int32_t>(m * 2), csz = static_cast<int32_t>(blk.size());
+        img.insert(img.end(), reinterpret_cast<const unsigned char*>(&usz), reinterpret_cast<const unsigned char*>(&usz) + 4);
+        img.insert(img.end(), reinterpret_cast<const unsigned char*>(&csz), reinterpret_cast<const unsigned char*>(&csz) + 4);
+        img.insert(img.end(), blk.begin(), blk.end());
+        pos += m;
+    }
+    return img;
+}
+
+static void block_pipeline(const std::vector<uint16_t>& flags, const uint64_t* want)
+{
+    const std::vector<unsigned char> img = make_image(flags, {51200, 512000, 7, 300001, 123456});
+    for (int threads : {1, 5, 20}) {
+        uint64_t out[32] = {0};
+        FLAGSTATS_blockfile_stats st;
+        const int rc = FLAGSTATS_hip_blockimage_lz4(img.data(), img.size(), threads, out, &st);
+        CHECK(rc == 0 && same(out, want), "block image, %d decoder threads: rc %d (%s)", threads, rc, FLAGSTATS_hip_last_error());
+        CHECK(st.n_flags == flags.size(), "block image: %llu flags seen", static_cast<unsigned long long>(st.n_flags));
+    }
+}
+
+static void golden_files(const std::string& dir)
+{
+    // counters of the reference-written files are in the manifest; here the files only have to give the same answer at
+    // every thread count (the CPU / GPU suites check them against the manifest)
+    for (const char* name : {"exact2_fast_a1.lz4", "hc_HC_c9.lz4", "ragged_fast_a2.lz4", "tiny_fast_a2.lz4"}) {
+        uint64_t first[32];
+        bool have = false;
+        for (int threads : {1, 5, 20}) {
+            uint64_t out[32] = {0};
+            const int rc = FLAGSTATS_hip_blockfile((dir + "/" + name).c_str(), threads, out, nullptr);
+            CHECK(rc == 0, "%s with %d threads: rc %d (%s)", name, threads, rc, FLAGSTATS_hip_last_error());
+            if (!have) {
+                std::memcpy(first, out, sizeof first);
+                have = true;
+            }
+            CHECK(same(out, first), "%s: counters differ between thread counts", name);
+        }
+    }
+}
+
+static void sessions(const std::vector<uint16_t>& flags, const uint64_t* want)
+{
+    // two concurrent sessions, each with its own streams and pinned buffers, pushing blocks of different sizes
+    auto one = [&](size_t block, int passes) {
+        FLAGSTATS_hip_stream* s = FLAGSTATS_hip_stream_open();
+        CHECK(s != nullptr, "stream_open: %s", FLAGSTATS_hip_last_error());
+        if (!s) return;
+        for (int p = 0; p < passes; ++p) {
+            uint64_t out[32] = {0};
+            for (size_t pos = 0; pos < flags.size(); pos += block) {
+                const size_t m = block < flags.size() - pos ? block : flags.size() - pos;
+                if ((pos / block) & 1) {
+                    CHECK(FLAGSTATS_hip_stream_push(s, flags.data() + pos, m) == 0, "push");
+                } else {
+                    uint16_t* dst = FLAGSTATS_hip_stream_acquire(s, m);
+                    CHECK(dst != nullptr, "acquire");
+                    if (!dst) break;
+                    std::memcpy(dst, flags.data() + pos, m * 2);
+                    CHECK(FLAGSTATS_hip_stream_commit(s, m) == 0, "commit");
+                }
+            }
+            CHECK(FLAGSTATS_hip_stream_finish(s, out) == 0 && same(out, want), "session (block %zu) pass %d", block, p);
+        }
+        FLAGSTATS_hip_stream_close(s);
+    };
+    std::thread a(one, static_cast<size_t>(512000), 2), b(one, static_cast<size_t>(70001), 2);
+    a.join();
+    b.join();
+}
+
+static void callers(const std::vector<uint16_t>& flags)
+{
+    // the reference API from several threads at once: small calls (polled result pairs), mid-size (one chunk), and
+    // one multi-chunk call with a small chunk size
+    std::vector<std::thread> pool;
+    for (int t = 0; t < 4; ++t)
+        pool.emplace_back([&, t] {
+            for (int it = 0; it < 60; ++it) {
+                const size_t n = (t * 7919 + it * 104729) % 200000 + 1, off = (it * 31337) % (flags.size() - n);
+                uint32_t got[32] = {0};
+                uint64_t want[32] = {0};
+                CHECK(FLAGSTATS_u16(flags.data() + off, static_cast<uint32_t>(n), got) == 0, "FLAGSTATS_u16");
+                oracle_flagstat_u16(flags.data() + off, n, want);
+                for (int k = 0; k < 32; ++k) CHECK(got[k] == want[k], "thread %d call %d slot %d", t, it, k);
+            }
+        });
+    for (auto& th : pool) th.join();
+    FLAGSTATS_hip_set("chunk_flags", 100000);
+    uint64_t got[32] = {0}, want[32] = {0};
+    CHECK(FLAGSTATS_u16_x64(flags.data(), flags.size(), got) == 0, "multi-chunk host call");
+    oracle_flagstat_u16(flags.data(), flags.size(), want);
+    CHECK(same(got, want), "multi-chunk host call counters");
+    FLAGSTATS_hip_set("chunk_flags", 32ull << 20);
+}
+
+static void multi(const std::vector<uint16_t>& flags, const uint64_t* want)
+{
+    const int devs[3] = {0, 1, 0};
+    uint64_t out[32] = {0};
+    CHECK(FLAGSTATS_hip_multi_u16_x64(flags.data(), flags.size(), devs, 3, out) == 0 && same(out, want), "multi_u16_x64 over {0,1,0}");
+    FLAGSTATS_hip_ctx* c0 = FLAGSTATS_hip_ctx_create(0);
+    FLAGSTATS_hip_ctx* c1 = FLAGSTATS_hip_ctx_create(1);
+    CHECK(c0 && c1, "ctx_create");
+    std::thread a([&] {
+        uint64_t o[32] = {0};
+        CHECK(FLAGSTATS_hip_ctx_u16_x64(c0, flags.data(), flags.size(), o) == 0 && same(o, want), "ctx 0");
+    });
+    std::thread b([&] {
+        uint64_t o[32] = {0};
+        CHECK(FLAGSTATS_hip_ctx_u16_x64(c1, flags.data(), flags.size(), o) == 0 && same(o, want), "ctx 1");
+    });
+    a.join();
+    b.join();
+    FLAGSTATS_hip_ctx_destroy(c0);
+    FLAGSTATS_hip_ctx_destroy(c1);
+}
+
+int main(int argc, char** argv)
+{
+    const size_t n = 3000017;
+    std::vector<uint16_t> flags(n);
+    oracle_generate_u16(ORACLE_GEN_NA12878, 7, 1, 0, n, flags.data());
+    uint64_t want[32] = {0};
+    oracle_flagstat_u16(flags.data(), n, want);
+    CHECK(FLAGSTATS_hip_init(0) == 0, "init: %s", FLAGSTATS_hip_last_error());
+    for (int round = 0; round < 2; ++round) {
+        block_pipeline(flags, want);
+        if (argc > 1) golden_files(argv[1]);
+        sessions(flags, want);
+        callers(flags);
+        multi(flags, want);
+        FLAGSTATS_hip_shutdown();  // second round: everything is created again
+    }
+    std::printf(g_fail ? "tsan_driver: %d FAILED checks\n" : "tsan_driver: all checks passed\n", g_fail);
+    return g_fail ? 1 : 0;
+}
