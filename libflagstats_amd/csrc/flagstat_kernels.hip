@@ -180,9 +180,13 @@ __device__ __forceinline__ void lds_dma16(const uint4* gsrc, uint32_t lds_dst)
 // "stage into LDS"): the vector is read from the wave's LDS slot (ds_read_b128) once the LDS-DMA
 // that filled it has landed -- 15 younger DMAs are always in flight behind it, hence vmcnt(15) --
 // and the slot is immediately re-targeted by the DMA for the lane's step after next.
-template <int DEPTH, int STAGE, bool NT, int USTRIDE>
+// STAGE 5 (the two-waves-per-SIMD experiment: 8 waves per workgroup, each with HALF a step in flight): vector u's
+// registers are re-issued for vector (u + 4) & 7 -- the second half of THIS step (`cur`) for u < 4, the first half of
+// the lane's next step (`next`, if HAS_NEXT) for u >= 4 -- so a wave keeps 4 loads (4 KiB) in flight and the 8 waves of
+// a CU together the same 32 KiB as the 4 waves of the default schedule.
+template <int DEPTH, int STAGE, bool NT, int USTRIDE, bool HAS_NEXT = true>
 __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t blk, const uint4* __restrict__ next,
-                                     LdsStage lds = LdsStage{nullptr, 0, 0})
+                                     LdsStage lds = LdsStage{nullptr, 0, 0}, const uint4* __restrict__ cur = nullptr)
 {
     constexpr bool ROLL = (STAGE == 1);
     uint32_t t8a = 0, t8b = 0, f8a = 0, f8b = 0, s8a = 0, s8b = 0;
@@ -206,6 +210,15 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
                     H0 = perm(x.y, x.x, 0x07050301u);
                     L1 = perm(x.w, x.z, 0x06040200u);
                     H1 = perm(x.w, x.z, 0x07050301u);
+                } else if constexpr (STAGE == 5) {
+                    const int uu = half * 4 + q * 2 + k;  // a constant after unrolling
+                    __builtin_amdgcn_sched_barrier(0);
+                    split_out(v[uu], L0, H0, L1, H1);
+                    if (uu < 4)
+                        v[uu + 4] = load_vec<NT>(cur + (uu + 4) * USTRIDE);
+                    else if constexpr (HAS_NEXT)
+                        v[uu - 4] = load_vec<NT>(next + (uu - 4) * USTRIDE);
+                    __builtin_amdgcn_sched_barrier(0);
                 } else if constexpr (ROLL) {
                     // Split the vector out of its registers HERE (a load may land at any time, so the registers it
                     // targets must be dead first), then re-issue into the same registers.  The asm keeps hipcc from
@@ -449,11 +462,11 @@ __device__ __forceinline__ void grouped_epilogue(const uint64_t* tot, uint64_t* 
 // USTRIDE = vectors between a lane's consecutive loads: 64 -> each wave owns a contiguous
 // 8 KiB of the step; 256 -> the 4 waves interleave at 1 KiB (each load instruction of the
 // workgroup covers a contiguous 4 KiB).
-template <bool NT, int USTRIDE>
+template <bool NT, int USTRIDE, int VPS = kVecPerStep>
 __device__ __forceinline__ void load_step(uint4 (&v)[kUnroll], const uint4* __restrict__ a0, uint64_t st, uint64_t lane_off,
                                           uint64_t lo, uint64_t hi, uint64_t fast_begin, uint64_t fast_end)
 {
-    const uint64_t j0 = st * kVecPerStep + lane_off;
+    const uint64_t j0 = st * VPS + lane_off;
     if (st >= fast_begin && st < fast_end) {
 #pragma unroll
         for (int u = 0; u < kUnroll; ++u) v[u] = load_vec<NT>(a0 + j0 + u * USTRIDE);
@@ -463,14 +476,15 @@ __device__ __forceinline__ void load_step(uint4 (&v)[kUnroll], const uint4* __re
     }
 }
 
-template <int DEPTH, int STAGE = 0, bool NT = false, int USTRIDE = 64>
+template <int DEPTH, int STAGE = 0, bool NT = false, int USTRIDE = 64, bool HAS_NEXT = true>
 __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t& blk,
-                                               const uint4* __restrict__ next = nullptr, LdsStage lds = LdsStage{nullptr, 0, 0})
+                                               const uint4* __restrict__ next = nullptr, LdsStage lds = LdsStage{nullptr, 0, 0},
+                                               const uint4* __restrict__ cur = nullptr)
 {
     // blk is the same in every lane; hipcc keeps it in a VGPR and branches through the exec mask (v_and, v_cmp,
     // s_and_saveexec per chain level) unless told so
     blk = __builtin_amdgcn_readfirstlane(blk);
-    step<DEPTH, STAGE, NT, USTRIDE>(s, v, blk, next, lds);
+    step<DEPTH, STAGE, NT, USTRIDE, HAS_NEXT>(s, v, blk, next, lds, cur);
     ++blk;
     if (blk == (1u << DEPTH) - 1u) {
         flush(s, (1u << DEPTH) - 1u);
@@ -483,7 +497,7 @@ __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnrol
 // step k+1 are in flight while step k is computed (one more 8 KiB per wave in
 // flight, +32 VGPRs).
 template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE>
-__global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
+__global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : (STAGE == 5 ? 2 * kThreads : kThreads)) void flagstat_count(const uint4* __restrict__ a0, uint64_t lo, uint64_t hi,
                                                            uint64_t nsteps, uint64_t fast_begin, uint64_t fast_end,
                                                            uint64_t* __restrict__ partials, uint32_t* ticket,
                                                            uint64_t* out, int mode, DynSched dyn, HostSignal sig)
@@ -504,7 +518,9 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagsta
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t wave = threadIdx.x >> 6;
     // vector of (wave, u, lane) within a step: wave*512 + u*64 + lane, or u*256 + wave*64 + lane
-    constexpr int US = INTERLEAVE ? kThreads : 64;
+    constexpr int T = (STAGE == 5) ? 2 * kThreads : kThreads;  // worker threads of a workgroup
+    constexpr int VPS = T * kUnroll;                            // vectors per step
+    constexpr int US = INTERLEAVE ? T : 64;
     const uint64_t lane_off = INTERLEAVE ? static_cast<uint64_t>(threadIdx.x)
                                          : static_cast<uint64_t>(wave) * (64 * kUnroll) + lane;
     const uint64_t G = gridDim.x;
@@ -519,14 +535,14 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagsta
     if constexpr (ROLL) {
         // ragged edge steps (at most the first and the last of the whole array) go through the
         // guarded loader, outside the pipelined loop
-        if (fast_begin != 0 && blockIdx.x == 0 && wave < kThreads / 64) {
+        if (fast_begin != 0 && blockIdx.x == 0 && wave < T / 64) {
             uint4 v[kUnroll];
-            load_step<NT, US>(v, a0, 0, lane_off, lo, hi, fast_begin, fast_end);
+            load_step<NT, US, VPS>(v, a0, 0, lane_off, lo, hi, fast_begin, fast_end);
             step_and_count(s, v, blk);
         }
-        if (nsteps > fast_end && nsteps - 1 >= fast_begin && (nsteps - 1) % G == blockIdx.x && wave < kThreads / 64) {
+        if (nsteps > fast_end && nsteps - 1 >= fast_begin && (nsteps - 1) % G == blockIdx.x && wave < T / 64) {
             uint4 v[kUnroll];
-            load_step<NT, US>(v, a0, nsteps - 1, lane_off, lo, hi, fast_begin, fast_end);
+            load_step<NT, US, VPS>(v, a0, nsteps - 1, lane_off, lo, hi, fast_begin, fast_end);
             step_and_count(s, v, blk);
         }
         // first fully in-range step of this workgroup
@@ -548,6 +564,24 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagsta
                     FSK_TL_ONCE(1);
                 }
                 step_and_count(s, v, blk);
+                FSK_TL_ONCE(1);
+            }
+        } else if constexpr (STAGE == 5) {
+            if (st < fast_end) {
+                uint4 v[kUnroll];
+                const uint4* p = a0 + st * VPS + lane_off;
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {  // the first half step; the rest is issued as it is consumed
+                    v[u] = load_vec<NT>(p + u * US);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                for (; st + G < fast_end; st += G) {
+                    const uint4* pn = p + G * VPS;
+                    step_and_count<DEPTH, 5, NT, US, true>(s, v, blk, pn, LdsStage{nullptr, 0, 0}, p);
+                    FSK_TL_ONCE(1);
+                    p = pn;
+                }
+                step_and_count<DEPTH, 5, NT, US, false>(s, v, blk, nullptr, LdsStage{nullptr, 0, 0}, p);
                 FSK_TL_ONCE(1);
             }
         } else if constexpr (STAGE == 4) {
@@ -766,11 +800,12 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagsta
     FSK_TL(3);
 
     // wave sums on the VALU (DPP), then the 4 waves through LDS
-    __shared__ uint32_t red[kThreads / 64][kInternal];
+    constexpr int kWaves = (STAGE == 5 ? 2 * kThreads : kThreads) / 64;  // waves that count
+    __shared__ uint32_t red[kWaves][kInternal];
     uint32_t wsum[kInternal];
 #pragma unroll
     for (int c = 0; c < kInternal; ++c) wsum[c] = wave_sum_lane63(s.acc[c]);
-    if (lane == 63 && wave < kThreads / 64) {  // (the dynamic schedule's scheduler wave counts nothing)
+    if (lane == 63 && wave < kWaves) {  // (the dynamic schedule's scheduler wave counts nothing)
 #pragma unroll
         for (int c = 0; c < kInternal; ++c) red[wave][c] = wsum[c];
     }
@@ -778,7 +813,7 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : kThreads) void flagsta
     uint64_t sum = 0;
     if (threadIdx.x < kInternal) {
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) sum += red[w][threadIdx.x];
+        for (int w = 0; w < kWaves; ++w) sum += red[w][threadIdx.x];
     }
     if (mode & 32) {
         // Latency form (a grid of ONE workgroup, result pairs in pinned host memory): this workgroup's totals ARE the
@@ -957,7 +992,7 @@ template <int DEPTH, bool NT, bool PREFETCH, bool INTERLEAVE, int STAGE = 0>
 static hipError_t launch_count_t(const fsk::CountArgs& a, hipStream_t stream)
 {
     hipLaunchKernelGGL((fsk::flagstat_count<DEPTH, NT, PREFETCH, INTERLEAVE, STAGE>), dim3(a.grid),
-                       dim3(STAGE == 4 ? fsk::kThreads + 64 : fsk::kThreads), 0, stream,
+                       dim3(STAGE == 4 ? fsk::kThreads + 64 : (STAGE == 5 ? 2 * fsk::kThreads : fsk::kThreads)), 0, stream,
                        reinterpret_cast<const uint4*>(a.a0), a.lo, a.hi, a.nsteps, a.fast_begin, a.fast_end, a.partials,
                        a.ticket, a.out, a.mode, a.dyn, a.sig);
     return hipGetLastError();
@@ -980,10 +1015,11 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     a.lo = (addr - base) / 2;
     a.hi = a.lo + n;
     const uint64_t nvec = (a.hi + 7) / 8;
-    a.nsteps = (nvec + fsk::kVecPerStep - 1) / fsk::kVecPerStep;
-    // steps whose 2048 vectors are all fully inside [lo, hi)
+    const uint64_t vps = ((variant & 255) == 29 ? 2 : 1) * fsk::kVecPerStep;  // schedule 29: 512-thread workgroups, 64 KiB steps
+    a.nsteps = (nvec + vps - 1) / vps;
+    // steps whose vectors are all fully inside [lo, hi)
     a.fast_begin = (a.lo == 0) ? 0 : 1;
-    a.fast_end = (a.hi / 8) / fsk::kVecPerStep;
+    a.fast_end = (a.hi / 8) / vps;
     if (a.fast_end < a.fast_begin) a.fast_end = a.fast_begin;
     if (static_cast<uint64_t>(grid) > a.nsteps) grid = static_cast<uint32_t>(a.nsteps);
     a.grid = grid;
@@ -1051,6 +1087,9 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     // bit 7: 25 + guided self-scheduling.  Balances the XCDs to within 2 us of each other and is NOT faster (HBM, not the
     // split between XCDs, sets the time: profiles/r03/dyn_sweep*.log, timeline_153.log) -- evidence, tuning build only
     case 153: e = launch_count_t<8, true, false, true, 4>(a, stream); break;
+    // 25 with TWO waves per SIMD: 512-thread workgroups, every wave rolls over half a step (4 loads in flight), same
+    // 32 KiB in flight per CU -- the VERDICT r02 experiment on K1's VALU headroom (profiles/r03/two_waves_per_simd.log)
+    case 29: e = launch_count_t<8, true, false, true, 5>(a, stream); break;
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
     case 13: e = launch_count_t<8, true, true, true>(a, stream); break;
@@ -1116,6 +1155,7 @@ extern "C" int fsk_variant_supported(int variant)
     case 9:
     case 25: return 1;
 #ifdef FLAGSTAT_TUNING_VARIANTS
+    case 29:
     case 153:
     case 0:
     case 1:
