@@ -162,11 +162,10 @@ def lib() -> ctypes.CDLL:
         fn = getattr(handle, name)  # AttributeError here = header/library drift
         fn.restype = restype
         fn.argtypes = argtypes
-    # every Python call site checks return codes and raises FlagstatsHipError, so the reference-shaped
-    # entry points return their error here instead of abort()ing (the C default for callers that
-    # ignore it); an explicit FLAGSTATS_HIP_ON_ERROR in the environment wins
-    if "FLAGSTATS_HIP_ON_ERROR" not in os.environ:
-        handle.FLAGSTATS_hip_set(b"on_error", 0)
+    # The library's process-wide "on_error" policy is left alone: the reference-shaped entry points (FLAGSTATS_u16,
+    # FLAGSTAT_hip, STORM_pospopcnt_u16) abort() after a failure by default because their reference callers ignore the
+    # return value -- another consumer of the same .so in this process (the reference's own .pyx, say) must keep that
+    # protection.  This package calls the int-returning 64-bit entry points instead and raises FlagstatsHipError.
     _lib = handle
     return handle
 

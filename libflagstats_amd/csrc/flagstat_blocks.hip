@@ -179,7 +179,15 @@ bool node_cpuset(int node, cpu_set_t* set)
         }
         if (*p == ',') ++p;
     }
-    return count > 0;
+    if (count == 0) return false;
+    // never widen what the process was given (taskset, a container's cpuset): pin to node CPUs INSIDE the current mask,
+    // and leave the threads alone if the two do not overlap
+    cpu_set_t mine;
+    if (sched_getaffinity(0, sizeof mine, &mine) == 0) {
+        CPU_AND(set, set, &mine);
+        if (CPU_COUNT(set) == 0) return false;
+    }
+    return true;
 }
 
 // CPUs this process may use per the cgroup v2 CPU controller ("<quota> <period>" or "max <period>"); 0 = no limit known

@@ -66,6 +66,7 @@ struct EventPair {
 int count_device_sync(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t* out, int op = fsint::OP_FLAGSTAT)
 {
     std::lock_guard<std::mutex> lk(e.mu);
+    if (fsint::engine_alive(e)) return -1;
     DeviceGuard guard(e.device);
     if (!guard.ok()) return -1;
     HIP_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), e.stream[0]));
@@ -303,11 +304,11 @@ FLAGSTATS_hip_ctx* FLAGSTATS_hip_ctx_create(int device)
 void FLAGSTATS_hip_ctx_destroy(FLAGSTATS_hip_ctx* ctx)
 {
     if (!ctx) return;
-    fsint::engine_destroy(ctx->engine);
+    fsint::engine_destroy(ctx->engine);  // after a FLAGSTATS_hip_shutdown: only drops the (dead) object
     delete ctx;
 }
 
-int FLAGSTATS_hip_ctx_device(const FLAGSTATS_hip_ctx* ctx) { return ctx ? ctx->engine->device : -1; }
+int FLAGSTATS_hip_ctx_device(const FLAGSTATS_hip_ctx* ctx) { return (ctx && !ctx->engine->dead.load()) ? ctx->engine->device : -1; }
 
 int FLAGSTATS_hip_ctx_u16_x64(FLAGSTATS_hip_ctx* ctx, const uint16_t* array, uint64_t n, uint64_t* out)
 {

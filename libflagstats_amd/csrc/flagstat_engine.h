@@ -51,6 +51,11 @@ Knobs& knobs();
 enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2, OP_BASE_MASK = 3, OP_SUPERSET = 4, OP_HOST_OUT = 8 };
 
 struct Engine {
+    // Handles that outlive a FLAGSTATS_hip_shutdown (sessions, explicit contexts) keep the OBJECT alive through `refs`; the
+    // shutdown releases the engine's GPU resources and marks it `dead`, after which every operation on it fails loudly
+    // and the last handle to let go deletes it (engine_release).
+    std::atomic<int> refs{0};
+    std::atomic<bool> dead{false};
     int device = -1;
     int cus = 0;
     int numa_node = -1;                            // host NUMA node closest to the device (-1 unknown)
@@ -105,8 +110,11 @@ void multi_forget();                               // flagstat_multi.hip: drop c
 Engine* engine_for_device(int device);
 Engine* default_engine();
 // a private engine (own streams and buffers) on `device`; release with engine_destroy
-Engine* engine_create(int device);
-void engine_destroy(Engine* e);
+Engine* engine_create(int device);               // refs = 1 (the creator's handle)
+void engine_destroy(Engine* e);                  // releases the GPU resources now, the object with the last reference
+void engine_retain(Engine* e);
+void engine_release(Engine* e);
+int engine_alive(const Engine& e);               // 0, or a recorded error if the engine was shut down
 void shutdown_all();
 int default_device();                              // -1 before the first successful init
 int select_default_device(int device);             // FLAGSTATS_hip_init

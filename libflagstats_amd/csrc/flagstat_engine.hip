@@ -28,7 +28,7 @@ constexpr size_t kSmallInBytes = 2ull << 20;       // pinned input buffer: up to
 thread_local std::string g_err;
 
 std::mutex g_reg_mu;                               // registry only; never held across GPU work
-std::vector<std::unique_ptr<Engine>> g_default;    // index = device id
+std::vector<Engine*> g_default;                    // index = device id; the registry holds one reference each
 std::vector<Engine*> g_private;                    // engine_create()d, for shutdown_all
 std::atomic<int> g_default_device{-1};
 Knobs g_knobs;
@@ -239,11 +239,15 @@ Engine* engine_for_device(int device)
         device = g_default_device.load();
         if (device < 0) device = static_cast<int>(env_u64("FLAGSTATS_HIP_DEVICE", 0));
     }
-    std::lock_guard<std::mutex> lk(g_reg_mu);
-    if (device < static_cast<int>(g_default.size()) && g_default[device]) {
-        if (g_default_device.load() < 0) g_default_device = device;
-        return g_default[device].get();
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (device < static_cast<int>(g_default.size()) && g_default[device]) {
+            if (g_default_device.load() < 0) g_default_device = device;
+            return g_default[device];
+        }
     }
+    // build it outside the registry lock (streams, allocations: GPU work), then publish; if another thread was faster,
+    // its engine wins and this one is given back
     std::unique_ptr<Engine> e(new Engine());
     if (engine_setup(*e, device)) {
         if (e->device >= 0) {
@@ -252,10 +256,26 @@ Engine* engine_for_device(int device)
         }
         return nullptr;
     }
-    if (static_cast<int>(g_default.size()) <= device) g_default.resize(device + 1);
-    g_default[device] = std::move(e);
-    if (g_default_device.load() < 0) g_default_device = device;
-    return g_default[device].get();
+    Engine* loser = nullptr;
+    Engine* winner = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        if (static_cast<int>(g_default.size()) <= device) g_default.resize(device + 1, nullptr);
+        if (g_default[device]) {
+            loser = e.release();
+        } else {
+            e->refs = 1;
+            g_default[device] = e.release();
+        }
+        winner = g_default[device];
+        if (g_default_device.load() < 0) g_default_device = device;
+    }
+    if (loser) {
+        DeviceGuard guard(loser->device);
+        release_engine_resources(*loser);
+        delete loser;
+    }
+    return winner;
 }
 
 Engine* default_engine() { return engine_for_device(-1); }
@@ -287,57 +307,80 @@ Engine* engine_create(int device)
         }
         return nullptr;
     }
+    e->refs = 1;
     std::lock_guard<std::mutex> lk(g_reg_mu);
     g_private.push_back(e.get());
     return e.release();
 }
 
+void engine_retain(Engine* e)
+{
+    if (e) e->refs.fetch_add(1);
+}
+
+void engine_release(Engine* e)
+{
+    if (e && e->refs.fetch_sub(1) == 1) delete e;  // resources went with the shutdown / destroy that marked it dead
+}
+
+int engine_alive(const Engine& e)
+{
+    if (!e.dead.load()) return 0;
+    return fail_text("this engine was released by FLAGSTATS_hip_shutdown (or its context was destroyed); open a new session / context");
+}
+
+namespace {
+// release an engine's GPU resources exactly once and mark it dead; the object stays until its last reference goes
+void retire_engine(Engine* e)
+{
+    bool was = false;
+    if (!e->dead.compare_exchange_strong(was, true)) return;
+    std::lock_guard<std::mutex> lk(e->mu);
+    DeviceGuard guard(e->device);
+    release_engine_resources(*e);
+    e->stream[0] = e->stream[1] = nullptr;
+    e->d_out[0] = e->d_out[1] = nullptr;
+    e->stage[0] = e->stage[1] = nullptr;
+    e->stage_flags[0] = e->stage_flags[1] = 0;
+    e->ws[0] = e->ws[1] = Workspace();
+    e->h_out = e->h_out_dev = nullptr;
+    e->small_in = e->small_in_dev = nullptr;
+    e->chunk_done[0] = e->chunk_done[1] = nullptr;
+    e->pinned[0] = e->pinned[1] = e->pinned[2] = nullptr;
+    e->pinned_bytes = 0;
+}
+}  // namespace
+
 void engine_destroy(Engine* e)
 {
-    if (!e) return;
+    if (!e) return;  // (private engines only; default engines are released by shutdown_all)
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
-        bool found = false;
         for (size_t i = 0; i < g_private.size(); ++i)
             if (g_private[i] == e) {
                 g_private.erase(g_private.begin() + static_cast<long>(i));
-                found = true;
                 break;
             }
-        if (!found) return;  // default engines are released by shutdown_all only
     }
-    {
-        std::lock_guard<std::mutex> lk(e->mu);
-        DeviceGuard guard(e->device);
-        release_engine_resources(*e);
-    }
-    delete e;
+    retire_engine(e);   // no-op if a shutdown got there first
+    engine_release(e);  // the creator's reference
 }
 
 void shutdown_all()
 {
-    std::vector<std::unique_ptr<Engine>> defaults;
-    std::vector<Engine*> privates;
+    std::vector<Engine*> defaults, privates;
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);
         defaults.swap(g_default);
         privates.swap(g_private);
         g_default_device = -1;
     }
-    for (auto& e : defaults) {
+    for (Engine* e : defaults) {
         if (!e) continue;
-        std::lock_guard<std::mutex> lk(e->mu);
-        DeviceGuard guard(e->device);
-        release_engine_resources(*e);
+        retire_engine(e);
+        engine_release(e);  // the registry's reference; sessions still holding one keep the (dead) object
     }
-    for (Engine* e : privates) {
-        {
-            std::lock_guard<std::mutex> lk(e->mu);
-            DeviceGuard guard(e->device);
-            release_engine_resources(*e);
-        }
-        delete e;
-    }
+    for (Engine* e : privates) retire_engine(e);  // their creators' handles (ctx, multi) drop the reference
 }
 
 int device_of_pointer(const void* p, const char* what, int* device, bool* plain_device_memory)
@@ -541,16 +584,21 @@ void* host_alloc_on_node(size_t bytes, int numa_node)
 {
     void* p = nullptr;
     bool bound = false;
-#ifdef SYS_set_mempolicy
+#if defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+    // MPOL_PREFERRED (1) for the calling thread while the pinned pages are created; the caller's own policy (numactl
+    // --interleave, say) is read first and put back afterwards
+    int old_mode = 0;
+    unsigned long old_mask[16] = {0};
+    bool have_old = false;
     if (numa_node >= 0 && numa_node < 64 && g_knobs.numa.load()) {
-        // MPOL_PREFERRED (1) for the calling thread while the pinned pages are created
+        have_old = syscall(SYS_get_mempolicy, &old_mode, old_mask, sizeof(old_mask) * 8, nullptr, 0ul) == 0;
         unsigned long mask = 1ul << numa_node;
-        bound = syscall(SYS_set_mempolicy, 1, &mask, sizeof(mask) * 8 + 1) == 0;
+        bound = have_old && syscall(SYS_set_mempolicy, 1, &mask, sizeof(mask) * 8 + 1) == 0;
     }
 #endif
     hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, bound ? hipHostMallocNumaUser : hipHostMallocDefault);
-#ifdef SYS_set_mempolicy
-    if (bound) (void)syscall(SYS_set_mempolicy, 0, nullptr, 0);  // MPOL_DEFAULT
+#if defined(SYS_set_mempolicy) && defined(SYS_get_mempolicy)
+    if (bound) (void)syscall(SYS_set_mempolicy, old_mode, old_mode ? old_mask : nullptr, old_mode ? sizeof(old_mask) * 8 : 0ul);
 #endif
     if (e != hipSuccess) {
         fail_hip("hipHostMalloc", e);
@@ -584,6 +632,7 @@ int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
     if (n == 0) return 0;
     if (!h) return fail_text("NULL array with n > 0");
     std::lock_guard<std::mutex> lk(e.mu);
+    if (engine_alive(e)) return -1;
     DeviceGuard guard(e.device);
     if (!guard.ok()) return -1;
     const uint64_t chunk = g_knobs.chunk_flags.load() < 8 ? 8 : g_knobs.chunk_flags.load();

@@ -116,7 +116,8 @@ namespace fsint {
 void multi_forget()
 {
     std::lock_guard<std::mutex> lk(g_multi_mu);
-    g_multi.clear();  // the engines themselves are private engines: shutdown_all releases them
+    for (Engine* e : g_multi) fsint::engine_destroy(e);  // private engines of the multi-device entry
+    g_multi.clear();
 }
 }  // namespace fsint
 

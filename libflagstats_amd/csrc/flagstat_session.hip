@@ -74,6 +74,8 @@ FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void)
     if (!guard.ok()) return nullptr;
     FLAGSTATS_hip_stream* s = new FLAGSTATS_hip_stream();
     s->eng = eng;
+    fsint::engine_retain(eng);  // the session only needs the engine's device / geometry; a FLAGSTATS_hip_shutdown while it is
+                                // open releases the engine's own buffers but leaves the object to the session
     s->cap = (fsint::chunk_bytes() + 15) & ~15ull;
     if (s->cap < (1ull << 20)) s->cap = 1ull << 20;
     hipError_t e = hipSuccess;
@@ -90,10 +92,8 @@ FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void)
         e = hipStreamCreateWithFlags(&s->st[i], hipStreamNonBlocking);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->dstage[i]), s->cap);
         if (e == hipSuccess) e = hipMalloc(reinterpret_cast<void**>(&s->d_out[i]), 32 * sizeof(uint64_t));
-        if (e == hipSuccess) e = hipMemset(s->d_out[i], 0, 32 * sizeof(uint64_t));
+        if (e == hipSuccess) e = hipMemsetAsync(s->d_out[i], 0, 32 * sizeof(uint64_t), s->st[i]);  // ordered on ITS stream
     }
-    // the memsets ran on the NULL stream, which the session's non-blocking streams do not order against
-    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e == hipSuccess) e = hipHostMalloc(reinterpret_cast<void**>(&s->h_out), 2 * 32 * sizeof(uint64_t), hipHostMallocDefault);
     if (e != hipSuccess) {
         fsint::fail_hip("FLAGSTATS_hip_stream_open", e);
@@ -197,6 +197,7 @@ void FLAGSTATS_hip_stream_close(FLAGSTATS_hip_stream* s)
         if (s->h_out) (void)hipHostFree(s->h_out);
         s->h_out = nullptr;
     }
+    fsint::engine_release(s->eng);
     delete s;
 }
 

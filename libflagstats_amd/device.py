@@ -70,10 +70,10 @@ class DeviceFlags:
 def pospopcnt_host(values: np.ndarray) -> np.ndarray:
     """``STORM_pospopcnt_u16`` (python/libalgebra.h:3496-3551) of a host array: uint32[16], zeroed first."""
     v = np.ascontiguousarray(values, dtype=np.uint16)
-    out = np.full(16, 0xDEADBEEF, dtype=np.uint32)  # the callee zeroes it, like the reference
-    _lib.check(_lib.lib().STORM_pospopcnt_u16(v.ctypes.data if v.size else None, v.size, out.ctypes.data),
-               "STORM_pospopcnt_u16")
-    return out
+    wide = np.zeros(16, dtype=np.uint64)             # the int-returning twin: a failure raises, never aborts
+    _lib.check(_lib.lib().FLAGSTATS_hip_pospopcnt_u16_x64(v.ctypes.data if v.size else None, v.size, wide.ctypes.data),
+               "FLAGSTATS_hip_pospopcnt_u16_x64")
+    return wide.astype(np.uint32)
 
 
 def pospopcnt_torch(t, out=None):

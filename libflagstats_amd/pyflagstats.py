@@ -2,9 +2,11 @@
 
 Mirror of ``python/libflagstats.pyx:8-37``: same argument checks and messages,
 same dict layout, same derived fields, same value type (``numpy.uint32``); the
-32 counters come from ``FLAGSTATS_u16`` of ``libflagstats_hip.so`` (the C-ABI
-replacement of ``libflagstats.h:3024-3070``) instead of the header-only CPU
-kernels.
+32 counters come from ``libflagstats_hip.so`` (the C-ABI replacement of
+``libflagstats.h:3024-3070``) instead of the header-only CPU kernels -- through
+``FLAGSTATS_u16_x64``, the int-returning twin of ``FLAGSTATS_u16``, so that a GPU
+failure raises here instead of aborting the interpreter (``FLAGSTATS_u16`` itself
+has no error channel and aborts by default, as its reference callers ignore it).
 
 Counter contents follow ``FLAGSTAT_scalar`` (``libflagstats.h:118-142``): only
 the 19 live slots are ever non-zero.  On an x86 host the reference's dispatcher
@@ -24,15 +26,12 @@ SAM_FLAG_NAMES = ["FPAIRED", "FPROPER_PAIR", "FUNMAP", "FMUNMAP", "FREVERSE", "F
 
 
 def counters_u32(values: np.ndarray) -> np.ndarray:
-    """32 ``uint32`` counters of a host ``uint16`` array through ``FLAGSTATS_u16``."""
-    flags = np.zeros(32, dtype="uint32")
-    lib = _lib.lib()
+    """32 ``uint32`` counters of a host ``uint16`` array, as ``FLAGSTATS_u16`` gives them (uint32 length, counters
+    modulo 2^32)."""
     n = len(values)
     if n >= 2 ** 32:
         raise ValueError("FLAGSTATS_u16 takes a uint32 length; use flagstats_x64 for >= 2^32 flags")
-    rc = lib.FLAGSTATS_u16(values.ctypes.data, n, flags.ctypes.data)
-    _lib.check(int(rc), "FLAGSTATS_u16")
-    return flags
+    return counters_u64(values).astype("uint32")
 
 
 def counters_u64(values: np.ndarray) -> np.ndarray:

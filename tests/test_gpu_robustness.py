@@ -84,3 +84,37 @@ def test_shutdown_and_lazy_reinit(hip):
     assert np.array_equal(out, want)
     assert hip.FLAGSTATS_hip_device_id() == 0
     assert {k: hip.FLAGSTATS_hip_get(k) for k in knobs} == knobs            # knobs survive a shutdown
+
+
+def test_handles_opened_before_a_shutdown_stay_safe(hip):
+    """FLAGSTATS_hip_shutdown with live handles.  Engines are reference-counted: an explicit context taken
+    before the shutdown fails loudly afterwards (its buffers are gone) and can still be destroyed; a streaming session
+    owns its streams and buffers and keeps working; nothing dereferences freed memory."""
+    import oracle
+    from libflagstats_amd import _lib
+    a = oracle.generate(oracle.GEN_UNIFORM, 17, 0xFFFF, 0, 250_003)
+    want = oracle.flagstat_hist(a)
+    ctx = hip.FLAGSTATS_hip_ctx_create(0)
+    assert ctx
+    ses = hip.FLAGSTATS_hip_stream_open()
+    assert ses
+    out = np.zeros(32, dtype=np.uint64)
+    _lib.check(hip.FLAGSTATS_hip_ctx_u16_x64(ctx, a.ctypes.data, a.size, out.ctypes.data), "ctx before shutdown")
+    assert np.array_equal(out, want)
+    hip.FLAGSTATS_hip_shutdown()
+    out[:] = 0
+    rc = hip.FLAGSTATS_hip_ctx_u16_x64(ctx, a.ctypes.data, a.size, out.ctypes.data)
+    assert rc != 0 and b"FLAGSTATS_hip_shutdown" in hip.FLAGSTATS_hip_last_error() and not out.any()
+    assert hip.FLAGSTATS_hip_ctx_device(ctx) == -1
+    hip.FLAGSTATS_hip_ctx_destroy(ctx)
+    for _ in range(2):
+        out[:] = 0
+        _lib.check(hip.FLAGSTATS_hip_stream_push(ses, a.ctypes.data, a.size), "session push after shutdown")
+        _lib.check(hip.FLAGSTATS_hip_stream_finish(ses, out.ctypes.data), "session finish after shutdown")
+        assert np.array_equal(out, want)
+    hip.FLAGSTATS_hip_stream_close(ses)
+    out[:] = 0
+    _lib.check(hip.FLAGSTATS_u16_x64(a.ctypes.data, a.size, out.ctypes.data), "lazy re-init")
+    assert np.array_equal(out, want)
+    _lib.check(hip.FLAGSTATS_hip_init(0), "init")
+    hip.FLAGSTATS_hip_set(b"on_error", 0)

@@ -31,11 +31,10 @@ def _while_stream_a_is_busy(fn_on_b, big, out_a, a, reps=150):
 
 
 def test_first_call_on_a_fresh_stream_does_not_wait_for_other_streams(hip):
-    """A long job (150 launches over 2 GiB, ~45 ms) runs on stream A.  A FIRST call on a brand-new stream must cost no
-    more than a call on a stream the library already knows: its set-up is an allocation plus stream-ordered zeroing
-    on ITS stream -- no hipDeviceSynchronize, no NULL-stream work (r02 had both) that would wait for A to drain.
-    (Whether work on a second stream overtakes a saturated first one at all is the GPU's queue scheduling; the warm
-    call and a plain torch fill measure that in the same situation.)"""
+    """A long job (150 launches over 2 GiB, ~45 ms) runs on stream A.  A FIRST call on a brand-new stream sets its
+    workspace up with an allocation plus stream-ordered zeroing on ITS stream -- no hipDeviceSynchronize, no NULL-stream
+    work (r02 had both) that would wait for A to drain: it can finish while A is still busy.  (A warm call and a plain
+    torch fill on other streams are timed in the same situation, for the record.)"""
     import torch
 
     import oracle
@@ -69,20 +68,25 @@ def test_first_call_on_a_fresh_stream_does_not_wait_for_other_streams(hip):
             ev.record(s)
         return ev
 
+    # Which hardware queue a stream lands on is the runtime's business: a stream that shares A's queue waits behind A
+    # whatever the library does.  So the first call is made on several fresh streams (each one IS a first call: a new
+    # workspace) and at least one of them must finish while A is still busy -- with a device-wide wait inside the first
+    # call (r02) none could.
     t_fill, t_a0, busy_fill = _while_stream_a_is_busy(torch_fill, big, out_a, a)
     t_warm, t_a1, busy_warm = _while_stream_a_is_busy(count_on(warm), big, out_a, a)
-    out_b.zero_()
-    t_first, t_a2, busy_first = _while_stream_a_is_busy(count_on(torch.cuda.Stream()), big, out_a, a)
+    firsts = []
+    for _ in range(4):
+        firsts.append(_while_stream_a_is_busy(count_on(torch.cuda.Stream()), big, out_a, a))
+    out_b_calls = 1 + len(firsts)
     print("stream A drains in %.1f ms; on another stream meanwhile: torch fill done at %.1f ms (A busy: %s), warm count at %.1f ms "
-          "(A busy: %s), FIRST count on a fresh stream at %.1f ms (A busy: %s)"
-          % (t_a2, t_fill, busy_fill, t_warm, busy_warm, t_first, busy_first))
-    assert t_first <= t_warm + 5.0, (t_fill, t_warm, t_first, t_a2)
-    assert busy_first or not busy_warm, "a first call waited for stream A although a warm call does not"
+          "(A busy: %s), FIRST counts on fresh streams at %s ms (A busy: %s)"
+          % (firsts[0][1], t_fill, busy_fill, t_warm, busy_warm, ["%.1f" % f[0] for f in firsts], [f[2] for f in firsts]))
+    assert any(f[2] and f[0] < 0.5 * f[1] for f in firsts), firsts
     torch.cuda.synchronize()
     want_b = oracle.flagstat_generated(oracle.GEN_UNIFORM, 4, 0xFFFF, 0, small.numel())
-    assert np.array_equal(out_b.cpu().numpy().view(np.uint64), want_b)
+    assert np.array_equal(out_b.cpu().numpy().view(np.uint64), want_b * np.uint64(out_b_calls))
     want_a = oracle.flagstat_generated(oracle.GEN_UNIFORM, 3, 0xFFFF, 0, big.numel())
-    assert np.array_equal(out_a.cpu().numpy().view(np.uint64), want_a * np.uint64(3 * 150))
+    assert np.array_equal(out_a.cpu().numpy().view(np.uint64), want_a * np.uint64(6 * 150))
 
 
 @pytest.mark.parametrize("store", [False, True])

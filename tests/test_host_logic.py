@@ -109,7 +109,14 @@ def test_no_gpu_means_loud_failure_not_fallback():
     assert lib.FLAGSTATS_hip_available() == 0
     a = np.arange(100, dtype=np.uint16)
     flags = np.zeros(32, dtype=np.uint32)
-    rc = lib.FLAGSTATS_u16(a.ctypes.data, a.size, flags.ctypes.data)
+    # importing the Python package leaves the process-wide policy alone: reference-shaped entries abort by default
+    assert lib.FLAGSTATS_hip_get(b"on_error") == 1 or "FLAGSTATS_HIP_ON_ERROR" in os.environ
+    old = lib.FLAGSTATS_hip_get(b"on_error")
+    lib.FLAGSTATS_hip_set(b"on_error", 0)          # this test wants the return code, not an abort() of the test runner
+    try:
+        rc = lib.FLAGSTATS_u16(a.ctypes.data, a.size, flags.ctypes.data)
+    finally:
+        lib.FLAGSTATS_hip_set(b"on_error", old)
     assert rc != 0 and not flags.any()
     assert b"libflagstats_hip" in lib.FLAGSTATS_hip_last_error()
     import pyflagstats

@@ -26,8 +26,12 @@ def test_gpu_host_entry_matches_golden(hip):
     from libflagstats_amd import device
     for case in load_golden("pospopcnt.json")["cases"]:
         a = _input(case)
-        got = device.pospopcnt_host(a)                      # zeroes out[] first, like the reference
+        got = device.pospopcnt_host(a)
         assert np.array_equal(got.astype(np.uint64), np.array(case["counts"], dtype=np.uint64)), case["n"]
+        # the reference-shaped symbol itself: zeroes out[] first, like the reference (python/libalgebra.h:3497)
+        raw = np.full(16, 0xDEADBEEF, dtype=np.uint32)
+        assert hip.STORM_pospopcnt_u16(a.ctypes.data if a.size else None, a.size, raw.ctypes.data) == 0
+        assert np.array_equal(raw, got), case["n"]
         if a.size > 1:
             assert np.array_equal(device.pospopcnt_host(a[1:]).astype(np.uint64),
                                   np.array(case["counts"], dtype=np.uint64) - np.array(
