@@ -533,6 +533,16 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tmax[0]), float(tmax[1])
 
+    # shader clock under K1's load, measured after the timed region (same thermal state, a few ms later)
+    sclk = None
+    if rank == 0:
+        try:
+            mhz = ctypes.c_double(0.0)
+            _lib.check(lib.FLAGSTATS_hip_sclk_under_load(flags.data_ptr(), n, max(3, min(20, int(30.0 / max(ev_ms / args.steps, 1e-3)))),
+                                                         ctypes.byref(mhz)), "FLAGSTATS_hip_sclk_under_load")
+            sclk = round(mhz.value, 1)
+        except Exception as e:  # noqa: BLE001 -- a missing clock reading must not cost the bench line
+            print("bench.py: no shader clock reading (%r)" % (e,), file=sys.stderr)
     ms_per_step = wall * 1e3 / args.steps
     total_flags = args.flags_per_gpu if args.strong else n * world
     value = total_flags * args.steps / wall / 1e9          # whole-job Gflags/s
@@ -601,6 +611,7 @@ def main():
                          "algorithmic_bytes_per_launch": 2 * n,
                          "event_ms_per_launch": round(ev_ms_per_step, 5),
                          "step_ms": quantiles(step_ms),
+                         "sclk_mhz": sclk,
                          "read_probe_GBs": round(probe_gbs, 1) if probe_gbs else None,
                          "frac_of_read_probe": round(achieved / probe_gbs, 4) if probe_gbs else None},
             "cpu_baseline": cpu,

@@ -14,7 +14,8 @@
  * file, which the reference's header also includes (:61) -- the STORM_* helpers
  * its block readers call (aligned malloc / free, alignment query).  With those,
  * /root/reference/benchmark/flagstats.cpp builds unmodified against this
- * directory (tests/test_reference_bench_build.py).
+ * directory (oracle/Makefile target refbench -> oracle/_ref/bench_hip; run on the GPU by
+ * tests/test_blockfiles_golden.py::test_reference_main_program_on_the_gpu_engine).
  */
 #ifndef LIBFLAGSTATS_H_SHIM_HIP_
 #define LIBFLAGSTATS_H_SHIM_HIP_

@@ -218,6 +218,12 @@ int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmu
 int FLAGSTATS_hip_time_device_u16_rotating(const uint16_t* d_array, uint64_t n, uint64_t stride_flags, uint32_t slots,
                                            int warmup, int reps, float* ms_total, uint64_t* out);
 
+/* shader clock the chip sustains WHILE `launches` back-to-back K1 launches over d_array[0..n) run: a one-wave probe per XCD
+ * on a second stream compares the shader-clock counter with the constant 100 MHz reference counter.  K1 is ~65 % VALU-busy
+ * at one wave per SIMD, so a chip that holds a lower clock under this load (power, temperature) is slower on the SAME
+ * kernel: bench.py reports the number next to the roofline fraction (roofline.sclk_mhz).  Returns 0 on success. */
+int FLAGSTATS_hip_sclk_under_load(const uint16_t* d_array, uint64_t n, int launches, double* sclk_mhz);
+
 /* ---- block files: the reference's `bench decompress -d` / `-D` callers ----
  * File format written by benchmark/flagstats.cpp:119-138 and read at :311-316: a sequence of
  *   int32 uncompressed_size, int32 compressed_size, <raw LZ4 block>   (little-endian; not LZ4 frames).

@@ -84,6 +84,7 @@ SIGNATURES = {
     "FLAGSTATS_hip_time_device_u16_rotating": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
                                                               ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_float),
                                                               ctypes.c_void_p]),
+    "FLAGSTATS_hip_sclk_under_load": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.POINTER(ctypes.c_double)]),
     "FLAGSTATS_hip_blockfile_lz4": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p,
                                                    ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_blockimage_lz4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,

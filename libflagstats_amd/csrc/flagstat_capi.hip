@@ -517,6 +517,57 @@ int FLAGSTATS_hip_time_device_u16_rotating(const uint16_t* d_array, uint64_t n, 
     return 0;
 }
 
+int FLAGSTATS_hip_sclk_under_load(const uint16_t* d_array, uint64_t n, int launches, double* sclk_mhz)
+{
+    if (!sclk_mhz || launches < 1 || launches > 10000) return fail_text("bad arguments");
+    Engine* ep = engine_of_array(d_array, n);
+    if (!ep) return -1;
+    Engine& e = *ep;
+    std::lock_guard<std::mutex> lk(e.mu);
+    if (fsint::engine_alive(e)) return -1;
+    DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    // time `launches` K1 launches first (untimed warm-up included), then spin the probe for ~80 % of that while the same
+    // launches run again on the other stream
+    EventPair ev;
+    int rc = ev.create();
+    if (rc) return rc;
+    HIP_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), e.stream[0]));
+    HIP_TRY(hipEventRecord(ev.e0, e.stream[0]));
+    for (int i = 0; i < launches; ++i) {
+        rc = fsint::count_device_async(e, d_array, n, e.d_out[0], e.stream[0], e.ws[0]);
+        if (rc) return rc;
+    }
+    HIP_TRY(hipEventRecord(ev.e1, e.stream[0]));
+    HIP_TRY(hipStreamSynchronize(e.stream[0]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, ev.e0, ev.e1));
+    uint64_t ticks = static_cast<uint64_t>(ms * 1e-3 * 0.8 * 1e8);  // 100 MHz reference
+    if (ticks < 1000) ticks = 1000;
+    if (ticks > 100000000ull) ticks = 100000000ull;
+    constexpr uint32_t kProbes = 8;
+    uint64_t* d_probe = e.d_out[1];  // 4 KiB
+    HIP_TRY(hipMemsetAsync(d_probe, 0, kProbes * 16, e.stream[1]));
+    for (int i = 0; i < launches; ++i) {
+        rc = fsint::count_device_async(e, d_array, n, e.d_out[0], e.stream[0], e.ws[0]);
+        if (rc) return rc;
+        if (i == 0) HIP_TRY(fsk_clock_probe(d_probe, kProbes, ticks, e.stream[1]));  // starts once the first launch is queued
+    }
+    uint64_t h[2 * kProbes];
+    HIP_TRY(hipMemcpyAsync(e.h_out, d_probe, sizeof h, hipMemcpyDeviceToHost, e.stream[1]));
+    HIP_TRY(hipStreamSynchronize(e.stream[1]));
+    HIP_TRY(hipStreamSynchronize(e.stream[0]));
+    std::memcpy(h, e.h_out, sizeof h);
+    double cyc = 0, ref = 0;
+    for (uint32_t b = 0; b < kProbes; ++b) {
+        cyc += static_cast<double>(h[2 * b]);
+        ref += static_cast<double>(h[2 * b + 1]);
+    }
+    if (ref <= 0) return fail_text("the clock probe did not run");
+    *sclk_mhz = cyc / ref * 100.0;
+    return 0;
+}
+
 /* ---- row f4: plain positional popcount (python/libalgebra.h:3496-3551) ---- */
 int FLAGSTATS_hip_pospopcnt_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
 {

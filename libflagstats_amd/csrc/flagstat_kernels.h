@@ -84,6 +84,9 @@ hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, uint32_t gr
                                 uint64_t* d_out16, hipStream_t stream, int direct);
 // read-only bandwidth probe (measurement only)
 hipError_t fsk_read_probe(const void* d_buf, uint64_t bytes, uint32_t grid, int nt, uint32_t* d_sink, hipStream_t stream);
+// shader clock under load (measurement only): d_out[2 * b] = shader-clock cycles, d_out[2 * b + 1] = 100 MHz reference ticks
+// that workgroup b (one wave) spent spinning; ticks <= 1e8 (1 s)
+hipError_t fsk_clock_probe(uint64_t* d_out, uint32_t grid, uint64_t ticks, hipStream_t stream);
 // on-device input makers (flagstat_generate.hip)
 hipError_t fsk_generate(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, uint32_t mask, uint64_t first_index,
                         hipStream_t stream);

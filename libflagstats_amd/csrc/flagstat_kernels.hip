@@ -33,12 +33,15 @@
 //                      step count, so the amortised cost stays 1 CSA per input at
 //                      any depth and the cross-lane transpose happens once per
 //                      epoch (2^DEPTH-1 steps), not per block as on x86 (:1751).
-//                      Epoch flush: v_bcnt_u32_b32 per (plane, counter) into 19
-//                      u32 lane counters; kernel end: wave butterfly + LDS ->
-//                      per-block uint64[19] partials.
-//  K2 flagstat_finalize sums partials on device, maps the 19 internal counters
-//                      to the reference's 32 slots and ADDS into out[32]
-//                      (accumulate contract).
+//                      Epoch flush: the chain is carry-propagated into 12 binary planes, then
+//                      v_and_b32 + v_dot4_u32_u8 per (plane, counter) into 21 u32 lane counters
+//                      (19 live slots + primary-paired reads x {pass, fail}).  Kernel end: DPP wave
+//                      sums + LDS, then EITHER the workgroup adds its totals -- mapped to the
+//                      reference's slots -- to out[32] with device atomics (the += contract's default:
+//                      one launch; from 64 workgroups on through 8 per-XCD copies, grouped_epilogue),
+//                      OR it writes per-workgroup uint64[21] partials for K2 (store form, host counters).
+//  K2 flagstat_finalize sums the partials of one launch, maps the 21 internal counters to the
+//                      reference's 32 slots and stores / adds them.
 //
 // Zero flags contribute to no counter (KAT x=0), so ragged heads/tails and idle
 // lanes are handled by zero-filling: no host-side tail, no scalar fallback.
@@ -927,8 +930,8 @@ __global__ __launch_bounds__(kThreads) void flagstat_read_probe(const uint4* __r
 }
 
 // ------------------------------------------------------------------ K2
-// One workgroup of 16 waves: wave w sums column w (and w+16) of partials[19][nblocks]
-// with coalesced 8-byte loads, then 32 threads map the 19 internal counters to the
+// One workgroup of 16 waves: wave w sums column w (and w+16) of partials[21][nblocks]
+// with coalesced 8-byte loads, then 32 threads map the 21 internal counters to the
 // reference's 32 slots (index = FLAGSTAT_*_OFF, libflagstats.h:69-112; +16 for fail-QC)
 // and ADD into out[32].  Slots the scalar rule never writes get nothing added.
 constexpr int kFinalizeThreads = 1024;

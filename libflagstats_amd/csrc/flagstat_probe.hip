@@ -66,3 +66,35 @@ extern "C" hipError_t fsk_read_probe2(const void* d_buf, uint64_t bytes, int mod
     }
     return hipGetLastError();
 }
+
+
+// ------------------------------------------------------------------ shader clock under load
+// One wave per workgroup, `grid` workgroups (one per XCD is enough): samples the shader-clock counter (s_memtime,
+// clock64) and the constant 100 MHz reference counter (s_memrealtime, wall_clock64) around `ticks` reference ticks of
+// spinning.  Launched on a side stream while K1 launches run on another, cycles / ticks x 100 MHz is the shader
+// clock the chip sustained UNDER that load -- the number sysfs does not give reliably (bench.py: roofline.sclk_mhz).
+// The exit condition is the reference clock, which always advances.
+namespace fsk {
+__global__ void clock_probe(uint64_t* __restrict__ out, uint64_t ticks)
+{
+    const uint64_t w0 = wall_clock64();
+    const uint64_t c0 = clock64();
+    uint64_t w1 = w0;
+    while (w1 - w0 < ticks) {
+        __builtin_amdgcn_s_sleep(8);
+        w1 = wall_clock64();
+    }
+    const uint64_t c1 = clock64();
+    if (threadIdx.x == 0) {
+        out[2 * blockIdx.x] = c1 - c0;
+        out[2 * blockIdx.x + 1] = w1 - w0;
+    }
+}
+}  // namespace fsk
+
+extern "C" hipError_t fsk_clock_probe(uint64_t* d_out, uint32_t grid, uint64_t ticks, hipStream_t stream)
+{
+    if (!d_out || grid == 0 || grid > 64 || ticks == 0 || ticks > 100000000ull) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(fsk::clock_probe, dim3(grid), dim3(64), 0, stream, d_out, ticks);
+    return hipGetLastError();
+}

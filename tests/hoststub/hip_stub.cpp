@@ -446,6 +446,16 @@ hipError_t fsk_generate(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, 
 
 hipError_t fsk_read_probe(const void*, uint64_t, uint32_t, int, uint32_t*, hipStream_t) { return hipSuccess; }
 hipError_t fsk_read_probe2(const void*, uint64_t, int, int, uint32_t, uint32_t, int, uint32_t*, hipStream_t) { return hipSuccess; }
+hipError_t fsk_clock_probe(uint64_t* d_out, uint32_t grid, uint64_t ticks, hipStream_t stream)
+{
+    enqueue(stream, [=] {
+        for (uint32_t b = 0; b < grid; ++b) {
+            d_out[2 * b] = ticks * 21;
+            d_out[2 * b + 1] = ticks;
+        }
+    });
+    return hipSuccess;
+}
 int fsk_variant_supported(int variant) { return (variant & 255) == 9 || (variant & 255) == 25; }
 void fsk_set_anatomy(int) {}
 int fsk_tuning_build(void) { return 0; }
