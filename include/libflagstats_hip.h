@@ -256,6 +256,16 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
  * report of `bench decompress -s` (block file) / `-S` (raw file) needs, benchmark/flagstats.cpp:577-588 */
 int FLAGSTATS_hip_blockfile_superset(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 int FLAGSTATS_hip_file_raw_superset(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
+/* EXPERIMENT (flagstat_lz4_gpu.hip): the same LZ4 block image with the decode ON THE GPU -- the compressed image goes over
+ * PCIe, one wave decodes one block through LDS, K1 counts the decoded buffer.  Synchronous; out[32] += counters.  Kept as
+ * a measured alternative to the host pipeline above (profiles/r03/gpu_lz4_*.log), not used by the file entries. */
+typedef struct FLAGSTATS_gpu_lz4_stats {
+    uint64_t n_blocks, n_flags, bad_blocks, compressed_bytes, decoded_bytes;
+    double h2d_ms, decode_ms, count_ms;            /* stream-event times of the three phases */
+    uint64_t sequences, far_matches;               /* LZ4 sequences decoded; matches that reached behind the LDS ring */
+    uint64_t ring_kib;                             /* LDS ring per wave (env FLAGSTATS_HIP_GPU_LZ4_RING = 16 | 8) */
+} FLAGSTATS_gpu_lz4_stats;
+int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t bytes, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats);
 /* the host LZ4 *block* decoder used above (replaces the reference's call to liblz4's
  * LZ4_decompress_safe, benchmark/flagstats.cpp:316): returns decoded bytes, < 0 on malformed input */
 int64_t FLAGSTATS_lz4_block_decode(const void* src, uint64_t srclen, void* dst, uint64_t dstcap);

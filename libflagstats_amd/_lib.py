@@ -27,6 +27,14 @@ class BlockfileStats(ctypes.Structure):
                 ("wait_decode_s", ctypes.c_double), ("wait_copy_s", ctypes.c_double), ("threads", ctypes.c_int32), ("chunks", ctypes.c_int32)]
 
 
+class GpuLz4Stats(ctypes.Structure):
+    """FLAGSTATS_gpu_lz4_stats of include/libflagstats_hip.h."""
+    _fields_ = [("n_blocks", ctypes.c_uint64), ("n_flags", ctypes.c_uint64), ("bad_blocks", ctypes.c_uint64),
+                ("compressed_bytes", ctypes.c_uint64), ("decoded_bytes", ctypes.c_uint64),
+                ("h2d_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("count_ms", ctypes.c_double),
+                ("sequences", ctypes.c_uint64), ("far_matches", ctypes.c_uint64), ("ring_kib", ctypes.c_uint64)]
+
+
 # name -> (restype, argtypes); mirrors include/libflagstats_hip.h one to one
 SIGNATURES = {
     "FLAGSTATS_u16": (ctypes.c_uint64, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
@@ -89,6 +97,7 @@ SIGNATURES = {
                                                    ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_blockimage_lz4": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
                                                     ctypes.POINTER(BlockfileStats)]),
+    "FLAGSTATS_hip_blockimage_lz4_gpu": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.POINTER(GpuLz4Stats)]),
     "FLAGSTATS_hip_blockimage_zstd": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p,
                                                      ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_blockfile_zstd": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),

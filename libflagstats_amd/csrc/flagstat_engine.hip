@@ -592,8 +592,9 @@ void* host_alloc_on_node(size_t bytes, int numa_node)
     bool have_old = false;
     if (numa_node >= 0 && numa_node < 64 && g_knobs.numa.load()) {
         have_old = syscall(SYS_get_mempolicy, &old_mode, old_mask, sizeof(old_mask) * 8, nullptr, 0ul) == 0;
+        if (!have_old) old_mode = 0;  // cannot read it (sandboxed): bind anyway and put MPOL_DEFAULT back, as r02 did
         unsigned long mask = 1ul << numa_node;
-        bound = have_old && syscall(SYS_set_mempolicy, 1, &mask, sizeof(mask) * 8 + 1) == 0;
+        bound = syscall(SYS_set_mempolicy, 1, &mask, sizeof(mask) * 8 + 1) == 0;
     }
 #endif
     hipError_t e = hipHostMalloc(&p, bytes ? bytes : 1, bound ? hipHostMallocNumaUser : hipHostMallocDefault);
