@@ -165,7 +165,8 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *   "numa"           1 (default): pinned buffers and block-decoder threads are placed on the GPU's host NUMA node
  *   "group_min_grid" K1's atomic epilogue goes through the workspace's 8 per-XCD copies (8 x 2 contended adds on the
  *                    caller's counters per launch instead of one pair per workgroup) from this many workgroups on
- *                    (default 64; 0 = always)
+ *                    (default 64; 0 = any grid), as long as a workgroup has at most 24 steps (arrays up to ~192 MiB:
+ *                    beyond that the workgroups finish too far apart for the contention to matter)
  *   "small_flags"    host-pointer calls of up to this many flags (default and maximum 1048576) are copied by the CPU into a pinned buffer
  *                    that K1 reads in place over PCIe -- no copy call; larger single-chunk calls use an asynchronous H2D
  *                    copy into device staging.  0 = always stage

@@ -970,6 +970,7 @@ static std::atomic<int> g_epoch_stagger{1};          // K1 mode bit 4: waves of 
 
 extern "C" void fsk_set_epoch_stagger(int on) { g_epoch_stagger = on ? 1 : 0; }
 
+constexpr uint64_t kGroupMaxStepsPerWorkgroup = 24;  // <= 192 MiB on a 256-CU chip
 static std::atomic<uint32_t> g_group_min_grid{64};  // grids below this add straight to out[] (one level)
 
 extern "C" void fsk_set_group_min_grid(uint32_t min_grid) { g_group_min_grid = min_grid; }
