@@ -13,7 +13,7 @@ Everything is inside `#if defined(FLAGSTATS_HAVE_HIP)`: without that macro the h
 Build the consumer with -DFLAGSTATS_HAVE_HIP and link -lflagstats_hip.
 
 Selection rule (the length-aware rule of libflagstats.h:2999-3021 extended by one branch):
-  GPU  iff  n_len >= FLAGSTATS_HIP_MIN_LEN (compile-time default 2^18, env FLAGSTATS_HIP_MIN_LEN overrides)
+  GPU  iff  n_len >= FLAGSTATS_HIP_MIN_LEN (compile-time default 2^17, env FLAGSTATS_HIP_MIN_LEN overrides)
             and env FLAGSTATS_BACKEND is not "cpu"  and  FLAGSTATS_hip_available();
   otherwise the reference's own rule picks among its CPU kernels, unchanged.
 """
@@ -27,8 +27,9 @@ DECLS = r'''
 int FLAGSTAT_hip(const uint16_t* array, uint32_t len, uint32_t* flags); /* same shape as every FLAGSTAT_<impl> */
 int FLAGSTATS_hip_available(void);
 #ifndef FLAGSTATS_HIP_MIN_LEN
-#define FLAGSTATS_HIP_MIN_LEN (1u << 18) /* break-even of a host-pointer call vs FLAGSTAT_avx512 on 2x EPYC 9575F:
-                                          * ~2.5e5 flags (23 us call floor; 512,000 flags: 63 vs 94 us; profiles/r02/small_calls.log) */
+#define FLAGSTATS_HIP_MIN_LEN (1u << 17) /* break-even of a host-pointer call vs FLAGSTAT_avx512 on 2x EPYC 9575F:
+                                          * ~1.3e5 flags (15 us call floor; 131,072 flags: 23 vs 24 us; 512,000: 51 vs 93 us;
+                                          * profiles/r03/small_calls.log) */
 #endif
 static int FLAGSTATS_hip_wanted(uint32_t n_len)
 {

@@ -34,10 +34,10 @@ def test_patched_dispatcher_rule():
         assert run(STUB, n)[0] == "FLAGSTAT_scalar"
     small, _ = run(STUB, 1000)
     assert small in CPU_KERNELS and small != "FLAGSTAT_scalar"
-    below, _ = run(STUB, (1 << 18) - 1)
+    below, _ = run(STUB, (1 << 17) - 1)
     assert below in CPU_KERNELS
     # at / above it: the engine, through both entry points (slot 31 carries the stub's marker)
-    for n in (1 << 18, 1_000_003):
+    for n in (1 << 17, 1_000_003):
         chosen, rows = run(STUB, n)
         assert chosen == "FLAGSTAT_hip"
         assert rows["func"][31] == 0xABCD and rows["u16"][31] == 0xABCD
@@ -67,7 +67,8 @@ def test_patched_reference_dispatch_on_hardware(hip):
     chosen, rows = run(REAL, 1000)
     assert chosen in CPU_KERNELS                      # short call: the host's own SIMD kernel, no PCIe round trip
     assert [rows["func"][s] for s in LIVE] == [rows["scalar"][s] for s in LIVE]
-    for n in (1 << 18, 5_000_001):
+    assert run(REAL, (1 << 17) - 1)[0] in CPU_KERNELS      # just below the measured break-even (profiles/r03/small_calls.log)
+    for n in (1 << 17, 5_000_001):
         chosen, rows = run(REAL, n)
         assert chosen == "FLAGSTAT_hip"
         for tag in ("func", "u16"):
