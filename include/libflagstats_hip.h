@@ -151,10 +151,13 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
 /* tuning knobs (also env FLAGSTATS_HIP_BLOCKS_PER_CU / _VARIANT / _FUSE / _EPILOGUE / _CHUNK_FLAGS / _ON_ERROR / _NUMA /
  * _GROUP_MIN_GRID / _FENCE_FREE_EVENTS).  key =
  *   "blocks_per_cu"  workgroups per CU of K1's grid (default 1)
- *   "variant"        K1 schedule: bit0 non-temporal loads, bit1 chain depth 7, bit2 register
- *                    prefetch, bit3 interleaved waves, bit4 rolling re-issue, bit5 LDS-DMA ring, bit6
- *                    rolling at distance 2, bit7 dynamic schedule (default 25; shipped: 9 and 25; the others -- incl. 153 and
-                    its "dyn_*" policy keys -- only in a `make TUNING=1` build)
+ *   "variant"        K1 schedule.  Shipped: 71 (default since r03: non-temporal loads, rolling re-issue at a distance of 6
+ *                    vectors = 24 KiB in flight per CU, each wave a contiguous 8 KiB of a step), 25 (r01-r02 default: rolling
+ *                    over a whole step = 32 KiB in flight, waves interleaved at 1 KiB) and 9 (plain loop).  Up to 31 the
+ *                    number is a bit set (bit0 non-temporal loads, bit1 chain depth 7, bit2 register prefetch, bit3
+ *                    interleaved waves, bit4 rolling re-issue), larger numbers are labels; everything that lost a sweep
+ *                    (incl. 153 = dynamic schedule with its "dyn_*" policy keys, 29 = two waves per SIMD, 41 = LDS-DMA
+ *                    ring) exists only in a `make TUNING=1` build
  *   "epilogue"       accumulate (+=) forms into device memory: 1 (default) = K1's workgroups add their totals to the
  *                    counters with atomics, ONE launch per call, any number of streams may share a counter array;
  *                    0 = partials + K2 (then one counter array must be targeted from one stream at a time).
@@ -299,9 +302,10 @@ int STORM_pospopcnt_u16(const uint16_t* data, size_t len, uint32_t* out);
 int FLAGSTATS_hip_pospopcnt_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out);
 int FLAGSTATS_hip_device_pospopcnt_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream);
 
-/* read-only bandwidth probe with K1's load pattern and no flagstat arithmetic
- * (the analogue of the reference's memcpy baseline, linux/instrumented_benchmark.cpp:456-544):
- * `reps` sweeps of d_buf[0..bytes) (16-B aligned) between two hipEvents; nt = non-temporal loads. */
+/* read-only bandwidth probe, no flagstat arithmetic (the analogue of the reference's memcpy baseline,
+ * linux/instrumented_benchmark.cpp:456-544), in the fastest read pattern found on the chip (24 KiB in flight per CU:
+ * 384-thread workgroups x 4 vectors per lane; profiles/r03/read_probe_sweep.log): `reps` sweeps of d_buf[0..bytes)
+ * (16-B aligned) between two hipEvents; nt = non-temporal loads. */
 int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warmup, int reps, float* ms_total);
 
 /* parameterised variant for access-pattern sweeps (tools/probe_sweep.py): mode 0 grid-stride /

@@ -144,7 +144,7 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
     } else if (!std::strcmp(key, "variant")) {
         if (value > 255) return fail_text("variant must be 0..255");
         if (!fsk_variant_supported(static_cast<int>(value)))
-            return fail_text("this build carries K1 schedules 9 and 25 only (the sweeps' losers need make TUNING=1)");
+            return fail_text("this build carries K1 schedules 9, 25 and 71 only (the sweeps' losers need make TUNING=1)");
         k.variant = static_cast<int>(value);
     } else if (!std::strcmp(key, "fuse")) {
         if (value > 1) return fail_text("fuse must be 0 or 1");
@@ -631,11 +631,13 @@ static int probe_common(const void* d_buf, int warmup, int reps, float* ms_total
 
 int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warmup, int reps, float* ms_total)
 {
-    const int params[1] = {nt};
+    // the fastest read-only pattern found on this chip (profiles/r03/read_probe_sweep.log): one 384-thread workgroup per
+    // CU, 4 vectors per lane per step = 24 KiB in flight per CU, grid-stride (r01-r02 used 256 x 8 = 32 KiB: 1.5-2 % less)
+    const int params[4] = {0, 4, 384, nt};
     return probe_common(
         d_buf, warmup, reps, ms_total,
-        [](const void* b, uint64_t n, uint32_t grid, uint32_t* sink, hipStream_t s, const int* p) {
-            return fsk_read_probe(b, n, grid, p[0], sink, s);
+        [](const void* b, uint64_t n, uint32_t g, uint32_t* sink, hipStream_t s, const int* p) {
+            return fsk_read_probe2(b, n, p[0], p[1], static_cast<uint32_t>(p[2]), g, p[3], sink, s);
         },
         bytes, 0, params);
 }

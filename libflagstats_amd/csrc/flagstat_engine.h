@@ -29,7 +29,7 @@ struct Workspace {
 // process-wide tuning knobs (FLAGSTATS_hip_set / env FLAGSTATS_HIP_*); they survive a shutdown
 struct Knobs {
     std::atomic<uint32_t> blocks_per_cu{0};       // 0 = auto (1)
-    std::atomic<int> variant{25};                 // K1 schedule, see flagstat_kernels.hip
+    std::atomic<int> variant{71};                 // K1 schedule, see flagstat_kernels.hip (71: rolling at distance 6, r03)
     std::atomic<uint32_t> dyn_first_pct{75}, dyn_div{4}, dyn_cmax{32}, dyn_min_steps{32}, dyn_lgq{3};  // dynamic schedule (variant bit 7)
     std::atomic<uint64_t> small_flags{1ull << 20}; // host arrays up to this many flags: copied into the pinned input buffer and read
                                                   // in place (no H2D copy call); 0 = always stage through device memory

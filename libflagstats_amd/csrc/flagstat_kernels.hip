@@ -191,7 +191,11 @@ template <int DEPTH, int STAGE, bool NT, int USTRIDE, bool HAS_NEXT = true>
 __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32_t blk, const uint4* __restrict__ next,
                                      LdsStage lds = LdsStage{nullptr, 0, 0}, const uint4* __restrict__ cur = nullptr)
 {
-    constexpr bool ROLL = (STAGE == 1);
+    constexpr bool ROLL = (STAGE == 1 || STAGE == 6 || STAGE == 7 || STAGE == 8);
+    // measurement only (tuning variants 61 / 63): re-issue the loads in groups of RG instead of one by one -- RG vectors
+    // are split out of their registers, then their RG loads go out back to back
+    constexpr int RG = STAGE == 7 ? 2 : (STAGE == 8 ? 4 : 1);
+    uint32_t PL[kUnroll][4];
     uint32_t t8a = 0, t8b = 0, f8a = 0, f8b = 0, s8a = 0, s8b = 0;
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
@@ -213,30 +217,51 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
                     H0 = perm(x.y, x.x, 0x07050301u);
                     L1 = perm(x.w, x.z, 0x06040200u);
                     H1 = perm(x.w, x.z, 0x07050301u);
-                } else if constexpr (STAGE == 5) {
+                } else if constexpr (STAGE == 5 || STAGE == 9 || STAGE == 10 || STAGE == 11 || STAGE == 12) {
+                    // rolling at a distance of RD < 8 vectors: vector u's registers are re-issued for vector u + RD of
+                    // the same step, or u + RD - 8 of the next one (STAGE 5: RD = 4 with 8 waves; 9 / 10 / 11:
+                    // measurement only, RD = 6 / 7 / 5 with 4 waves = 24 / 28 / 20 KiB in flight per CU)
+                    constexpr int RD = STAGE == 5 ? 4 : ((STAGE == 9 || STAGE == 12) ? 6 : (STAGE == 10 ? 7 : 5));
                     const int uu = half * 4 + q * 2 + k;  // a constant after unrolling
                     __builtin_amdgcn_sched_barrier(0);
                     split_out(v[uu], L0, H0, L1, H1);
-                    if (uu < 4)
-                        v[uu + 4] = load_vec<NT>(cur + (uu + 4) * USTRIDE);
+                    if (uu + RD < 8)
+                        v[uu + RD] = load_vec<NT>(cur + (uu + RD) * USTRIDE);
                     else if constexpr (HAS_NEXT)
-                        v[uu - 4] = load_vec<NT>(next + (uu - 4) * USTRIDE);
+                        v[uu + RD - 8] = load_vec<NT>(next + (uu + RD - 8) * USTRIDE);
                     __builtin_amdgcn_sched_barrier(0);
                 } else if constexpr (ROLL) {
                     // Split the vector out of its registers HERE (a load may land at any time, so the registers it
                     // targets must be dead first), then re-issue into the same registers.  The asm keeps hipcc from
                     // turning the reads into loop-top PHI moves (which wait for all 8 loads), the sched_barriers from
                     // sinking the loads below the arithmetic.
-                    __builtin_amdgcn_sched_barrier(0);
-                    split_out(v[half * 4 + q * 2 + k], L0, H0, L1, H1);
-                    v[half * 4 + q * 2 + k] = load_vec<NT>(next + (half * 4 + q * 2 + k) * USTRIDE);
-                    __builtin_amdgcn_sched_barrier(0);
+                    const int uu = half * 4 + q * 2 + k;  // a constant after unrolling
+                    if (uu % RG == 0) {
+                        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                        for (int r = 0; r < RG; ++r) split_out(v[uu + r], PL[uu + r][0], PL[uu + r][1], PL[uu + r][2], PL[uu + r][3]);
+#pragma unroll
+                        for (int r = 0; r < RG; ++r) v[uu + r] = load_vec<NT>(next + (uu + r) * USTRIDE);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    L0 = PL[uu][0];
+                    H0 = PL[uu][1];
+                    L1 = PL[uu][2];
+                    H1 = PL[uu][3];
                 } else {
                     const uint4 x = v[half * 4 + q * 2 + k];
                     L0 = perm(x.y, x.x, 0x06040200u);
                     H0 = perm(x.y, x.x, 0x07050301u);
                     L1 = perm(x.w, x.z, 0x06040200u);
                     H1 = perm(x.w, x.z, 0x07050301u);
+                }
+                if constexpr (STAGE == 6 || STAGE == 12) {
+                    // measurement only (tuning variants 57 / 73): K1's exact load schedule with the arithmetic reduced to
+                    // one XOR per dword -- what the rolling re-issue reads when the VALU does nothing else
+                    T[2 * k] = L0 ^ H0;
+                    T[2 * k + 1] = L1 ^ H1;
+                    F[2 * k] = F[2 * k + 1] = S[2 * k] = S[2 * k + 1] = 0;
+                    continue;
                 }
                 uint32_t qa, qb, ka, kb;
                 front4(L0, H0, T[2 * k], qa, ka);
@@ -249,6 +274,10 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
                 // reads (bits 6,7 of the keep-mask).  lut & (keep | 0x3f) is ONE v_bitop3_b32.
                 S[2 * k] = perm(0u, 0x84428140u, qa) & (ka | 0x3F3F3F3Fu);
                 S[2 * k + 1] = perm(0u, 0x84428140u, qb) & (kb | 0x3F3F3F3Fu);
+            }
+            if constexpr (STAGE == 6 || STAGE == 12) {
+                s.t1 ^= T[0] ^ T[1] ^ T[2] ^ T[3];
+                continue;
             }
             uint32_t t2a, t2b, f2a, f2b, s2a, s2b;
             csa(t2a, s.t1, s.t1, T[0], T[1]);
@@ -265,6 +294,7 @@ __device__ __forceinline__ void step(Lane<DEPTH>& s, uint4 (&v)[kUnroll], uint32
         csa(half ? f8b : f8a, s.f4, s.f4, f4a, f4b);
         csa(half ? s8b : s8a, s.s4, s.s4, s4a, s4b);
     }
+    if constexpr (STAGE == 6 || STAGE == 12) return;
     uint32_t ct, cf, cs;
     csa(ct, s.t8, s.t8, t8a, t8b);  // weight-16 carries
     csa(cf, s.f8, s.f8, f8a, f8b);
@@ -551,7 +581,7 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : (STAGE == 5 ? 2 * kThr
         // first fully in-range step of this workgroup
         uint64_t st = blockIdx.x;
         if (st < fast_begin) st += G;  // fast_begin is 0 or 1
-        if constexpr (STAGE == 1) {
+        if constexpr (STAGE == 1 || STAGE == 6 || STAGE == 7 || STAGE == 8) {
             if (st < fast_end) {
                 uint4 v[kUnroll];
                 const uint4* p = a0 + st * kVecPerStep + lane_off;
@@ -563,28 +593,29 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : (STAGE == 5 ? 2 * kThr
                 }
                 for (; st + G < fast_end; st += G) {
                     p += G * kVecPerStep;
-                    step_and_count<DEPTH, 1, NT, US>(s, v, blk, p);
+                    step_and_count<DEPTH, STAGE, NT, US>(s, v, blk, p);
                     FSK_TL_ONCE(1);
                 }
                 step_and_count(s, v, blk);
                 FSK_TL_ONCE(1);
             }
-        } else if constexpr (STAGE == 5) {
+        } else if constexpr (STAGE == 5 || STAGE == 9 || STAGE == 10 || STAGE == 11 || STAGE == 12) {
+            constexpr int RD = STAGE == 5 ? 4 : ((STAGE == 9 || STAGE == 12) ? 6 : (STAGE == 10 ? 7 : 5));
             if (st < fast_end) {
                 uint4 v[kUnroll];
                 const uint4* p = a0 + st * VPS + lane_off;
 #pragma unroll
-                for (int u = 0; u < 4; ++u) {  // the first half step; the rest is issued as it is consumed
+                for (int u = 0; u < RD; ++u) {  // the first RD vectors; the rest is issued as they are consumed
                     v[u] = load_vec<NT>(p + u * US);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 for (; st + G < fast_end; st += G) {
                     const uint4* pn = p + G * VPS;
-                    step_and_count<DEPTH, 5, NT, US, true>(s, v, blk, pn, LdsStage{nullptr, 0, 0}, p);
+                    step_and_count<DEPTH, STAGE, NT, US, true>(s, v, blk, pn, LdsStage{nullptr, 0, 0}, p);
                     FSK_TL_ONCE(1);
                     p = pn;
                 }
-                step_and_count<DEPTH, 5, NT, US, false>(s, v, blk, nullptr, LdsStage{nullptr, 0, 0}, p);
+                step_and_count<DEPTH, STAGE, NT, US, false>(s, v, blk, nullptr, LdsStage{nullptr, 0, 0}, p);
                 FSK_TL_ONCE(1);
             }
         } else if constexpr (STAGE == 4) {
@@ -1081,12 +1112,16 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
     // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers,
     // 32 = staging through a per-wave LDS ring filled by LDS-DMA, 64 = rolling at distance 2 (two buffers).
-    // The shipped library carries the default schedule (25) and the plain loop it is measured against (9).
+    // Numbers from 57 on are plain labels.  The shipped library carries the default schedule (71), the r02 default (25)
+    // and the plain loop they are measured against (9).
     // The schedules that lost the r01 sweeps stay in the source as evidence and are compiled only into a
     // tuning build (make TUNING=1 -> -DFLAGSTAT_TUNING_VARIANTS; tools/tune.py, profiles/r01/tune_*.log).
     switch (variant & 255) {
     case 9: e = launch_count_t<8, true, false, true>(a, stream); break;
-    case 25: e = launch_count_t<8, true, false, true, 1>(a, stream); break;
+    case 25: e = launch_count_t<8, true, false, true, 1>(a, stream); break;   // r01-r02 default: rolling over a whole step
+    // default since r03: rolling at a distance of 6 vectors (24 KiB in flight per CU instead of 32), each wave a
+    // contiguous 8 KiB of the step -- +2.3-2.8 % at 8 GiB, +4 % at 1 GiB (profiles/r03/rolling_distance_sweep.log)
+    case 71: e = launch_count_t<8, true, false, false, 9>(a, stream); break;
 #ifdef FLAGSTAT_TUNING_VARIANTS
     // bit 7: 25 + guided self-scheduling.  Balances the XCDs to within 2 us of each other and is NOT faster (HBM, not the
     // split between XCDs, sets the time: profiles/r03/dyn_sweep*.log, timeline_153.log) -- evidence, tuning build only
@@ -1094,6 +1129,18 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     // 25 with TWO waves per SIMD: 512-thread workgroups, every wave rolls over half a step (4 loads in flight), same
     // 32 KiB in flight per CU -- the VERDICT r02 experiment on K1's VALU headroom (profiles/r03/two_waves_per_simd.log)
     case 29: e = launch_count_t<8, true, false, true, 5>(a, stream); break;
+    // measurement only: 25's load schedule with (almost) no arithmetic (57), and 25 with each wave owning a contiguous
+    // 8 KiB of the step instead of the 1 KiB interleave (17) -- where the last 1.5 % to the read probe is
+    case 57: e = launch_count_t<8, true, false, true, 6>(a, stream); break;
+    case 17: e = launch_count_t<8, true, false, false, 1>(a, stream); break;
+    case 61: e = launch_count_t<8, true, false, true, 7>(a, stream); break;  // loads re-issued in pairs
+    case 63: e = launch_count_t<8, true, false, true, 8>(a, stream); break;  // ... in fours
+    case 65: e = launch_count_t<8, true, false, true, 11>(a, stream); break; // rolling distance 5 vectors (20 KiB per CU in flight)
+    case 67: e = launch_count_t<8, true, false, true, 9>(a, stream); break;  // 6 (24 KiB)
+    case 69: e = launch_count_t<8, true, false, true, 10>(a, stream); break; // 7 (28 KiB)
+    case 73: e = launch_count_t<8, true, false, true, 12>(a, stream); break; // 6, (almost) no arithmetic: the schedule's own ceiling
+    case 75: e = launch_count_t<8, true, false, false, 11>(a, stream); break; // 5, contiguous
+    case 77: e = launch_count_t<8, true, false, false, 10>(a, stream); break; // 7, contiguous
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
     case 13: e = launch_count_t<8, true, true, true>(a, stream); break;
@@ -1157,9 +1204,20 @@ extern "C" int fsk_variant_supported(int variant)
 {
     switch (variant & 255) {
     case 9:
-    case 25: return 1;
+    case 25:
+    case 71: return 1;
 #ifdef FLAGSTAT_TUNING_VARIANTS
+    case 17:
     case 29:
+    case 57:
+    case 61:
+    case 63:
+    case 65:
+    case 67:
+    case 69:
+    case 73:
+    case 75:
+    case 77:
     case 153:
     case 0:
     case 1:

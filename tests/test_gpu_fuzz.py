@@ -18,7 +18,7 @@ def test_random_lengths_offsets_geometries(hip):
     old_f, old_e = hip.FLAGSTATS_hip_get(b"fuse"), hip.FLAGSTATS_hip_get(b"epilogue")
     # the shipped library carries the default schedule and the plain loop; a tuning build (make TUNING=1) all of them
     tuning = bool(hip.FLAGSTATS_hip_get(b"tuning_build"))
-    variants = [9, 25] + ([0, 1, 13, 27, 29, 41, 89, 153] if tuning else [])
+    variants = [9, 25, 71] + ([0, 1, 13, 17, 27, 29, 41, 61, 63, 65, 67, 69, 75, 77, 89, 153] if tuning else [])
     try:
         for it in range(int(os.environ.get("FLAGSTATS_FUZZ_ITERS", "150"))):   # a soak run sets thousands
             kind = int(rs.randint(0, 3))

@@ -16,7 +16,10 @@ n = 2 ** 32
 d = device.DeviceFlags(n).generate(0, seed=1, mask=0xFFFF)
 cus = lib.FLAGSTATS_hip_compute_units()
 rows = []
-combos = list(itertools.product((0, 1), (1,), (256, 512, 1024), (2, 4, 8, 16), (1, 2, 4)))
+# r03: workgroup sizes between the powers of two as well -- r01's sweep only ever had 8 / 16 / 32 / 64 KiB in flight per
+# CU and missed the optimum near 24 KiB that the rolling schedule found (profiles/r03/rolling_distance_sweep.log)
+sizes = (256, 512, 1024) if "--r01" in sys.argv else (128, 192, 256, 320, 384, 448, 512, 768, 1024)
+combos = list(itertools.product((0, 1), (1,), sizes, (2, 4, 8, 16), (1, 2, 4)))
 for rnd in range(3):
     for mode, nt, threads, unroll, bpc in combos:
         if threads * unroll * 16 * bpc > 256 * 1024:      # > 256 KiB in flight per CU: pointless
