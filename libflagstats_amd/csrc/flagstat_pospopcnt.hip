@@ -39,9 +39,17 @@ __device__ __forceinline__ void pos_chain_push(PosLane& s, uint32_t blk, uint32_
     }
 }
 
-// 8 vectors = 32 dwords = 64 words per lane.  ROLL as in K1: copy out, re-issue into the same registers.
-template <bool ROLL>
-__device__ __forceinline__ void pos_step(PosLane& s, uint4 (&v)[kUnroll], uint32_t blk, const uint4* __restrict__ next)
+// Load schedule as K1's default (flagstat_kernels.hip, variant 71): each wave owns a contiguous 8 KiB of a step, and
+// vector u's registers are re-issued -- as soon as it has been copied out -- for vector u + 6 of the same step (`cur`)
+// or u - 2 of the lane's next step (`next`): 6 loads = 6 KiB per wave, 24 KiB per CU in flight, the chip's fastest
+// read pattern (profiles/r03/read_probe_sweep.log, rolling_distance_sweep.log).
+constexpr int kPosRD = 6;    // rolling distance in vectors
+constexpr int kPosUS = 64;   // vectors between a lane's consecutive loads (wave-contiguous layout)
+
+// 8 vectors = 32 dwords = 64 words per lane.  ROLL: copy out, re-issue into the same registers.
+template <bool ROLL, bool HAS_NEXT = true>
+__device__ __forceinline__ void pos_step(PosLane& s, uint4 (&v)[kUnroll], uint32_t blk, const uint4* __restrict__ next,
+                                         const uint4* __restrict__ cur = nullptr)
 {
     uint32_t c16[2];
 #pragma unroll
@@ -57,7 +65,10 @@ __device__ __forceinline__ void pos_step(PosLane& s, uint4 (&v)[kUnroll], uint32
                 if constexpr (ROLL) {
                     __builtin_amdgcn_sched_barrier(0);
                     x = copy_out(x);
-                    v[u] = load_vec<true>(next + u * kThreads);
+                    if (u + kPosRD < kUnroll)
+                        v[u + kPosRD] = load_vec<true>(cur + (u + kPosRD) * kPosUS);
+                    else if constexpr (HAS_NEXT)
+                        v[u + kPosRD - kUnroll] = load_vec<true>(next + (u + kPosRD - kUnroll) * kPosUS);
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 uint32_t a, b;
@@ -97,10 +108,12 @@ __device__ __forceinline__ void pos_flush(PosLane& s)
     for (int j = 0; j < kPosDepth; ++j) s.A[j] = s.B[j] = 0;
 }
 
-template <bool ROLL>
-__device__ __forceinline__ void pos_step_and_count(PosLane& s, uint4 (&v)[kUnroll], uint32_t& blk, const uint4* next)
+template <bool ROLL, bool HAS_NEXT = true>
+__device__ __forceinline__ void pos_step_and_count(PosLane& s, uint4 (&v)[kUnroll], uint32_t& blk, const uint4* next,
+                                                   const uint4* cur = nullptr)
 {
-    pos_step<ROLL>(s, v, blk, next);
+    blk = __builtin_amdgcn_readfirstlane(blk);  // wave-uniform: scalar branches in the chain
+    pos_step<ROLL, HAS_NEXT>(s, v, blk, next, cur);
     ++blk;
     if (blk == (1u << kPosDepth) - 1u) {
         pos_flush(s);
@@ -119,14 +132,14 @@ __global__ __launch_bounds__(kThreads) void pospopcnt_count(const uint4* __restr
 #pragma unroll
     for (int c = 0; c < 16; ++c) s.acc[c] = 0;
     const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
-    const uint64_t lane_off = threadIdx.x;  // vector of (u, thread) within a step: u*256 + thread
+    const uint64_t lane_off = static_cast<uint64_t>(wave) * (64 * kUnroll) + lane;  // vector of (wave, u, lane): wave*512 + u*64 + lane
     const uint64_t G = gridDim.x;
     uint32_t blk = 0;
 
     auto edge_step = [&](uint64_t st) {
         uint4 v[kUnroll];
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) v[u] = load_guarded(a0, st * kVecPerStep + lane_off + u * kThreads, lo, hi);
+        for (int u = 0; u < kUnroll; ++u) v[u] = load_guarded(a0, st * kVecPerStep + lane_off + u * kPosUS, lo, hi);
         pos_step_and_count<false>(s, v, blk, nullptr);
     };
     if (fast_begin != 0 && blockIdx.x == 0) edge_step(0);
@@ -138,15 +151,16 @@ __global__ __launch_bounds__(kThreads) void pospopcnt_count(const uint4* __restr
         uint4 v[kUnroll];
         const uint4* p = a0 + st * kVecPerStep + lane_off;
 #pragma unroll
-        for (int u = 0; u < kUnroll; ++u) {
-            v[u] = load_vec<true>(p + u * kThreads);
+        for (int u = 0; u < kPosRD; ++u) {  // the first 6 vectors; the rest is issued as they are consumed
+            v[u] = load_vec<true>(p + u * kPosUS);
             __builtin_amdgcn_sched_barrier(0);
         }
         for (; st + G < fast_end; st += G) {
-            p += G * kVecPerStep;
-            pos_step_and_count<true>(s, v, blk, p);
+            const uint4* pn = p + G * kVecPerStep;
+            pos_step_and_count<true, true>(s, v, blk, pn, p);
+            p = pn;
         }
-        pos_step_and_count<false>(s, v, blk, nullptr);
+        pos_step_and_count<true, false>(s, v, blk, nullptr, p);
     }
     pos_flush(s);
 
