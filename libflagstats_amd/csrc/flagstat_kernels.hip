@@ -10,9 +10,13 @@
 // design is for wave64 / VALU / HBM3E:
 //
 //  K1 flagstat_count   grid-stride over 32 KiB "steps"; each lane loads 8 x 16 B
-//                      (global_load_dwordx4, 1 KiB per wave-instruction, fully
+//                      (global_load_dwordx4 nt, 1 KiB per wave-instruction, fully
 //                      coalesced), straight to VGPRs (read-once stream: an LDS
-//                      round trip buys nothing).  Per 16 B (8 flags):
+//                      round trip buys nothing), six of them in flight at any time: a
+//                      vector's registers are re-issued for the vector six places on as
+//                      soon as it has been split out (24 KiB in flight per CU is what this
+//                      chip reads fastest: profiles/r03/rolling_distance_sweep.log).
+//                      Per 16 B (8 flags):
 //                        * v_perm_b32 splits 2 dwords (4 flags) into a dword of
 //                          low bytes L and a dword of high bytes H  (byte-planar:
 //                          every later op works on 4 flags at once);
@@ -525,6 +529,29 @@ __device__ __forceinline__ void step_and_count(Lane<DEPTH>& s, uint4 (&v)[kUnrol
     }
 }
 
+// measurement only (tuning variants 79 / 81): the distance-RD rolling loop as a function, so that the waves of a workgroup
+// can run different distances (22 or 26 KiB in flight per CU)
+template <int DEPTH, int RSTAGE, bool NT, int US, int VPS>
+__device__ __forceinline__ void roll_partial(Lane<DEPTH>& s, uint32_t& blk, const uint4* __restrict__ a0, uint64_t st, uint64_t G,
+                                             uint64_t fast_end, uint64_t lane_off)
+{
+    constexpr int RD = RSTAGE == 9 ? 6 : (RSTAGE == 10 ? 7 : 5);
+    if (st >= fast_end) return;
+    uint4 v[kUnroll];
+    const uint4* p = a0 + st * VPS + lane_off;
+#pragma unroll
+    for (int u = 0; u < RD; ++u) {
+        v[u] = load_vec<NT>(p + u * US);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    for (; st + G < fast_end; st += G) {
+        const uint4* pn = p + G * VPS;
+        step_and_count<DEPTH, RSTAGE, NT, US, true>(s, v, blk, pn, LdsStage{nullptr, 0, 0}, p);
+        p = pn;
+    }
+    step_and_count<DEPTH, RSTAGE, NT, US, false>(s, v, blk, nullptr, LdsStage{nullptr, 0, 0}, p);
+}
+
 // PREFETCH = false: load 8 x 16 B, wait, compute; latency is hidden by the other
 // waves of the SIMD only.  PREFETCH = true: two register buffers, the loads of
 // step k+1 are in flight while step k is computed (one more 8 KiB per wave in
@@ -618,6 +645,12 @@ __global__ __launch_bounds__(STAGE == 4 ? kThreads + 64 : (STAGE == 5 ? 2 * kThr
                 step_and_count<DEPTH, STAGE, NT, US, false>(s, v, blk, nullptr, LdsStage{nullptr, 0, 0}, p);
                 FSK_TL_ONCE(1);
             }
+        } else if constexpr (STAGE == 13 || STAGE == 14) {
+            // waves 0 and 2 at distance 6, waves 1 and 3 at 7 (13: 26 KiB per CU) or 5 (14: 22 KiB per CU)
+            if (wave & 1u)
+                roll_partial<DEPTH, STAGE == 13 ? 10 : 11, NT, US, VPS>(s, blk, a0, st, G, fast_end, lane_off);
+            else
+                roll_partial<DEPTH, 9, NT, US, VPS>(s, blk, a0, st, G, fast_end, lane_off);
         } else if constexpr (STAGE == 4) {
             // Rolling registers + GUIDED SELF-SCHEDULING of the fully in-range steps (q-space [0, N), step = fast_begin + q).
             // Why: the XCDs do not read HBM equally fast, and which one is slow changes from launch to launch
@@ -1140,6 +1173,8 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     case 69: e = launch_count_t<8, true, false, true, 10>(a, stream); break; // 7 (28 KiB)
     case 73: e = launch_count_t<8, true, false, true, 12>(a, stream); break; // 6, (almost) no arithmetic: the schedule's own ceiling
     case 75: e = launch_count_t<8, true, false, false, 11>(a, stream); break; // 5, contiguous
+    case 79: e = launch_count_t<8, true, false, false, 13>(a, stream); break; // 6 / 7 by wave parity (26 KiB), contiguous
+    case 81: e = launch_count_t<8, true, false, false, 14>(a, stream); break; // 6 / 5 by wave parity (22 KiB), contiguous
     case 77: e = launch_count_t<8, true, false, false, 10>(a, stream); break; // 7, contiguous
     case 0: e = launch_count_t<8, false, false, false>(a, stream); break;
     case 1: e = launch_count_t<8, true, false, false>(a, stream); break;
@@ -1218,6 +1253,8 @@ extern "C" int fsk_variant_supported(int variant)
     case 73:
     case 75:
     case 77:
+    case 79:
+    case 81:
     case 153:
     case 0:
     case 1:

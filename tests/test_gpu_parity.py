@@ -112,7 +112,7 @@ def test_empty_and_null(hip):
 
 
 # --------------------------------------------------------------------------- oracle, seeded inputs
-@pytest.mark.parametrize("variant", [0, 1, 9, 13, 17, 25, 27, 29, 41, 61, 63, 65, 67, 69, 71, 75, 77, 89, 153])
+@pytest.mark.parametrize("variant", [0, 1, 9, 13, 17, 25, 27, 29, 41, 61, 63, 65, 67, 69, 71, 75, 77, 79, 81, 89, 153])
 def test_kernel_variants_agree_with_oracle(hip, variant):
     import oracle
     from libflagstats_amd import _lib, device
