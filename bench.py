@@ -310,13 +310,20 @@ def main():
             try:
                 ident = torch.zeros(128, dtype=torch.uint8)
                 if rank == 0:
+                    # a failure here must not keep rank 0 out of the broadcast the other ranks are waiting in: it
+                    # ships an all-zero id instead, and every rank then skips the C-ABI communicator
                     buf = (ctypes.c_char * 128)()
-                    _lib.check(lib.FLAGSTATS_hip_comm_unique_id(buf), "FLAGSTATS_hip_comm_unique_id")
-                    ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+                    if lib.FLAGSTATS_hip_comm_unique_id(buf) == 0:
+                        ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+                    else:
+                        print("bench.py: FLAGSTATS_hip_comm_unique_id failed: %s"
+                              % lib.FLAGSTATS_hip_last_error().decode(errors="replace"), file=sys.stderr)
                 if args.backend == "nccl":
                     ident = ident.to(dev)
                 dist.broadcast(ident, src=0)
                 raw = bytes(ident.cpu().numpy().tobytes())
+                if not any(raw):
+                    raise _lib.FlagstatsHipError("rank 0 could not make an RCCL unique id")
                 # ncclCommInitRank is itself a collective: if it never returns on some rank (first time this path
                 # meets a real multi-GPU node), do not hang the run -- give it a bounded time on a helper thread,
                 # then let every rank agree (below) to carry the all-reduce with torch.distributed instead
@@ -343,7 +350,11 @@ def main():
             except Exception as e:  # noqa: BLE001 -- a scaling run must not die on the communicator; say so instead
                 print("bench.py: C-ABI RCCL communicator unavailable (%r); using torch.distributed all_reduce" % (e,),
                       file=sys.stderr)
+                if comm and not comm_init_hung:
+                    lib.FLAGSTATS_hip_comm_destroy(comm)
                 comm = None
+                rccl_nranks = None
+                ar_impl = "torch.distributed (%s)" % args.backend
             # every rank must take the same path
             flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
