@@ -170,11 +170,13 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *                    caller's counters per launch instead of one pair per workgroup) from this many workgroups on
  *                    (default 64; 0 = any grid), as long as a workgroup has at most 24 steps (arrays up to ~192 MiB:
  *                    beyond that the workgroups finish too far apart for the contention to matter)
- *   "small_flags"    host-pointer calls of up to this many flags (default and maximum 1048576) are copied by the CPU into a pinned buffer
- *                    that K1 reads in place over PCIe -- no copy call; larger single-chunk calls use an asynchronous H2D
- *                    copy into device staging.  0 = always stage
- *   "poll"           1 (default): single-chunk host-pointer calls wait for a completion word the last kernel writes next to
- *                    the counters in pinned host memory instead of synchronising the stream; 0 = hipStreamSynchronize
+ *   "small_flags"    host-pointer calls of up to this many flags (default 1048576, maximum 4194304) are copied by the CPU --
+ *                    no copy call -- into the engine's input buffer: fine-grained device memory written through the PCIe BAR
+ *                    (knob "small_bar", default 1, needs a large-BAR device; read-only key "small_in_is_device" says which), else
+ *                    pinned host memory that K1 reads in place.  Larger single-chunk calls use an asynchronous H2D copy into
+ *                    device staging.  0 = always stage
+ *   "poll"           1 (default): single-chunk host-pointer calls poll the {value, sequence} pairs the last kernel writes to
+ *                    pinned host memory instead of synchronising the stream; 0 = hipStreamSynchronize
  *   "epoch_stagger"  1 (default): the four waves of a K1 workgroup fold their bit-sliced counters (every 255 steps)
  *                    at different steps, so HBM never idles for it chip-wide; 0 = all at the same step (r02)
  *   "fence_free_events" FLAGSTATS_hip_stream_wait_stream / the overlapped all-reduce: 1 = ordering events without the

@@ -28,7 +28,7 @@ int FLAGSTAT_hip(const uint16_t* array, uint32_t len, uint32_t* flags); /* same 
 int FLAGSTATS_hip_available(void);
 #ifndef FLAGSTATS_HIP_MIN_LEN
 #define FLAGSTATS_HIP_MIN_LEN (1u << 17) /* break-even of a host-pointer call vs FLAGSTAT_avx512 on 2x EPYC 9575F:
-                                          * ~1.3e5 flags (15 us call floor; 131,072 flags: 23 vs 24 us; 512,000: 51 vs 93 us;
+                                          * ~1.1e5 flags (13 us call floor; 131,072 flags: 23 vs 24 us; 512,000: 39 vs 93 us;
                                           * profiles/r03/small_calls.log) */
 #endif
 static int FLAGSTATS_hip_wanted(uint32_t n_len)

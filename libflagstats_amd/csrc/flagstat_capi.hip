@@ -159,6 +159,9 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         k.epilogue = static_cast<int>(value);
     } else if (!std::strcmp(key, "small_flags")) {
         k.small_flags = value;
+    } else if (!std::strcmp(key, "small_bar")) {
+        if (value > 1) return fail_text("small_bar must be 0 or 1");
+        k.small_bar = static_cast<int>(value);   // takes effect for engines created afterwards
     } else if (!std::strcmp(key, "poll")) {
         if (value > 1) return fail_text("poll must be 0 or 1");
         k.poll = static_cast<int>(value);
@@ -215,6 +218,12 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "dyn_lg_queues")) return k.dyn_lgq.load();
     if (!std::strcmp(key, "group_min_grid")) return k.group_min_grid.load();
     if (!std::strcmp(key, "small_flags")) return k.small_flags.load();
+    if (!std::strcmp(key, "small_bar")) return static_cast<uint64_t>(k.small_bar.load());
+    if (!std::strcmp(key, "small_in_is_device")) {
+        if (fsint::default_device() < 0) return 0;
+        Engine* e = fsint::default_engine();
+        return e && e->small_bar_in ? 1 : 0;
+    }
     if (!std::strcmp(key, "poll")) return static_cast<uint64_t>(k.poll.load());
     if (!std::strcmp(key, "epoch_stagger")) return static_cast<uint64_t>(k.epoch_stagger.load());
     if (!std::strcmp(key, "fuse")) return static_cast<uint64_t>(k.fuse.load());

@@ -33,6 +33,8 @@ struct Knobs {
     std::atomic<uint32_t> dyn_first_pct{75}, dyn_div{4}, dyn_cmax{32}, dyn_min_steps{32}, dyn_lgq{3};  // dynamic schedule (variant bit 7)
     std::atomic<uint64_t> small_flags{1ull << 20}; // host arrays up to this many flags: copied into the pinned input buffer and read
                                                   // in place (no H2D copy call); 0 = always stage through device memory
+    std::atomic<int> small_bar{1};                // 1: small-call input goes into device memory through the BAR when the device has a
+                                                  // large BAR (read at engine creation); 0: always pinned host memory
     std::atomic<int> poll{1};                     // single-launch host calls wait by polling a completion word the kernel writes
     std::atomic<int> epoch_stagger{1};            // K1: waves of a workgroup flush their epochs at different steps
     std::atomic<uint32_t> group_min_grid{64};     // K1's atomic epilogue goes through per-XCD copies from this many workgroups on
@@ -67,8 +69,11 @@ struct Engine {
     uint64_t stage_flags[2] = {0, 0};
     uint64_t* h_out = nullptr;                     // pinned 2 x 32 (also mapped into the device); words 64..127 = the small-call path's {value, seq} pairs
     uint64_t* h_out_dev = nullptr;                 // the same buffer as the device sees it
-    uint16_t* small_in = nullptr;                  // pinned input buffer of the small-call path, read in place by K1
-    uint16_t* small_in_dev = nullptr;
+    uint16_t* small_in = nullptr;                  // small-call input, pinned host memory that K1 reads in place
+    uint16_t* small_in_dev = nullptr;              // ... as K1 reads it
+    size_t small_pinned_bytes = 0;
+    uint16_t* small_bar_in = nullptr;              // small-call input above 2^17 flags: fine-grained DEVICE memory the CPU writes
+                                                   // through the PCIe BAR (nullptr: no large BAR, the pinned buffer serves all sizes)
     uint64_t small_seq = 0;                        // sequence number of the last small call (what its kernel stores next to each slot)
     uint32_t small_since_sync = 0;                 // polled calls since the stream was last synchronised
     hipEvent_t chunk_done[2] = {nullptr, nullptr}; // host streaming: chunk in slot i has been counted

@@ -23,7 +23,8 @@ namespace fsint {
 namespace {
 
 constexpr size_t kHostOutBytes = 1024;             // words 0..63: 2 x 32 counters; words 64..127: the small-call path's 32 {value, seq} pairs
-constexpr size_t kSmallInBytes = 2ull << 20;       // pinned input buffer: up to 1 Mi flags (knob small_flags picks the threshold)
+constexpr size_t kSmallInBytes = 8ull << 20;       // input buffer of the small-call path: up to 4 Mi flags (knob small_flags picks the threshold)
+constexpr uint64_t kSmallPinnedFlags = 1ull << 17; // up to here the pinned buffer (read in place) beats the BAR-written device buffer
 
 thread_local std::string g_err;
 
@@ -77,6 +78,7 @@ void read_env_knobs()
         g_knobs.dyn_cmax = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_CMAX", g_knobs.dyn_cmax));
         g_knobs.dyn_min_steps = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_MIN_STEPS", g_knobs.dyn_min_steps));
         g_knobs.small_flags = env_u64("FLAGSTATS_HIP_SMALL_FLAGS", g_knobs.small_flags);
+        g_knobs.small_bar = static_cast<int>(env_u64("FLAGSTATS_HIP_SMALL_BAR", static_cast<uint64_t>(g_knobs.small_bar)));
         g_knobs.poll = static_cast<int>(env_u64("FLAGSTATS_HIP_POLL", static_cast<uint64_t>(g_knobs.poll)));
         g_knobs.epoch_stagger = static_cast<int>(env_u64("FLAGSTATS_HIP_EPOCH_STAGGER", static_cast<uint64_t>(g_knobs.epoch_stagger)));
         fsk_set_epoch_stagger(g_knobs.epoch_stagger.load());
@@ -135,6 +137,7 @@ void release_engine_resources(Engine& e)
     }
     if (e.h_out) (void)hipHostFree(e.h_out);
     if (e.small_in) (void)hipHostFree(e.small_in);
+    if (e.small_bar_in) (void)hipFree(e.small_bar_in);
     for (int i = 0; i < 2; ++i)
         if (e.chunk_done[i]) (void)hipEventDestroy(e.chunk_done[i]);
     for (int i = 0; i < 3; ++i)
@@ -170,7 +173,19 @@ int engine_setup(Engine& e, int device)
     HIP_TRY(hipHostMalloc(&e.h_out, kHostOutBytes, hipHostMallocDefault));
     std::memset(e.h_out, 0, kHostOutBytes);
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e.h_out_dev), e.h_out, 0));
-    HIP_TRY(hipHostMalloc(&e.small_in, kSmallInBytes, hipHostMallocDefault));
+    // Input buffers of the small-call path.  (1) Pinned host memory that K1 reads in place over PCIe: lowest latency for a
+    // few KiB (n = 1,000: 12.5 us).  (2) Fine-grained DEVICE memory that the CPU writes straight through the PCIe BAR
+    // (posted, write-combined: 43 GB/s measured, tests/perf/bar_write_probe.py, against ~20 GB/s for the CPU's copy into
+    // pinned memory plus the kernel's PCIe read): the data crosses the bus once, pushed, and K1 reads it from HBM --
+    // 512,000 flags: 40-46 us instead of 51, 1 Mi flags: 65-72 instead of 106.  Without a large BAR, (1) serves both.
+    int large_bar = 0;
+    if (g_knobs.small_bar.load() && hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, device) == hipSuccess && large_bar) {
+        void* p = nullptr;
+        if (hipExtMallocWithFlags(&p, kSmallInBytes, hipDeviceMallocFinegrained) == hipSuccess) e.small_bar_in = static_cast<uint16_t*>(p);
+    }
+    (void)hipGetLastError();
+    e.small_pinned_bytes = e.small_bar_in ? kSmallPinnedFlags * sizeof(uint16_t) : kSmallInBytes;
+    HIP_TRY(hipHostMalloc(&e.small_in, e.small_pinned_bytes, hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e.small_in_dev), e.small_in, 0));
     return 0;
 }
@@ -653,9 +668,14 @@ int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
         // above that (measured: between 1 Mi and 2 Mi flags, profiles/r03/small_calls_threshold.log) the runtime's
         // asynchronous H2D copy into device staging is faster than the CPU's memcpy.
         const bool in_place = n <= g_knobs.small_flags.load() && n * sizeof(uint16_t) <= kSmallInBytes;
+        const bool through_bar = in_place && e.small_bar_in && n > kSmallPinnedFlags;
         const bool poll = g_knobs.poll.load() != 0;
         const uint16_t* src = e.stage[0];
-        if (in_place) {
+        if (through_bar) {
+            std::memcpy(e.small_bar_in, h, n * sizeof(uint16_t));
+            _mm_sfence();  // the write-combined stores leave the CPU before the doorbell of the launch
+            src = e.small_bar_in;
+        } else if (in_place) {
             std::memcpy(e.small_in, h, n * sizeof(uint16_t));
             src = e.small_in_dev;
         } else {

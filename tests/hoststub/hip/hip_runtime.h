@@ -54,6 +54,10 @@ hipError_t hipDeviceSynchronize(void);
 hipError_t hipGetLastError(void);
 const char* hipGetErrorString(hipError_t e);
 
+enum hipDeviceAttribute_t { hipDeviceAttributeIsLargeBar = 1 };
+enum { hipDeviceMallocFinegrained = 1 };
+hipError_t hipDeviceGetAttribute(int* value, hipDeviceAttribute_t attr, int device);
+hipError_t hipExtMallocWithFlags(void** p, size_t bytes, unsigned flags);
 hipError_t hipMalloc(void** p, size_t bytes);
 template <class T>
 static inline hipError_t hipMalloc(T** p, size_t bytes) { return hipMalloc(reinterpret_cast<void**>(p), bytes); }

@@ -21,9 +21,10 @@ ref = oracle.load_ref()
 if "--old" in sys.argv:
     lib.FLAGSTATS_hip_set(b"small_flags", 0)
     lib.FLAGSTATS_hip_set(b"poll", 0)
-print("small_flags=%d poll=%d" % (lib.FLAGSTATS_hip_get(b"small_flags"), lib.FLAGSTATS_hip_get(b"poll")))
+print("small_flags=%d poll=%d input buffer in %s" % (lib.FLAGSTATS_hip_get(b"small_flags"), lib.FLAGSTATS_hip_get(b"poll"),
+      "device memory (written through the BAR)" if lib.FLAGSTATS_hip_get(b"small_in_is_device") else "pinned host memory"))
 print("flags      hip_us/call  hip_Gflags/s   ref_us/call  ref_Gflags/s")
-for n in (1000, 16384, 50000, 100000, 131072, 200000, 512000, 2 ** 21, 2 ** 24, 2 ** 26):
+for n in (1000, 16384, 50000, 80000, 100000, 131072, 200000, 512000, 2 ** 20, 2 ** 21, 2 ** 22, 2 ** 24, 2 ** 26):
     a = oracle.generate(oracle.GEN_NA12878, 1, 1, 0, n)
     flags = np.zeros(32, dtype=np.uint32)
     reps = max(20, min(2000, 2 ** 28 // n))

@@ -15,13 +15,21 @@ def capi(hip, a, flags=None):
     return flags
 
 
+@pytest.mark.parametrize("bar", [1, 0])
 @pytest.mark.parametrize("poll,small_flags", [(1, 1 << 20), (1, 131072), (1, 0), (0, 131072), (0, 0), (1, 10 ** 9)])
-def test_many_small_calls_with_changing_data(hip, poll, small_flags):
+def test_many_small_calls_with_changing_data(hip, poll, small_flags, bar):
+    """bar = 1: the input buffer is device memory written by the CPU through the PCIe BAR (where the device has a large
+    BAR); bar = 0: pinned host memory read in place.  The buffer kind is fixed when an engine is created, hence the
+    shutdown / re-init around each setting."""
     import oracle
     from libflagstats_amd import _lib
-    old = {k: hip.FLAGSTATS_hip_get(k) for k in (b"poll", b"small_flags")}
+    old = {k: hip.FLAGSTATS_hip_get(k) for k in (b"poll", b"small_flags", b"small_bar")}
     _lib.check(hip.FLAGSTATS_hip_set(b"poll", poll), "poll")
     _lib.check(hip.FLAGSTATS_hip_set(b"small_flags", small_flags), "small_flags")
+    _lib.check(hip.FLAGSTATS_hip_set(b"small_bar", bar), "small_bar")
+    hip.FLAGSTATS_hip_shutdown()
+    _lib.check(hip.FLAGSTATS_hip_init(0), "init")
+    assert bar or not hip.FLAGSTATS_hip_get(b"small_in_is_device")
     try:
         rs = np.random.RandomState(77)
         pool = oracle.generate(oracle.GEN_UNIFORM, 123, 0xFFFF, 0, 1_200_000)
@@ -37,6 +45,8 @@ def test_many_small_calls_with_changing_data(hip, poll, small_flags):
     finally:
         for k, v in old.items():
             hip.FLAGSTATS_hip_set(k, v)
+        hip.FLAGSTATS_hip_shutdown()
+        _lib.check(hip.FLAGSTATS_hip_init(0), "init")
 
 
 def test_small_calls_from_several_threads(hip):
