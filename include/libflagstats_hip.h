@@ -310,6 +310,10 @@ int FLAGSTATS_hip_device_pospopcnt_u16(const uint16_t* d_array, uint64_t n, uint
  * (16-B aligned) between two hipEvents; nt = non-temporal loads. */
 int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warmup, int reps, float* ms_total);
 
+/* the fastest pattern with the load's cache-policy bits spelled out (tools/policy_probe.py): policy 0 plain, 1 nt, 2 sc1,
+ * 3 sc0 sc1, 4 sc1 nt, 5 sc0 sc1 nt, 6 sc0, 7 sc0 nt */
+int FLAGSTATS_hip_read_probe_policy(const void* d_buf, uint64_t bytes, int policy, int warmup, int reps, float* ms_total);
+
 /* parameterised variant for access-pattern sweeps (tools/probe_sweep.py): mode 0 grid-stride /
  * 1 block-contiguous; unroll 2|4|8|16 vectors of 16 B per lane per step; threads per workgroup. */
 int FLAGSTATS_hip_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads, uint32_t grid,

@@ -120,6 +120,8 @@ SIGNATURES = {
                                                           ctypes.c_void_p]),
     "FLAGSTATS_hip_read_probe": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                                 ctypes.c_int, ctypes.POINTER(ctypes.c_float)]),
+    "FLAGSTATS_hip_read_probe_policy": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                                       ctypes.POINTER(ctypes.c_float)]),
     "FLAGSTATS_hip_read_probe2": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
                                                  ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int,
                                                  ctypes.POINTER(ctypes.c_float)]),

@@ -651,6 +651,19 @@ int FLAGSTATS_hip_read_probe(const void* d_buf, uint64_t bytes, int nt, int warm
         bytes, 0, params);
 }
 
+extern "C" hipError_t fsk_read_probe_policy(const void* d_buf, uint64_t bytes, int policy, uint32_t grid, uint32_t* d_sink, hipStream_t s);
+
+int FLAGSTATS_hip_read_probe_policy(const void* d_buf, uint64_t bytes, int policy, int warmup, int reps, float* ms_total)
+{
+    const int params[1] = {policy};
+    return probe_common(
+        d_buf, warmup, reps, ms_total,
+        [](const void* b, uint64_t n, uint32_t g, uint32_t* sink, hipStream_t s, const int* p) {
+            return fsk_read_probe_policy(b, n, p[0], g, sink, s);
+        },
+        bytes, 0, params);
+}
+
 int FLAGSTATS_hip_read_probe2(const void* d_buf, uint64_t bytes, int mode, int unroll, uint32_t threads, uint32_t grid,
                               int nt, int warmup, int reps, float* ms_total)
 {
