@@ -269,7 +269,10 @@ typedef struct FLAGSTATS_gpu_lz4_stats {
     uint64_t n_blocks, n_flags, bad_blocks, compressed_bytes, decoded_bytes;
     double h2d_ms, decode_ms, count_ms;            /* stream-event times of the three phases */
     uint64_t sequences, far_matches;               /* LZ4 sequences decoded; matches that reached behind the LDS ring */
-    uint64_t ring_kib;                             /* LDS ring per wave (env FLAGSTATS_HIP_GPU_LZ4_RING = 16 | 8) */
+    uint64_t ring_kib;                             /* LDS ring per wave (env FLAGSTATS_HIP_GPU_LZ4_RING = 8 | 16) */
+    uint64_t chunks;                               /* pieces the image went over PCIe in (env FLAGSTATS_HIP_GPU_LZ4_CHUNKS) */
+    double pipeline_ms;                            /* first copy .. counters done; with chunks > 1, h2d_ms = all copies and
+                                                      decode_ms = the decode time left exposed after the last copy */
 } FLAGSTATS_gpu_lz4_stats;
 int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t bytes, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats);
 /* the host LZ4 *block* decoder used above (replaces the reference's call to liblz4's

@@ -32,7 +32,8 @@ class GpuLz4Stats(ctypes.Structure):
     _fields_ = [("n_blocks", ctypes.c_uint64), ("n_flags", ctypes.c_uint64), ("bad_blocks", ctypes.c_uint64),
                 ("compressed_bytes", ctypes.c_uint64), ("decoded_bytes", ctypes.c_uint64),
                 ("h2d_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("count_ms", ctypes.c_double),
-                ("sequences", ctypes.c_uint64), ("far_matches", ctypes.c_uint64), ("ring_kib", ctypes.c_uint64)]
+                ("sequences", ctypes.c_uint64), ("far_matches", ctypes.c_uint64), ("ring_kib", ctypes.c_uint64),
+                ("chunks", ctypes.c_uint64), ("pipeline_ms", ctypes.c_double)]
 
 
 # name -> (restype, argtypes); mirrors include/libflagstats_hip.h one to one

@@ -36,21 +36,33 @@ struct GpuBlock {
 // RING: bytes of recent output kept in LDS (matches up to RING - 64 back are LDS -> LDS); INWIN: staged input window.
 // 16 KiB + 4 KiB = 7 waves per CU (1792 blocks in flight); 8 KiB + 1 KiB = 17 per CU (4352: a 4 GiB file's 4195 blocks
 // all at once), at the price of more matches that reach behind the ring.
-template <uint32_t RING, uint32_t INWIN>
+template <uint32_t RING, uint32_t INWIN, bool PROF = false>
 __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks,
                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status,
                                                      unsigned long long* __restrict__ tally)
 {
     constexpr uint32_t kRingMask = RING - 1, kFlush = RING / 4;
-    __shared__ __attribute__((aligned(16))) uint8_t ring[RING];
-    __shared__ __attribute__((aligned(16))) uint8_t inw[INWIN + 16];
+    constexpr uint32_t kJt = RING + INWIN + 16;  // j table: jt[18 * o + lane] = lane mod o (o = 1..17), lane (o = 18), lane < 18
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kJt + 19 * 18 + 2];  // the kernel's only LDS object: offset 0
+    uint8_t* const ring = lds;
+    uint8_t* const inw = lds + RING;
+    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)));  // LDS byte address
     const GpuBlock b = blocks[blockIdx.x];
     const uint8_t* src = comp + b.src_off;
     uint8_t* dst = out + b.dst_off;
     const uint32_t iend = b.src_len, oend = b.dst_len;
     const uint32_t lane = threadIdx.x;
     uint32_t ip = 0, op = 0, in_base = 0, in_valid = 0, flushed = 0;
-    uint32_t err = 0, nseq = 0, nfar = 0;
+    uint32_t err = ring_lds ? 7u : 0u, nseq = 0, nfar = 0;  // the hand-scheduled copy loop takes ring offsets as LDS addresses
+    // PROF: wave cycles per phase (s_memtime), summed over all waves into tally[2..]
+    unsigned long long t_lit = 0, n_lit = 0, t_copy = 0, t_far = 0, t_slow = 0, t_flush = 0, t_cover = 0, t_parse = 0, n_batch = 0, n_slow = 0, t_mark = 0;
+    auto tick = [&]() { if (PROF) t_mark = __builtin_readcyclecounter(); };
+    auto tock = [&](unsigned long long& acc) { if (PROF) { const unsigned long long now = __builtin_readcyclecounter(); acc += now - t_mark; t_mark = now; } };
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    if (threadIdx.x < 18u) {
+        for (uint32_t o = 0; o <= 18u; ++o) lds[kJt + 18u * o + threadIdx.x] = static_cast<uint8_t>(o == 0u ? 0u : (o == 18u ? threadIdx.x : threadIdx.x % o));
+    }
+    const uint32_t magic = lane ? 65535u / lane + 1u : 0u;  // ceil(2^16 / lane): (j * magic) >> 16 == j / lane for j < 64
 
     // make inw[] cover [ip, ip + need) (need <= 80) unless the block ends first
     auto cover = [&](uint32_t need) {
@@ -90,8 +102,226 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
         }
     };
 
-    while (ip < iend) {
+    while (ip < iend && !err) {
+        // ---- fast path: batches of up to 16 "bare" sequences -- no literals, match of 4..18 bytes -- which is 95 % of an
+        // LZ4-fast FLAG stream.  A bare sequence is exactly 3 input bytes, so lanes 0..15 parse 16 of them AT ONCE (one
+        // unaligned LDS read each), a 16-lane prefix sum of the match lengths gives every sequence its output position,
+        // and one ballot says how many leading sequences of the batch are bare and valid.  Only the copies themselves
+        // run in order, one per step, steered by scalars read out of the parsed lanes; a match behind the ring reads the
+        // flushed output (RING - 64 > kFlush + 16 * 18: that source always lies below `flushed`).
+        for (;;) {
+            tick();
+            cover(64);
+            tock(t_cover);
+            const uint32_t in_limit = in_base + in_valid;
+            const uint32_t pos = ip + 3u * lane;
+            bool ok = lane < 16u && pos + 3u <= in_limit;
+            uint32_t w = 0xFFu;
+            if (ok) __builtin_memcpy(&w, &inw[pos - in_base], 4);               // token, offset lo, offset hi, (next token)
+            const uint32_t tok = w & 255u, offk = (w >> 8) & 0xFFFFu, mlk = tok + 4u;
+            uint32_t incl = ok ? mlk : 0u;
+            incl += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(incl), 0x111, 0xF, 0xF, false));  // row_shr:1
+            incl += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(incl), 0x112, 0xF, 0xF, false));  // row_shr:2
+            incl += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(incl), 0x114, 0xF, 0xF, false));  // row_shr:4
+            incl += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(incl), 0x118, 0xF, 0xF, false));  // row_shr:8
+            const uint32_t opk = op + incl - mlk;                                // where sequence k writes (if all before it are bare)
+            ok = ok && tok < 15u && offk != 0u && offk <= opk && opk + mlk <= oend;
+            const uint64_t bad = __builtin_amdgcn_ballot_w64(!ok);               // lanes >= 16 are never ok: bad != 0
+            const uint32_t nb = static_cast<uint32_t>(__builtin_ctzll(bad));     // leading bare sequences of this batch, 0..16
+            const uint32_t packed = offk | (mlk << 16);
+            // The copies, one per step and in order.  The next sequence's scalars (offset, length, lane -> source index)
+            // are prepared while this one's LDS read is in flight.  j = lane mod off through the 16-bit reciprocal of
+            // off (off < 64; a longer period never wraps inside 18 bytes: reciprocal 0).
+            auto unpack = [&](uint32_t k, uint32_t& off, uint32_t& ml, uint32_t& j) {
+                const uint32_t p = __builtin_amdgcn_readlane(packed, k);
+                off = p & 0xFFFFu;
+                ml = p >> 16;
+                uint32_t m = __builtin_amdgcn_readlane(magic, off & 63u);
+                if (off >= 64u) m = 0;
+                j = lane - __umul24(__umul24(lane, m) >> 16, off);
+            };
+            ++n_batch;
+            tock(t_parse);
+            uint64_t farm = __builtin_amdgcn_ballot_w64(offk > RING - 64u) & ((1ull << nb) - 1ull);  // bare, but behind the ring
+            uint32_t k = 0;
+            // Hand-scheduled copy loop (the decoder is issue-bound, so every instruction per sequence counts): 6 vector, 6
+            // scalar and 3 LDS instructions per sequence.  What a sequence needs was computed for all 16 at once above --
+            // A = ring offset of the source, B = of the destination, T = row of the j table (lane -> lane mod off), G =
+            // source offset in the flushed output for a match behind the ring -- and is read out of lane k as scalars
+            // that feed vector adds directly.  Lanes 0..17 copy whatever the match length: the bytes past it are not
+            // yet valid output, the next sequence overwrites them (and 18 < 64 keeps the ring's oldest valid source
+            // clear of them).  The j row of sequence k + 2 is fetched while sequence k's byte is in flight, so the only
+            // wait of a step is for that byte.  Batches where a source or destination would wrap around the end of the
+            // ring (1 in ~20) take the masked loop below instead.
+            const uint32_t Avec = (opk - offk) & kRingMask, Bvec = opk & kRingMask, Gvec = opk - offk;
+            const uint32_t Tvec = kJt + 18u * (offk < 18u ? offk : 18u);
+            const uint64_t wraps = __builtin_amdgcn_ballot_w64(Avec > RING - 18u || Bvec > RING - 18u) & ((1ull << nb) - 1ull);
+            if (nb && !wraps) {
+                uint32_t d, jA, jB, la, ra, wa, wb, g, sT, sA, sB, sG, kk, k2;
+                const uint32_t farm32 = static_cast<uint32_t>(farm);
+#define LZ_STEP(JNEW, JUSE, WCUR, WNEXT, FARLABEL, BACKLABEL)                  \
+    "ds_read_u8 %[d], %[ra]\n\t"                                              \
+    "s_add_u32 %[k2], %[kk], 2\n\t"                                           \
+    "s_bitcmp1_b32 %[farm], %[kk]\n\t"                                        \
+    "v_readlane_b32 %[sT], %[T], %[k2]\n\t"                                   \
+    "s_cbranch_scc1 " FARLABEL "f\n"                                           \
+    BACKLABEL ":\n\t"                                                         \
+    "s_add_u32 %[kk], %[kk], 1\n\t"                                           \
+    "v_add_u32 %[la], %[sT], %[lane]\n\t"                                     \
+    "ds_read_u8 " JNEW ", %[la]\n\t"                                          \
+    "v_readlane_b32 %[sA], %[A], %[kk]\n\t"                                   \
+    "v_readlane_b32 %[sB], %[B], %[kk]\n\t"                                   \
+    "s_cmp_lt_u32 %[kk], %[nb]\n\t"                                           \
+    "s_waitcnt lgkmcnt(2)\n\t"                                                \
+    "v_add_u32 %[ra], %[sA], " JUSE "\n\t"                                    \
+    "v_add_u32 " WNEXT ", %[sB], %[lane]\n\t"                                 \
+    "s_waitcnt lgkmcnt(1)\n\t"                                                \
+    "ds_write_b8 " WCUR ", %[d]\n\t"                                          \
+    "s_cbranch_scc0 9f\n\t"
+#define LZ_FAR(FARLABEL, BACKLABEL)                                           \
+    FARLABEL ":\n\t"                                                          \
+    "v_readlane_b32 %[sG], %[G], %[kk]\n\t"                                   \
+    "s_nop 0\n\t"                                                             \
+    "v_add_u32 %[g], %[sG], %[lane]\n\t"                                      \
+    "global_load_ubyte %[g], %[g], %[dst] sc1\n\t"                            \
+    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                       \
+    "v_mov_b32 %[d], %[g]\n\t"                                                \
+    "s_branch " BACKLABEL "b\n"
+                asm volatile(
+                    "s_mov_b64 exec, 0x3ffff\n\t"
+                    "v_readlane_b32 %[sT], %[T], 0\n\t"
+                    "v_readlane_b32 %[sA], %[A], 0\n\t"
+                    "v_readlane_b32 %[sB], %[B], 0\n\t"
+                    "v_add_u32 %[la], %[sT], %[lane]\n\t"
+                    "ds_read_u8 %[jA], %[la]\n\t"
+                    "v_readlane_b32 %[sT], %[T], 1\n\t"
+                    "s_mov_b32 %[kk], 0\n\t"
+                    "v_add_u32 %[la], %[sT], %[lane]\n\t"
+                    "ds_read_u8 %[jB], %[la]\n\t"
+                    "v_add_u32 %[wa], %[sB], %[lane]\n\t"
+                    "s_waitcnt lgkmcnt(1)\n\t"
+                    "v_add_u32 %[ra], %[sA], %[jA]\n"
+                    "1:\n\t"
+                    LZ_STEP("%[jA]", "%[jB]", "%[wa]", "%[wb]", "3", "2")
+                    LZ_STEP("%[jB]", "%[jA]", "%[wb]", "%[wa]", "5", "4")
+                    "s_branch 1b\n"
+                    LZ_FAR("3", "2")
+                    LZ_FAR("5", "4")
+                    "9:\n\t"
+                    "s_waitcnt lgkmcnt(0)\n\t"
+                    "s_mov_b64 exec, -1"
+                    : [d] "=&v"(d), [jA] "=&v"(jA), [jB] "=&v"(jB), [la] "=&v"(la), [ra] "=&v"(ra), [wa] "=&v"(wa), [wb] "=&v"(wb), [g] "=&v"(g),
+                      [sT] "=&s"(sT), [sA] "=&s"(sA), [sB] "=&s"(sB), [sG] "=&s"(sG), [kk] "=&s"(kk), [k2] "=&s"(k2)
+                    : [T] "v"(Tvec), [A] "v"(Avec), [B] "v"(Bvec), [G] "v"(Gvec), [lane] "v"(lane), [farm] "s"(farm32), [nb] "s"(nb),
+                      [dst] "s"(dst)
+                    : "memory", "scc");
+#undef LZ_STEP
+#undef LZ_FAR
+                op += __builtin_amdgcn_readlane(incl, nb - 1u);
+                nfar += static_cast<uint32_t>(__builtin_popcountll(farm));
+                k = nb;
+                tock(t_copy);
+            }
+            while (k < nb) {
+                const uint32_t kend = farm ? static_cast<uint32_t>(__builtin_ctzll(farm)) : nb;
+                if (k < kend) {
+                    // Near run [k, kend): one hand-scheduled step per sequence.  The LDS read of sequence k is issued, the
+                    // scalars and addresses of sequence k + 1 are computed while it is in flight, then the write of k;
+                    // the next read follows the write without a wait (one wave's LDS operations execute in order).
+                    uint32_t off, ml, j;
+                    unpack(k, off, ml, j);
+                    uint32_t ra = (op - off + j) & kRingMask;  // (ring_lds == 0, checked at the top)
+                    uint32_t wa = (op + lane) & kRingMask;
+                    uint64_t mask = __builtin_amdgcn_ballot_w64(lane < ml);
+                    for (; k < kend; ++k) {
+                        uint32_t d, pos, t, sp, soff, sm;
+                        uint64_t maskn;
+                        const uint32_t k1 = (k + 1u) & 15u;  // (past the end of the run: parsed but unused)
+                        asm volatile(
+                            "s_mov_b64 exec, %[mask]\n\t"
+                            "ds_read_u8 %[d], %[ra]\n\t"
+                            "s_mov_b64 exec, -1\n\t"
+                            "v_readlane_b32 %[sp], %[packed], %[k1]\n\t"
+                            "s_add_u32 %[op], %[op], %[ml]\n\t"
+                            "v_add_u32 %[pos], %[op], %[lane]\n\t"
+                            "s_and_b32 %[soff], %[sp], 0xffff\n\t"
+                            "s_lshr_b32 %[ml], %[sp], 16\n\t"
+                            "s_nop 1\n\t"
+                            "v_readlane_b32 %[sm], %[magic], %[sp]\n\t"
+                            "v_cmp_gt_u32 %[maskn], %[ml], %[lane]\n\t"
+                            "s_cmp_lt_u32 %[soff], 64\n\t"
+                            "s_cselect_b32 %[sm], %[sm], 0\n\t"
+                            "v_mul_u32_u24 %[t], %[sm], %[lane]\n\t"
+                            "v_lshrrev_b32 %[t], 16, %[t]\n\t"
+                            "v_mad_u32_u24 %[t], %[t], %[soff], %[soff]\n\t"
+                            "v_sub_u32 %[ra], %[pos], %[t]\n\t"
+                            "v_and_b32 %[ra], %[rmask], %[ra]\n\t"
+                            "s_waitcnt lgkmcnt(0)\n\t"
+                            "s_mov_b64 exec, %[mask]\n\t"
+                            "ds_write_b8 %[wa], %[d]\n\t"
+                            "s_mov_b64 exec, -1\n\t"
+                            "s_mov_b64 %[mask], %[maskn]\n\t"
+                            "v_and_b32 %[wa], %[rmask], %[pos]"
+                            : [d] "=&v"(d), [pos] "=&v"(pos), [t] "=&v"(t), [sp] "=&s"(sp), [soff] "=&s"(soff), [sm] "=&s"(sm),
+                              [maskn] "=&s"(maskn), [ra] "+v"(ra), [wa] "+v"(wa), [mask] "+s"(mask), [op] "+s"(op), [ml] "+s"(ml)
+                            : [packed] "v"(packed), [magic] "v"(magic), [lane] "v"(lane), [k1] "s"(k1), [rmask] "n"(kRingMask)
+                            : "memory", "scc");
+                    }
+                }
+                tock(t_copy);
+                if (k < nb) {
+                    // sequence k reaches behind the ring: its source was flushed long ago; device-scope load, past the L1
+                    const uint32_t p = __builtin_amdgcn_readlane(packed, k);
+                    const uint32_t off = p & 0xFFFFu, ml = p >> 16;
+                    if (lane < ml)
+                        ring[(op + lane) & kRingMask] = __hip_atomic_load(&dst[op - off + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    op += ml;
+                    ++nfar;
+                    ++k;
+                    farm &= farm - 1ull;
+                    if (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    tock(t_far);
+                }
+            }
+            ip += 3u * nb;
+            nseq += nb;
+            flush_to(op);
+            tock(t_flush);
+            if (nb == 16u) continue;
+            // The sequence that ended the batch.  The usual one has 1..14 literals and a short match: its token is
+            // already here (lane nb's word), ONE LDS read brings the literals and the offset behind them into lanes, the
+            // literals go from those lanes to the ring, then the match as above.  Everything else -- long literal runs,
+            // long matches, the end of the block or of the staged window -- goes to the general code below.
+            const uint32_t tq = __builtin_amdgcn_readlane(w, nb) & 255u;        // (0xFF when lane nb had nothing to read)
+            const uint32_t ll = tq >> 4, mq = (tq & 15u) + 4u;
+            if (ll == 0u || ll == 15u || mq == 19u || ip + 3u + ll > in_limit || ll + mq > oend - op) break;
+            uint32_t lb = 0;
+            if (lane < ll + 2u) lb = inw[ip + 1u + lane - in_base];
+            const uint32_t offq = __builtin_amdgcn_readlane(lb, ll) | (__builtin_amdgcn_readlane(lb, ll + 1u) << 8);
+            if (lane < ll) ring[(op + lane) & kRingMask] = static_cast<uint8_t>(lb);
+            op += ll;
+            if (offq == 0u || offq > op) { err = 5; break; }
+            if (offq <= RING - 64u) {
+                uint32_t m = __builtin_amdgcn_readlane(magic, offq & 63u);
+                if (offq >= 64u) m = 0;
+                const uint32_t jq = lane - __umul24(__umul24(lane, m) >> 16, offq);
+                if (lane < mq) ring[(op + lane) & kRingMask] = ring[(op - offq + jq) & kRingMask];
+            } else {
+                ++nfar;
+                if (lane < mq)
+                    ring[(op + lane) & kRingMask] = __hip_atomic_load(&dst[op - offq + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+            op += mq;
+            ip += 3u + ll;
+            ++nseq;
+            ++n_lit;
+            flush_to(op);
+            tock(t_lit);
+        }
+        if (ip >= iend) break;
         cover(24);
+        tick();
+        ++n_slow;
         const uint32_t t3 = in_3bytes(ip);
         const uint32_t token = t3 & 255u;
         ++ip;
@@ -164,6 +394,7 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
             ml -= n;
             flush_to(op);
         }
+        tock(t_slow);
     }
     if (!err && op != oend) err = 6;
     // tail of the ring.  An odd trailing byte of a block is dropped like the reference's N = size >> 1
@@ -175,6 +406,19 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
         status[blockIdx.x] = err;
         atomicAdd(&tally[0], static_cast<unsigned long long>(nseq));
         atomicAdd(&tally[1], static_cast<unsigned long long>(nfar));
+        if (PROF) {
+            atomicAdd(&tally[2], t_copy);
+            atomicAdd(&tally[3], t_far);
+            atomicAdd(&tally[4], t_slow);
+            atomicAdd(&tally[5], t_flush);
+            atomicAdd(&tally[6], t_cover);
+            atomicAdd(&tally[7], t_parse);
+            atomicAdd(&tally[8], n_batch);
+            atomicAdd(&tally[9], n_slow);
+            atomicAdd(&tally[10], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
+            atomicAdd(&tally[11], t_lit);
+            atomicAdd(&tally[12], n_lit);
+        }
     }
 }
 
@@ -213,6 +457,8 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     uint32_t* d_status = nullptr;
     unsigned long long* d_tally = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t landed[64] = {}, joined[8] = {};
+    hipStream_t dec_stream[8] = {};
     int rc = 0;
     auto cleanup = [&] {
         (void)hipStreamSynchronize(e.stream[0]);
@@ -221,7 +467,16 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
         if (d_blocks) (void)hipFree(d_blocks);
         if (d_status) (void)hipFree(d_status);
         if (d_tally) (void)hipFree(d_tally);
+        for (hipStream_t x : dec_stream)
+            if (x) {
+                (void)hipStreamSynchronize(x);
+                (void)hipStreamDestroy(x);
+            }
         for (hipEvent_t x : ev)
+            if (x) (void)hipEventDestroy(x);
+        for (hipEvent_t x : landed)
+            if (x) (void)hipEventDestroy(x);
+        for (hipEvent_t x : joined)
             if (x) (void)hipEventDestroy(x);
     };
 #define LZG_TRY(expr)                            \
@@ -235,29 +490,74 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     } while (0)
     hipStream_t s = e.stream[0];
     for (hipEvent_t& x : ev) LZG_TRY(hipEventCreate(&x));
+    for (hipEvent_t& x : joined) LZG_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
     LZG_TRY(hipMalloc(&d_comp, bytes + 64));
     LZG_TRY(hipMalloc(&d_out, dpos + 16));
     LZG_TRY(hipMalloc(&d_blocks, blocks.size() * sizeof(fsk::GpuBlock)));
     LZG_TRY(hipMalloc(&d_status, blocks.size() * sizeof(uint32_t)));
     LZG_TRY(hipMemsetAsync(d_out, 0, dpos + 16, s));            // padding between blocks counts nothing
     LZG_TRY(hipMemsetAsync(d_status, 0xFF, blocks.size() * sizeof(uint32_t), s));
-    LZG_TRY(hipMalloc(&d_tally, 16));
-    LZG_TRY(hipMemsetAsync(d_tally, 0, 16, s));
+    LZG_TRY(hipMalloc(&d_tally, 16 * 8));
+    LZG_TRY(hipMemsetAsync(d_tally, 0, 16 * 8, s));
     LZG_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(fsk::GpuBlock), hipMemcpyHostToDevice, s));
-    LZG_TRY(hipEventRecord(ev[0], s));
-    LZG_TRY(hipMemcpyAsync(d_comp, image, bytes, hipMemcpyHostToDevice, s));
-    LZG_TRY(hipEventRecord(ev[1], s));
-    // env FLAGSTATS_HIP_GPU_LZ4_RING = 16 (default) | 8: KiB of recent output per wave in LDS (see lz4_decode_wave)
+    // env FLAGSTATS_HIP_GPU_LZ4_RING = 8 (default) | 16: KiB of recent output per wave in LDS (see lz4_decode_wave)
     const char* rk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_RING");
-    const bool small_ring = rk && std::atoi(rk) == 8;
-    if (small_ring)
-        hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024>), dim3(static_cast<uint32_t>(blocks.size())), dim3(64), 0, s, d_comp,
-                           d_blocks, d_out, d_status, d_tally);
-    else
-        hipLaunchKernelGGL((fsk::lz4_decode_wave<16384, 4096>), dim3(static_cast<uint32_t>(blocks.size())), dim3(64), 0, s, d_comp,
-                           d_blocks, d_out, d_status, d_tally);
-    LZG_TRY(hipGetLastError());
-    LZG_TRY(hipEventRecord(ev[2], s));
+    const bool big_ring = rk && std::atoi(rk) == 16;
+    const char* pk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");  // tuning: per-phase wave cycles on stderr
+    const bool prof = pk && std::atoi(pk) != 0;
+    // The image goes over PCIe in `nchunks` pieces (whole blocks) on the copy stream; each piece's blocks are decoded by
+    // their own launch on one of `nstreams` decode streams as soon as the piece has landed, so all but the last piece's
+    // decode hides behind the copies.  env FLAGSTATS_HIP_GPU_LZ4_CHUNKS (default 8; 1 = copy everything, then decode),
+    // FLAGSTATS_HIP_GPU_LZ4_STREAMS (default 4).
+    const char* ck = std::getenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS");
+    const char* sk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_STREAMS");
+    uint32_t nchunks = ck ? static_cast<uint32_t>(std::atoi(ck)) : 8u;
+    uint32_t nstreams = sk ? static_cast<uint32_t>(std::atoi(sk)) : 4u;
+    if (nchunks < 1) nchunks = 1;
+    if (nchunks > 64) nchunks = 64;
+    if (nchunks > blocks.size()) nchunks = static_cast<uint32_t>(blocks.size());
+    if (nstreams < 1) nstreams = 1;
+    if (nstreams > 8) nstreams = 8;
+    if (nstreams > nchunks) nstreams = nchunks;
+    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamCreateWithFlags(&dec_stream[i], hipStreamNonBlocking));
+    for (uint32_t i = 0; i < nchunks; ++i) LZG_TRY(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming));
+    LZG_TRY(hipEventRecord(ev[0], s));
+    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamWaitEvent(dec_stream[i], ev[0], 0));  // buffers zeroed, index on the device
+    uint64_t first = 0;
+    for (uint32_t c = 0; c < nchunks; ++c) {
+        // piece c: blocks [first, last), split by compressed bytes
+        const uint64_t target = bytes / nchunks * (c + 1);
+        uint64_t last = first + 1;
+        while (last < blocks.size() && (c + 1 == nchunks || blocks[last].src_off + blocks[last].src_len <= target)) ++last;
+        if (c + 1 == nchunks) last = blocks.size();
+        const uint64_t lo = blocks[first].src_off - 8, hi = blocks[last - 1].src_off + blocks[last - 1].src_len;
+        LZG_TRY(hipMemcpyAsync(d_comp + lo, img + lo, hi - lo, hipMemcpyHostToDevice, s));
+        LZG_TRY(hipEventRecord(landed[c], s));
+        hipStream_t ds = dec_stream[c % nstreams];
+        LZG_TRY(hipStreamWaitEvent(ds, landed[c], 0));
+        const dim3 grid(static_cast<uint32_t>(last - first));
+        if (prof)
+            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 640, true>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
+                               d_status + first, d_tally);
+        else if (!big_ring)
+            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 640>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
+                               d_status + first, d_tally);
+        else
+            hipLaunchKernelGGL((fsk::lz4_decode_wave<16384, 4096>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
+                               d_status + first, d_tally);
+        LZG_TRY(hipGetLastError());
+        first = last;
+        if (first >= blocks.size()) {
+            nchunks = c + 1;
+            break;
+        }
+    }
+    LZG_TRY(hipEventRecord(ev[1], s));  // every piece has landed
+    for (uint32_t i = 0; i < nstreams; ++i) {
+        LZG_TRY(hipEventRecord(joined[i], dec_stream[i]));
+        LZG_TRY(hipStreamWaitEvent(s, joined[i], 0));
+    }
+    LZG_TRY(hipEventRecord(ev[2], s));  // ... and is decoded
     LZG_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), s));
     rc = fsint::count_device_async(e, reinterpret_cast<const uint16_t*>(d_out), dpos / 2, e.d_out[0], s, e.ws[0]);
     if (rc) {
@@ -266,17 +566,28 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     }
     LZG_TRY(hipEventRecord(ev[3], s));
     LZG_TRY(hipMemcpyAsync(e.h_out, e.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    unsigned long long tally[2] = {0, 0};
-    LZG_TRY(hipMemcpyAsync(tally, d_tally, 16, hipMemcpyDeviceToHost, s));
+    unsigned long long tally[16] = {0};
+    LZG_TRY(hipMemcpyAsync(tally, d_tally, sizeof tally, hipMemcpyDeviceToHost, s));
     std::vector<uint32_t> st(blocks.size());
     LZG_TRY(hipMemcpyAsync(st.data(), d_status, st.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LZG_TRY(hipStreamSynchronize(s));
     uint64_t bad = 0;
     for (uint32_t x : st) bad += x != 0;
-    float h2d = 0, dec = 0, cnt = 0;
+    float h2d = 0, dec = 0, cnt = 0, pipe = 0;
     LZG_TRY(hipEventElapsedTime(&h2d, ev[0], ev[1]));
     LZG_TRY(hipEventElapsedTime(&dec, ev[1], ev[2]));
     LZG_TRY(hipEventElapsedTime(&cnt, ev[2], ev[3]));
+    LZG_TRY(hipEventElapsedTime(&pipe, ev[0], ev[3]));
+    if (prof) {
+        int per_cu = 0;
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fsk::lz4_decode_wave<8192, 640, true>, 64, 0);
+        std::fprintf(stderr, "lz4 gpu profile: %d waves per CU fit\n", per_cu);
+        const double tot = static_cast<double>(tally[10]) + 1e-9;
+        std::fprintf(stderr, "lz4 gpu profile (ring 8 KiB): wave cycles %.3g | copy %.1f %% far %.1f %% lit %.1f %% slow %.1f %% flush %.1f %% cover %.1f %% parse %.1f %% | "
+                             "%llu batches (%.1f seq each), %llu short-literal + %llu slow sequences, %llu far\n",
+                     tot, 100 * tally[2] / tot, 100 * tally[3] / tot, 100 * tally[11] / tot, 100 * tally[4] / tot, 100 * tally[5] / tot, 100 * tally[6] / tot,
+                     100 * tally[7] / tot, tally[8], tally[8] ? static_cast<double>(tally[0] - tally[9] - tally[12]) / tally[8] : 0.0, tally[12], tally[9], tally[1]);
+    }
     if (stats) {
         stats->n_blocks = blocks.size();
         stats->n_flags = n_flags;
@@ -288,7 +599,9 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
         stats->count_ms = cnt;
         stats->sequences = tally[0];
         stats->far_matches = tally[1];
-        stats->ring_kib = small_ring ? 8 : 16;
+        stats->ring_kib = (!big_ring || prof) ? 8 : 16;
+        stats->chunks = nchunks;
+        stats->pipeline_ms = pipe;
     }
     if (!bad)
         for (int k = 0; k < 32; ++k) out[k] += e.h_out[k];

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--flags", type=int, default=2 ** 31)
     ap.add_argument("--modes", default="fast:2,hc:9")
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--configs", default="8/1/1,8/8/4", help="ring KiB / pieces / decode streams, comma separated")
+    ap.add_argument("--reps", type=int, default=3)
     args = ap.parse_args()
     import oracle
 
@@ -47,20 +49,23 @@ def main():
         print("LZ4-%s-%s image: %d flags, %d blocks, %d -> %d bytes (ratio %.2f), built in %.0f s"
               % (mode, level, n, nblocks, 2 * n, len(img), 2 * n / len(img), time.perf_counter() - t0), flush=True)
         buf = np.frombuffer(img, dtype=np.uint8)
-        for rep in range(6):
-            os.environ["FLAGSTATS_HIP_GPU_LZ4_RING"] = "16" if rep < 3 else "8"
-            out = np.zeros(32, dtype=np.uint64)
-            st = _lib.GpuLz4Stats()
-            t0 = time.perf_counter()
-            _lib.check(lib.FLAGSTATS_hip_blockimage_lz4_gpu(buf.ctypes.data, buf.size, out.ctypes.data, ctypes.byref(st)),
-                       "FLAGSTATS_hip_blockimage_lz4_gpu")
-            wall = time.perf_counter() - t0
-            assert np.array_equal(out, want), "GPU decode: counters differ from the oracle"
-            print("  GPU decode (ring %d KiB) rep %d: wall %.1f ms (incl. allocations) | H2D of the image %.1f ms, decode kernel %.1f ms "
-                  "(%.1f GB/s of output; %.1f M sequences, %.2f %% of the matches behind the ring), K1 %.2f ms  -> %.1f Gflags/s on "
-                  "H2D + decode + K1" % (st.ring_kib, rep, wall * 1e3, st.h2d_ms, st.decode_ms, st.decoded_bytes / st.decode_ms / 1e6,
-                                         st.sequences / 1e6, 100.0 * st.far_matches / max(1, st.sequences), st.count_ms,
-                                         n / (st.h2d_ms + st.decode_ms + st.count_ms) / 1e6), flush=True)
+        for ring, chunks, streams in [tuple(int(v) for v in c.split("/")) for c in args.configs.split(",")]:
+            os.environ["FLAGSTATS_HIP_GPU_LZ4_RING"] = str(ring)
+            os.environ["FLAGSTATS_HIP_GPU_LZ4_CHUNKS"] = str(chunks)
+            os.environ["FLAGSTATS_HIP_GPU_LZ4_STREAMS"] = str(streams)
+            for rep in range(args.reps):
+                out = np.zeros(32, dtype=np.uint64)
+                st = _lib.GpuLz4Stats()
+                t0 = time.perf_counter()
+                _lib.check(lib.FLAGSTATS_hip_blockimage_lz4_gpu(buf.ctypes.data, buf.size, out.ctypes.data, ctypes.byref(st)),
+                           "FLAGSTATS_hip_blockimage_lz4_gpu")
+                wall = time.perf_counter() - t0
+                assert np.array_equal(out, want), "GPU decode: counters differ from the oracle"
+                print("  GPU decode (ring %d KiB, %d pieces on %d streams) rep %d: wall %.1f ms (incl. allocations) | copies %.1f ms, decode "
+                      "after the last copy %.1f ms, K1 %.2f ms | %.1f M sequences, %.2f %% of the matches behind the ring -> pipeline "
+                      "%.1f ms = %.1f Gflags/s" % (st.ring_kib, st.chunks, streams, rep, wall * 1e3, st.h2d_ms, st.decode_ms, st.count_ms,
+                                                   st.sequences / 1e6, 100.0 * st.far_matches / max(1, st.sequences), st.pipeline_ms,
+                                                   n / st.pipeline_ms / 1e6), flush=True)
         for rep in range(3):
             got = np.zeros(32, dtype=np.uint64)
             hs = _lib.BlockfileStats()
