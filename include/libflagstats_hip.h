@@ -181,6 +181,10 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *                    at different steps, so HBM never idles for it chip-wide; 0 = all at the same step (r02)
  *   "fence_free_events" FLAGSTATS_hip_stream_wait_stream / the overlapped all-reduce: 1 = ordering events without the
  *                    system-scope fence (default 0)
+ *   "lz4_decoder"    LZ4 block files (FLAGSTATS_hip_blockfile*, blockimage_lz4): 0 = decode on host threads into pinned
+ *                    chunks (decoded flags cross PCIe), 1 = decode on the GPU (the compressed bytes cross PCIe, one wave
+ *                    per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default 1.5 GiB
+ *                    compressed: the measured break-even, profiles/r03/lz4_decoder_sweep.log), on the host below.  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
  * Read-only keys of FLAGSTATS_hip_get: "grid" (K1 workgroups), "numa_node" (of the default device),
  * "host_chunks" / "host_overlapped" (last multi-chunk host-pointer call on the default engine: chunks
  * submitted / chunks handed over while the previous chunk's copy + kernel were still in flight).
@@ -241,6 +245,10 @@ typedef struct FLAGSTATS_blockfile_stats {
     double wall_s, index_s, setup_s, decode_cpu_s; /* setup_s: index + buffers; decode_cpu_s: sum over threads */
     double wait_decode_s, wait_copy_s;             /* orchestrator: waiting for decoders / for H2D copies */
     int32_t threads, chunks;
+    int32_t gpu_decode, reserved;                  /* 1: the blocks were decoded on the GPU (knob "lz4_decoder"): threads =
+                                                      parallel file readers (0 in image mode), chunks = pieces copied,
+                                                      decode_cpu_s = 0, wait_copy_s = copies, wait_decode_s = decode left
+                                                      exposed after the last copy */
 } FLAGSTATS_blockfile_stats;
 int FLAGSTATS_hip_blockfile_lz4(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads, uint64_t* out,
@@ -273,6 +281,8 @@ typedef struct FLAGSTATS_gpu_lz4_stats {
     uint64_t chunks;                               /* pieces the image went over PCIe in (env FLAGSTATS_HIP_GPU_LZ4_CHUNKS) */
     double pipeline_ms;                            /* first copy .. counters done; with chunks > 1, h2d_ms = all copies and
                                                       decode_ms = the decode time left exposed after the last copy */
+    uint64_t uncompressed_bytes, readers;          /* sum of the blocks' declared sizes; file mode: parallel preads used */
+    double wall_s;                                 /* whole call: index, allocations, pipeline, results */
 } FLAGSTATS_gpu_lz4_stats;
 int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t bytes, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats);
 /* the host LZ4 *block* decoder used above (replaces the reference's call to liblz4's

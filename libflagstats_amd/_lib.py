@@ -24,7 +24,8 @@ class BlockfileStats(ctypes.Structure):
     _fields_ = [("n_flags", ctypes.c_uint64), ("n_blocks", ctypes.c_uint64), ("compressed_bytes", ctypes.c_uint64),
                 ("uncompressed_bytes", ctypes.c_uint64), ("wall_s", ctypes.c_double), ("index_s", ctypes.c_double),
                 ("setup_s", ctypes.c_double), ("decode_cpu_s", ctypes.c_double),
-                ("wait_decode_s", ctypes.c_double), ("wait_copy_s", ctypes.c_double), ("threads", ctypes.c_int32), ("chunks", ctypes.c_int32)]
+                ("wait_decode_s", ctypes.c_double), ("wait_copy_s", ctypes.c_double), ("threads", ctypes.c_int32), ("chunks", ctypes.c_int32),
+                ("gpu_decode", ctypes.c_int32), ("reserved", ctypes.c_int32)]
 
 
 class GpuLz4Stats(ctypes.Structure):
@@ -33,7 +34,8 @@ class GpuLz4Stats(ctypes.Structure):
                 ("compressed_bytes", ctypes.c_uint64), ("decoded_bytes", ctypes.c_uint64),
                 ("h2d_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("count_ms", ctypes.c_double),
                 ("sequences", ctypes.c_uint64), ("far_matches", ctypes.c_uint64), ("ring_kib", ctypes.c_uint64),
-                ("chunks", ctypes.c_uint64), ("pipeline_ms", ctypes.c_double)]
+                ("chunks", ctypes.c_uint64), ("pipeline_ms", ctypes.c_double),
+                ("uncompressed_bytes", ctypes.c_uint64), ("readers", ctypes.c_uint64), ("wall_s", ctypes.c_double)]
 
 
 # name -> (restype, argtypes); mirrors include/libflagstats_hip.h one to one

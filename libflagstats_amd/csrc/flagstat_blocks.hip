@@ -561,6 +561,45 @@ int pick_decoder(int codec, block_decode_fn* fn)
     return 0;
 }
 
+// LZ4 block files: knob "lz4_decoder" -- 0 host threads, 1 GPU, 2 (default) GPU from "lz4_gpu_min_bytes" compressed bytes up
+bool lz4_on_gpu(uint64_t bytes)
+{
+    const int mode = fsint::knobs().lz4_decoder.load();
+    return mode == 1 || (mode == 2 && bytes >= fsint::knobs().lz4_gpu_min_bytes.load());
+}
+
+int run_gpu_lz4(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, int threads, bool superset, uint64_t* out,
+                FLAGSTATS_blockfile_stats* st)
+{
+    std::lock_guard<std::mutex> lk(eng.mu);
+    if (fsint::engine_alive(eng)) return -1;
+    fsint::DeviceGuard guard(eng.device);
+    if (!guard.ok()) return -1;
+    fsint::Lz4GpuSource src;
+    src.img = img;
+    src.fd = fd;
+    src.bytes = bytes;
+    src.superset = superset;
+    src.threads = threads;
+    FLAGSTATS_gpu_lz4_stats g;
+    const int rc = fsint::lz4_gpu_run(eng, src, out, &g);
+    if (rc) return rc;
+    if (st) {
+        *st = FLAGSTATS_blockfile_stats{};
+        st->n_flags = g.n_flags;
+        st->n_blocks = g.n_blocks;
+        st->compressed_bytes = bytes;
+        st->uncompressed_bytes = g.uncompressed_bytes;
+        st->wall_s = g.wall_s;
+        st->wait_copy_s = g.h2d_ms * 1e-3;
+        st->wait_decode_s = g.decode_ms * 1e-3;
+        st->threads = static_cast<int32_t>(g.readers);
+        st->chunks = static_cast<int32_t>(g.chunks);
+        st->gpu_decode = 1;
+    }
+    return 0;
+}
+
 int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec,
                bool superset = false)
 {
@@ -571,6 +610,8 @@ int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FL
     static const uint8_t empty = 0;
     fsint::Engine* eng = fsint::default_engine();
     if (!eng) return -1;
+    if (codec == 0 && lz4_on_gpu(bytes))
+        return run_gpu_lz4(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, superset, out, stats);
     Source in;
     in.img = image ? static_cast<const uint8_t*>(image) : &empty;
     in.bytes = bytes;
@@ -599,6 +640,12 @@ int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_
     // on the page cache of the r02 boxes -- populating and tearing down 490 k PTEs costs what the copy
     // costs (19-22 vs 24-26 Gflags/s, profiles/r02/blockfile_lz4_4GiB.log) -- so it is opt-in.
     const uint64_t bytes = static_cast<uint64_t>(sb.st_size);
+    if (codec == 0 && lz4_on_gpu(bytes)) {
+        fsint::Engine* eng = fsint::default_engine();
+        const int rc = eng ? run_gpu_lz4(*eng, nullptr, fd, bytes, threads, superset, out, stats) : -1;
+        close(fd);
+        return rc;
+    }
     const char* io = std::getenv("FLAGSTATS_HIP_BLOCK_IO");
     void* map = MAP_FAILED;
     if (bytes && io && !std::strcmp(io, "mmap")) map = mmap(nullptr, bytes, PROT_READ, MAP_SHARED, fd, 0);

@@ -195,6 +195,11 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
     } else if (!std::strcmp(key, "fence_free_events")) {
         if (value > 1) return fail_text("fence_free_events must be 0 or 1");
         k.fence_free_events = static_cast<int>(value);
+    } else if (!std::strcmp(key, "lz4_decoder")) {
+        if (value > 2) return fail_text("lz4_decoder must be 0 (host threads), 1 (GPU) or 2 (by file size)");
+        k.lz4_decoder = static_cast<int>(value);
+    } else if (!std::strcmp(key, "lz4_gpu_min_bytes")) {
+        k.lz4_gpu_min_bytes = value;
     } else if (!std::strcmp(key, "numa")) {
         if (value > 1) return fail_text("numa must be 0 or 1");
         k.numa = static_cast<int>(value);
@@ -231,6 +236,8 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "tuning_build")) return static_cast<uint64_t>(fsk_tuning_build());
     if (!std::strcmp(key, "on_error")) return static_cast<uint64_t>(k.on_error.load());
     if (!std::strcmp(key, "numa")) return static_cast<uint64_t>(k.numa.load());
+    if (!std::strcmp(key, "lz4_decoder")) return static_cast<uint64_t>(k.lz4_decoder.load());
+    if (!std::strcmp(key, "lz4_gpu_min_bytes")) return k.lz4_gpu_min_bytes.load();
     if (!std::strcmp(key, "fence_free_events")) return static_cast<uint64_t>(k.fence_free_events.load());
     if (!std::strcmp(key, "grid")) {
         if (fsint::default_device() < 0) return 0;

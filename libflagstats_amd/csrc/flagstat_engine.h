@@ -19,6 +19,8 @@
 #include <mutex>
 #include <utility>
 
+struct FLAGSTATS_gpu_lz4_stats;
+
 namespace fsint {
 
 struct Workspace {
@@ -43,6 +45,8 @@ struct Knobs {
                                                   // out[] with atomics (one launch), 0 = partials + K2
     std::atomic<uint64_t> chunk_flags{32ull << 20};  // host streaming chunk: 32 Mi flags = 64 MiB
     std::atomic<int> on_error{1};                 // legacy uint32 entry points: 1 = abort after the message, 0 = return non-zero
+    std::atomic<int> lz4_decoder{2};              // LZ4 block files: 0 = decode on host threads, 1 = on the GPU, 2 = by size
+    std::atomic<uint64_t> lz4_gpu_min_bytes{3ull << 29};  // lz4_decoder 2: GPU decode for files of at least this many bytes
     std::atomic<int> fence_free_events{0};        // stream_wait_stream: 1 = ordering events without the system-scope fence (opt-in)
     std::atomic<int> numa{1};                     // block pipeline: 1 = pinned chunks + decoders on the GPU's NUMA node
 };
@@ -147,6 +151,16 @@ int stage_reserve(Engine& e, int slot, uint64_t flags);   // e.mu held
 int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3]);  // e.mu held
 void* host_alloc_on_node(size_t bytes, int numa_node);   // pinned, pages placed on `numa_node` when >= 0
 uint64_t chunk_bytes();
+
+// LZ4 block file decoded on the GPU (flagstat_lz4_gpu.hip).  img != nullptr: whole file image in memory; else fd: file mode.
+struct Lz4GpuSource {
+    const uint8_t* img = nullptr;
+    int fd = -1;
+    uint64_t bytes = 0;
+    bool superset = false;
+    int threads = 0;        // file mode: parallel preads (<= 0: up to 16)
+};
+int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, struct ::FLAGSTATS_gpu_lz4_stats* stats);  // e.mu held, device current
 
 }  // namespace fsint
 

@@ -20,6 +20,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <atomic>
+#include <chrono>
+#include <thread>
+#include <unistd.h>
 
 #include "../../include/libflagstats_hip.h"
 #include "flagstat_engine.h"
@@ -424,32 +428,48 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
 
 }  // namespace fsk
 
-extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t bytes, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
+namespace fsint {
+
+// LZ4 block file, decoded ON the GPU.  The compressed bytes cross PCIe (2-3x fewer than the decoded flags the host pipeline
+// sends), in `pieces` of whole blocks on the engine's copy stream; every piece's blocks are decoded by their own launch of
+// lz4_decode_wave (one wave per block) on a decode stream of its own as soon as the piece has landed, so all but the last
+// piece's decode hides behind the copies; one K1/K2 pass then counts the whole decoded buffer.  Image mode copies
+// straight out of the caller's memory; file mode reads the file with `threads` parallel preads into the engine's three
+// pinned chunk buffers and copies from there.  e.mu must be held.
+int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
 {
-    using fsint::fail_hip;
-    using fsint::fail_text;
-    if (!image || !out) return fail_text("NULL image or out");
-    fsint::Engine* ep = fsint::default_engine();
-    if (!ep) return -1;
-    fsint::Engine& e = *ep;
-    std::lock_guard<std::mutex> lk(e.mu);
-    if (fsint::engine_alive(e)) return -1;
-    fsint::DeviceGuard guard(e.device);
-    if (!guard.ok()) return -1;
+    const auto t_start = std::chrono::steady_clock::now();
+    const uint8_t* img = in.img;
+    const uint64_t bytes = in.bytes;
     // index: int32 uncompressed size, int32 compressed size, payload (benchmark/flagstats.cpp:119-138)
-    const uint8_t* img = static_cast<const uint8_t*>(image);
     std::vector<fsk::GpuBlock> blocks;
-    uint64_t pos = 0, dpos = 0, n_flags = 0;
+    uint64_t pos = 0, dpos = 0, n_flags = 0, usum = 0;
     while (pos < bytes) {
-        if (bytes - pos < 8) return fail_text("block image: truncated block header");
+        if (bytes - pos < 8) return fail_text("block file: truncated block header");
         int32_t us, cs;
-        std::memcpy(&us, img + pos, 4);
-        std::memcpy(&cs, img + pos + 4, 4);
-        if (us < 0 || cs < 0 || static_cast<uint64_t>(cs) > bytes - pos - 8) return fail_text("block image: bad block header");
+        uint8_t hdr[8];
+        if (img) {
+            std::memcpy(hdr, img + pos, 8);
+        } else if (pread(in.fd, hdr, 8, static_cast<off_t>(pos)) != 8) {
+            return fail_text("block file: cannot read block header");
+        }
+        std::memcpy(&us, hdr, 4);
+        std::memcpy(&cs, hdr + 4, 4);
+        if (us < 0 || cs < 0) return fail_text("block file: negative size in block header");
+        if (static_cast<uint64_t>(cs) > bytes - pos - 8) return fail_text("block file: block payload runs past end of file");
         blocks.push_back(fsk::GpuBlock{pos + 8, dpos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us)});
-        n_flags += static_cast<uint64_t>(us) >> 1;
+        n_flags += static_cast<uint64_t>(us) >> 1;  // as benchmark/flagstats.cpp:323
+        usum += static_cast<uint64_t>(us);
         dpos += (static_cast<uint64_t>(us) + 15) & ~15ull;
         pos += 8 + static_cast<uint64_t>(cs);
+    }
+    if (stats) {
+        *stats = FLAGSTATS_gpu_lz4_stats{};
+        stats->n_blocks = blocks.size();
+        stats->n_flags = n_flags;
+        stats->compressed_bytes = bytes;
+        stats->decoded_bytes = dpos;
+        stats->uncompressed_bytes = usum;
     }
     if (blocks.empty()) return 0;
     uint8_t *d_comp = nullptr, *d_out = nullptr;
@@ -457,26 +477,28 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     uint32_t* d_status = nullptr;
     unsigned long long* d_tally = nullptr;
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t landed[64] = {}, joined[8] = {};
+    hipEvent_t landed[8] = {}, joined[8] = {}, pin_free[3] = {};
     hipStream_t dec_stream[8] = {};
     int rc = 0;
     auto cleanup = [&] {
         (void)hipStreamSynchronize(e.stream[0]);
-        if (d_comp) (void)hipFree(d_comp);
-        if (d_out) (void)hipFree(d_out);
-        if (d_blocks) (void)hipFree(d_blocks);
-        if (d_status) (void)hipFree(d_status);
-        if (d_tally) (void)hipFree(d_tally);
         for (hipStream_t x : dec_stream)
             if (x) {
                 (void)hipStreamSynchronize(x);
                 (void)hipStreamDestroy(x);
             }
+        if (d_comp) (void)hipFree(d_comp);
+        if (d_out) (void)hipFree(d_out);
+        if (d_blocks) (void)hipFree(d_blocks);
+        if (d_status) (void)hipFree(d_status);
+        if (d_tally) (void)hipFree(d_tally);
         for (hipEvent_t x : ev)
             if (x) (void)hipEventDestroy(x);
         for (hipEvent_t x : landed)
             if (x) (void)hipEventDestroy(x);
         for (hipEvent_t x : joined)
+            if (x) (void)hipEventDestroy(x);
+        for (hipEvent_t x : pin_free)
             if (x) (void)hipEventDestroy(x);
     };
 #define LZG_TRY(expr)                            \
@@ -490,14 +512,17 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     } while (0)
     hipStream_t s = e.stream[0];
     for (hipEvent_t& x : ev) LZG_TRY(hipEventCreate(&x));
-    for (hipEvent_t& x : joined) LZG_TRY(hipEventCreateWithFlags(&x, hipEventDisableTiming));
     LZG_TRY(hipMalloc(&d_comp, bytes + 64));
     LZG_TRY(hipMalloc(&d_out, dpos + 16));
     LZG_TRY(hipMalloc(&d_blocks, blocks.size() * sizeof(fsk::GpuBlock)));
     LZG_TRY(hipMalloc(&d_status, blocks.size() * sizeof(uint32_t)));
-    LZG_TRY(hipMemsetAsync(d_out, 0, dpos + 16, s));            // padding between blocks counts nothing
-    LZG_TRY(hipMemsetAsync(d_status, 0xFF, blocks.size() * sizeof(uint32_t), s));
     LZG_TRY(hipMalloc(&d_tally, 16 * 8));
+    // only the slack between blocks (16-byte slots) and behind dropped odd bytes needs zero flags: blocks of the reference's
+    // writer are whole multiples of 16 bytes, so this is normally nothing at all
+    bool ragged = false;
+    for (const fsk::GpuBlock& b : blocks) ragged = ragged || (b.dst_len & 15u);
+    if (ragged) LZG_TRY(hipMemsetAsync(d_out, 0, dpos + 16, s));
+    LZG_TRY(hipMemsetAsync(d_status, 0xFF, blocks.size() * sizeof(uint32_t), s));
     LZG_TRY(hipMemsetAsync(d_tally, 0, 16 * 8, s));
     LZG_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(fsk::GpuBlock), hipMemcpyHostToDevice, s));
     // env FLAGSTATS_HIP_GPU_LZ4_RING = 8 (default) | 16: KiB of recent output per wave in LDS (see lz4_decode_wave)
@@ -505,33 +530,96 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     const bool big_ring = rk && std::atoi(rk) == 16;
     const char* pk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");  // tuning: per-phase wave cycles on stderr
     const bool prof = pk && std::atoi(pk) != 0;
-    // The image goes over PCIe in `nchunks` pieces (whole blocks) on the copy stream; each piece's blocks are decoded by
-    // their own launch on one of `nstreams` decode streams as soon as the piece has landed, so all but the last piece's
-    // decode hides behind the copies.  env FLAGSTATS_HIP_GPU_LZ4_CHUNKS (default 8; 1 = copy everything, then decode),
-    // FLAGSTATS_HIP_GPU_LZ4_STREAMS (default 4).
+    // pieces: a decode launch lasts as long as its slowest block whatever its size (one wave decodes ~35 MB/s), and
+    // launches on one stream run one after the other -- so few, large pieces, each on a stream of its own.  Default:
+    // one piece per 1024 blocks, at most 4.  env FLAGSTATS_HIP_GPU_LZ4_CHUNKS / _STREAMS override (tuning).
     const char* ck = std::getenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS");
     const char* sk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_STREAMS");
-    uint32_t nchunks = ck ? static_cast<uint32_t>(std::atoi(ck)) : 8u;
-    uint32_t nstreams = sk ? static_cast<uint32_t>(std::atoi(sk)) : 4u;
-    if (nchunks < 1) nchunks = 1;
-    if (nchunks > 64) nchunks = 64;
-    if (nchunks > blocks.size()) nchunks = static_cast<uint32_t>(blocks.size());
+    uint32_t npieces = ck ? static_cast<uint32_t>(std::atoi(ck)) : static_cast<uint32_t>((blocks.size() + 1023) / 1024);
+    if (!ck && npieces > 4) npieces = 4;
+    if (npieces < 1) npieces = 1;
+    if (npieces > 8) npieces = 8;
+    if (npieces > blocks.size()) npieces = static_cast<uint32_t>(blocks.size());
+    uint32_t nstreams = sk ? static_cast<uint32_t>(std::atoi(sk)) : npieces;
     if (nstreams < 1) nstreams = 1;
-    if (nstreams > 8) nstreams = 8;
-    if (nstreams > nchunks) nstreams = nchunks;
+    if (nstreams > npieces) nstreams = npieces;
     for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamCreateWithFlags(&dec_stream[i], hipStreamNonBlocking));
-    for (uint32_t i = 0; i < nchunks; ++i) LZG_TRY(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming));
+    for (uint32_t i = 0; i < npieces; ++i) LZG_TRY(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming));
+    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipEventCreateWithFlags(&joined[i], hipEventDisableTiming));
+    // file mode: the engine's pinned chunk buffers, filled by parallel preads
+    uint8_t* pinned[3] = {nullptr, nullptr, nullptr};
+    uint64_t span_cap = 0;
+    int readers = 0;
+    if (!img) {
+        span_cap = (chunk_bytes() + 15) & ~15ull;
+        if (span_cap < (4ull << 20)) span_cap = 4ull << 20;
+        void* bufs[3];
+        rc = pinned_reserve(e, span_cap, bufs);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
+        for (int i = 0; i < 3; ++i) {
+            pinned[i] = static_cast<uint8_t*>(bufs[i]);
+            LZG_TRY(hipEventCreateWithFlags(&pin_free[i], hipEventDisableTiming | hipEventBlockingSync));
+        }
+        readers = in.threads > 0 ? in.threads : static_cast<int>(std::thread::hardware_concurrency());
+        if (readers > 16) readers = 16;
+        if (readers < 1) readers = 1;
+    }
+    uint64_t spans = 0;
+    // file bytes [lo, hi) -> d_comp[lo, hi)
+    auto send = [&](uint64_t lo, uint64_t hi) -> int {
+        if (img) {
+            hipError_t e_ = hipMemcpyAsync(d_comp + lo, img + lo, hi - lo, hipMemcpyHostToDevice, s);
+            return e_ == hipSuccess ? 0 : fail_hip("hipMemcpyAsync(block image piece)", e_);
+        }
+        for (uint64_t at = lo; at < hi; at += span_cap, ++spans) {
+            const uint64_t len = hi - at < span_cap ? hi - at : span_cap;
+            const int pb = static_cast<int>(spans % 3);
+            if (spans >= 3) {
+                hipError_t e_ = hipEventSynchronize(pin_free[pb]);  // the copy that last used this buffer has left the host
+                if (e_ != hipSuccess) return fail_hip("hipEventSynchronize(pinned span)", e_);
+            }
+            const uint64_t share = ((len + static_cast<uint64_t>(readers) - 1) / static_cast<uint64_t>(readers) + 4095) & ~4095ull;
+            std::atomic<int> failed{0};
+            auto read_share = [&](uint64_t o) {
+                uint64_t end = o + share < len ? o + share : len;
+                while (o < end) {
+                    const ssize_t r = pread(in.fd, pinned[pb] + o, end - o, static_cast<off_t>(at + o));
+                    if (r <= 0) {
+                        failed.store(1);
+                        return;
+                    }
+                    o += static_cast<uint64_t>(r);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (uint64_t o = share; o < len; o += share) pool.emplace_back(read_share, o);
+            read_share(0);
+            for (std::thread& t : pool) t.join();
+            if (failed.load()) return fail_text("block file: short read");
+            hipError_t e_ = hipMemcpyAsync(d_comp + at, pinned[pb], len, hipMemcpyHostToDevice, s);
+            if (e_ == hipSuccess) e_ = hipEventRecord(pin_free[pb], s);
+            if (e_ != hipSuccess) return fail_hip("hipMemcpyAsync(block file span)", e_);
+        }
+        return 0;
+    };
     LZG_TRY(hipEventRecord(ev[0], s));
-    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamWaitEvent(dec_stream[i], ev[0], 0));  // buffers zeroed, index on the device
+    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamWaitEvent(dec_stream[i], ev[0], 0));  // index on the device, status preset
     uint64_t first = 0;
-    for (uint32_t c = 0; c < nchunks; ++c) {
+    uint32_t pieces_done = 0;
+    for (uint32_t c = 0; c < npieces && first < blocks.size(); ++c) {
         // piece c: blocks [first, last), split by compressed bytes
-        const uint64_t target = bytes / nchunks * (c + 1);
+        const uint64_t target = bytes / npieces * (c + 1);
         uint64_t last = first + 1;
-        while (last < blocks.size() && (c + 1 == nchunks || blocks[last].src_off + blocks[last].src_len <= target)) ++last;
-        if (c + 1 == nchunks) last = blocks.size();
+        while (last < blocks.size() && (c + 1 == npieces || blocks[last].src_off + blocks[last].src_len <= target)) ++last;
         const uint64_t lo = blocks[first].src_off - 8, hi = blocks[last - 1].src_off + blocks[last - 1].src_len;
-        LZG_TRY(hipMemcpyAsync(d_comp + lo, img + lo, hi - lo, hipMemcpyHostToDevice, s));
+        rc = send(lo, hi);
+        if (rc) {
+            cleanup();
+            return rc;
+        }
         LZG_TRY(hipEventRecord(landed[c], s));
         hipStream_t ds = dec_stream[c % nstreams];
         LZG_TRY(hipStreamWaitEvent(ds, landed[c], 0));
@@ -547,10 +635,7 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
                                d_status + first, d_tally);
         LZG_TRY(hipGetLastError());
         first = last;
-        if (first >= blocks.size()) {
-            nchunks = c + 1;
-            break;
-        }
+        ++pieces_done;
     }
     LZG_TRY(hipEventRecord(ev[1], s));  // every piece has landed
     for (uint32_t i = 0; i < nstreams; ++i) {
@@ -559,7 +644,8 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     }
     LZG_TRY(hipEventRecord(ev[2], s));  // ... and is decoded
     LZG_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), s));
-    rc = fsint::count_device_async(e, reinterpret_cast<const uint16_t*>(d_out), dpos / 2, e.d_out[0], s, e.ws[0]);
+    rc = count_device_async(e, reinterpret_cast<const uint16_t*>(d_out), dpos / 2, e.d_out[0], s, e.ws[0],
+                            OP_FLAGSTAT | (in.superset ? OP_SUPERSET : 0));
     if (rc) {
         cleanup();
         return rc;
@@ -589,28 +675,49 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
                      100 * tally[7] / tot, tally[8], tally[8] ? static_cast<double>(tally[0] - tally[9] - tally[12]) / tally[8] : 0.0, tally[12], tally[9], tally[1]);
     }
     if (stats) {
-        stats->n_blocks = blocks.size();
-        stats->n_flags = n_flags;
         stats->bad_blocks = bad;
-        stats->compressed_bytes = bytes;
-        stats->decoded_bytes = dpos;
         stats->h2d_ms = h2d;
         stats->decode_ms = dec;
         stats->count_ms = cnt;
         stats->sequences = tally[0];
         stats->far_matches = tally[1];
         stats->ring_kib = (!big_ring || prof) ? 8 : 16;
-        stats->chunks = nchunks;
+        stats->chunks = pieces_done;
         stats->pipeline_ms = pipe;
+        stats->readers = static_cast<uint64_t>(readers);
+        stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     }
-    if (!bad)
+    if (!bad) {
+        if (in.superset) e.h_out[9] -= dpos / 2 - n_flags;  // zero flags in the slack between blocks are not reads (see run_pipeline)
         for (int k = 0; k < 32; ++k) out[k] += e.h_out[k];
+    }
     cleanup();
     if (bad) {
         char buf[128];
-        std::snprintf(buf, sizeof buf, "GPU LZ4 decode: %llu malformed block(s)", static_cast<unsigned long long>(bad));
+        std::snprintf(buf, sizeof buf, "block file: %llu block(s) failed to decode to their declared size (GPU LZ4 decoder)",
+                      static_cast<unsigned long long>(bad));
         return fail_text(buf);
     }
     return 0;
 #undef LZG_TRY
+}
+
+}  // namespace fsint
+
+extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t bytes, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
+{
+    if (!out) return fsint::fail_text("NULL out");
+    if (!image && bytes) return fsint::fail_text("NULL image");
+    fsint::Engine* ep = fsint::default_engine();
+    if (!ep) return -1;
+    fsint::Engine& e = *ep;
+    std::lock_guard<std::mutex> lk(e.mu);
+    if (fsint::engine_alive(e)) return -1;
+    fsint::DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    static const uint8_t empty = 0;
+    fsint::Lz4GpuSource src;
+    src.img = image ? static_cast<const uint8_t*>(image) : &empty;
+    src.bytes = bytes;
+    return fsint::lz4_gpu_run(e, src, out, stats);
 }

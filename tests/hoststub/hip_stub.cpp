@@ -19,6 +19,8 @@
 #include <thread>
 #include <vector>
 
+#include "../../include/libflagstats_hip.h"
+#include "../../libflagstats_amd/csrc/flagstat_engine.h"
 #include "../../libflagstats_amd/csrc/flagstat_kernels.h"
 
 extern "C" {
@@ -472,3 +474,9 @@ void fsk_set_group_min_grid(uint32_t) {}
 void fsk_set_epoch_stagger(int) {}
 
 }  // extern "C"
+
+// the GPU LZ4 decoder (flagstat_lz4_gpu.hip) is device code: not part of the host build; small files never reach it (knob "lz4_decoder")
+namespace fsint {
+int lz4_gpu_run(Engine&, const Lz4GpuSource&, uint64_t*, FLAGSTATS_gpu_lz4_stats*) { return fail_text("GPU LZ4 decoder: not in the host stub build"); }
+}  // namespace fsint
+

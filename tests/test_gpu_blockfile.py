@@ -116,7 +116,7 @@ def test_raw_file(hip, tmp_path, n, odd):
     assert np.array_equal(got, want) and st["n_flags"] == flags.size
 
 
-# --------------------------------------------------------------------------- the GPU-side LZ4 decode experiment
+# --------------------------------------------------------------------------- LZ4 blocks decoded on the GPU (knob "lz4_decoder")
 def gpu_decode(hip, img):
     import ctypes
 
@@ -180,6 +180,100 @@ def test_gpu_side_lz4_decode_rejects_damaged_blocks(hip):
         for _ in range(40):                                   # flip bytes inside the first block's payload
             bad[8 + int(rs.randint(0, 100000))] ^= int(rs.randint(1, 256))
         rc, got, st = gpu_decode(hip, bytes(bad))      # must return (a flip may even leave a valid stream); no fault, no hang
-        assert rc == 0 or b"malformed" in hip.FLAGSTATS_hip_last_error()
+        assert rc == 0 or b"failed to decode" in hip.FLAGSTATS_hip_last_error()
     rc, got, st = gpu_decode(hip, bytes(img))
     assert rc == 0 and np.array_equal(got, expect(flags, bt.BLOCK_BYTES)[0])
+
+
+@pytest.fixture
+def gpu_decoder(hip):
+    """knob lz4_decoder = 1: every LZ4 block file goes through the GPU decoder whatever its size (default 2: from 1.5 GiB)"""
+    assert hip.FLAGSTATS_hip_get(b"lz4_decoder") == 2 and hip.FLAGSTATS_hip_get(b"lz4_gpu_min_bytes") == 3 << 29
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
+    yield hip
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 2) == 0
+
+
+@pytest.mark.parametrize("case", ["na_ragged", "exact_multiple", "uniform_incompressible", "hc9", "tiny_odd_blocks", "three_spans"])
+def test_block_file_entries_with_the_gpu_decoder(gpu_decoder, tmp_path, case):
+    """The product entries (file, image, by-extension, superset) with the blocks decoded on the GPU: same counters as the
+    host-thread pipeline and the oracle; file mode reads with 1, 3 and the default number of parallel preads, through
+    more than three pinned spans in the last case."""
+    import oracle
+    from libflagstats_amd import blockfile
+    hip = gpu_decoder
+    kw = dict(block_bytes=bt.BLOCK_BYTES, mode="fast", level=2)
+    if case == "na_ragged":
+        flags = oracle.generate(oracle.GEN_NA12878, 11, 1, 0, 512000 * 3 + 12345)
+    elif case == "exact_multiple":
+        flags = oracle.generate(oracle.GEN_NA12878, 12, 0, 0, 512000 * 2)
+    elif case == "uniform_incompressible":
+        flags = oracle.generate(oracle.GEN_UNIFORM, 13, 0xFFFF, 0, 512000 * 2 + 77)
+    elif case == "hc9":
+        flags = oracle.generate(oracle.GEN_NA12878, 14, 1, 0, 512000 + 999)
+        kw.update(mode="hc", level=9)
+    elif case == "tiny_odd_blocks":
+        flags = oracle.generate(oracle.GEN_UNIFORM, 15, 0x0FFF, 0, 200000)
+        kw.update(block_bytes=9999)
+    else:                               # incompressible, > 3 pinned spans of 64 MiB of FILE bytes: buffer recycling
+        flags = oracle.generate(oracle.GEN_UNIFORM, 16, 0xFFFF, 0, 512000 * 280 + 5)
+    path = tmp_path / (case + ".lz4")
+    size = bt.write_block_file(path, flags, **kw)
+    want, n = expect(flags, kw["block_bytes"])
+    for threads in (1, 3, 0):
+        got, st = blockfile.flagstat_lz4_file(str(path), threads)
+        assert np.array_equal(got, want), (case, threads)
+        assert st["n_flags"] == n and st["compressed_bytes"] == size and st["gpu_decode"] == 1
+        assert st["uncompressed_bytes"] == 2 * len(flags) and st["threads"] >= 1
+    img = open(path, "rb").read()
+    got, st = blockfile.flagstat_lz4_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 1 and st["threads"] == 0
+    got, st = blockfile.flagstat_file(str(path), 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 1
+    # superset counters (slots 0 / 16 = primary paired reads, slot 9 = pass-QC reads), against the host-thread pipeline
+    sup_gpu, st = blockfile.flagstat_file(str(path), 2, superset=True)
+    assert st["gpu_decode"] == 1
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 0) == 0
+    sup_host, st = blockfile.flagstat_file(str(path), 2, superset=True)
+    got_host, _ = blockfile.flagstat_lz4_file(str(path), 2)
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
+    assert st["gpu_decode"] == 0 and np.array_equal(got_host, want)
+    assert np.array_equal(sup_gpu, sup_host), case
+
+
+def test_gpu_decoder_is_chosen_by_size_and_fails_loudly(gpu_decoder, tmp_path):
+    import oracle
+    from libflagstats_amd import _lib, blockfile
+    hip = gpu_decoder
+    flags = oracle.generate(oracle.GEN_NA12878, 21, 1, 0, 512000 * 2 + 100)
+    img = bt.block_file_image(flags)
+    want = expect(flags, bt.BLOCK_BYTES)[0]
+    # by size (default rule 2): below the threshold the host threads decode, at it the GPU
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 2) == 0
+    got, st = blockfile.flagstat_lz4_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 0
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", len(img)) == 0
+    got, st = blockfile.flagstat_lz4_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 1
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 3 << 29) == 0
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 3) != 0
+    # damaged input: truncated header / payload, a header that claims more than the block holds, a corrupted payload
+    for cut in (3, 8 + 10, len(img) - 1):
+        with pytest.raises(_lib.FlagstatsHipError):
+            blockfile.flagstat_lz4_image(img[:cut], 2)
+    bad = bytearray(img)
+    bad[0:4] = (512000 * 2 + 1000).to_bytes(4, "little")
+    with pytest.raises(_lib.FlagstatsHipError):
+        blockfile.flagstat_lz4_image(bytes(bad), 2)
+    p = tmp_path / "cut.lz4"
+    p.write_bytes(img[:len(img) - 7])
+    with pytest.raises(_lib.FlagstatsHipError):
+        blockfile.flagstat_lz4_file(str(p), 2)
+    empty = tmp_path / "empty.lz4"
+    empty.write_bytes(b"")
+    got, st = blockfile.flagstat_lz4_file(str(empty), 2)
+    assert not got.any() and st["n_blocks"] == 0
+    # ... and the library is still usable, counters untouched by the failed calls
+    got, _ = blockfile.flagstat_lz4_image(img, 2)
+    assert np.array_equal(got, want)
