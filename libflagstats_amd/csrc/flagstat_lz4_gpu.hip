@@ -46,26 +46,24 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
                                                      unsigned long long* __restrict__ tally)
 {
     constexpr uint32_t kRingMask = RING - 1, kFlush = RING / 4;
-    constexpr uint32_t kJt = RING + INWIN + 16;  // j table: jt[18 * o + lane] = lane mod o (o = 1..17), lane (o = 18), lane < 18
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kJt + 19 * 18 + 2];  // the kernel's only LDS object: offset 0
+    constexpr uint32_t kLgRing = RING == 8192 ? 13 : 14;
+    static_assert(RING == 8192 || RING == 16384, "pass rows pack two ring offsets and a length into 32 bits");
+    constexpr uint32_t kScratch = RING + INWIN + 16;  // 64 bytes nobody reads: where idle lanes of a copy pass point
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kScratch + 64];
     uint8_t* const ring = lds;
     uint8_t* const inw = lds + RING;
-    const uint32_t ring_lds = __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(reinterpret_cast<uintptr_t>(lds)));  // LDS byte address
     const GpuBlock b = blocks[blockIdx.x];
     const uint8_t* src = comp + b.src_off;
     uint8_t* dst = out + b.dst_off;
     const uint32_t iend = b.src_len, oend = b.dst_len;
     const uint32_t lane = threadIdx.x;
     uint32_t ip = 0, op = 0, in_base = 0, in_valid = 0, flushed = 0;
-    uint32_t err = ring_lds ? 7u : 0u, nseq = 0, nfar = 0;  // the hand-scheduled copy loop takes ring offsets as LDS addresses
+    uint32_t err = 0, nseq = 0, nfar = 0;
     // PROF: wave cycles per phase (s_memtime), summed over all waves into tally[2..]
-    unsigned long long t_lit = 0, n_lit = 0, t_copy = 0, t_far = 0, t_slow = 0, t_flush = 0, t_cover = 0, t_parse = 0, n_batch = 0, n_slow = 0, t_mark = 0;
+    unsigned long long n_pass = 0, n_single = 0, t_lit = 0, n_lit = 0, t_copy = 0, t_far = 0, t_slow = 0, t_flush = 0, t_cover = 0, t_parse = 0, n_batch = 0, n_slow = 0, t_mark = 0;
     auto tick = [&]() { if (PROF) t_mark = __builtin_readcyclecounter(); };
     auto tock = [&](unsigned long long& acc) { if (PROF) { const unsigned long long now = __builtin_readcyclecounter(); acc += now - t_mark; t_mark = now; } };
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
-    if (threadIdx.x < 18u) {
-        for (uint32_t o = 0; o <= 18u; ++o) lds[kJt + 18u * o + threadIdx.x] = static_cast<uint8_t>(o == 0u ? 0u : (o == 18u ? threadIdx.x : threadIdx.x % o));
-    }
     const uint32_t magic = lane ? 65535u / lane + 1u : 0u;  // ceil(2^16 / lane): (j * magic) >> 16 == j / lane for j < 64
 
     // make inw[] cover [ip, ip + need) (need <= 80) unless the block ends first
@@ -132,161 +130,68 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
             ok = ok && tok < 15u && offk != 0u && offk <= opk && opk + mlk <= oend;
             const uint64_t bad = __builtin_amdgcn_ballot_w64(!ok);               // lanes >= 16 are never ok: bad != 0
             const uint32_t nb = static_cast<uint32_t>(__builtin_ctzll(bad));     // leading bare sequences of this batch, 0..16
-            const uint32_t packed = offk | (mlk << 16);
-            // The copies, one per step and in order.  The next sequence's scalars (offset, length, lane -> source index)
-            // are prepared while this one's LDS read is in flight.  j = lane mod off through the 16-bit reciprocal of
-            // off (off < 64; a longer period never wraps inside 18 bytes: reciprocal 0).
-            auto unpack = [&](uint32_t k, uint32_t& off, uint32_t& ml, uint32_t& j) {
-                const uint32_t p = __builtin_amdgcn_readlane(packed, k);
-                off = p & 0xFFFFu;
-                ml = p >> 16;
-                uint32_t m = __builtin_amdgcn_readlane(magic, off & 63u);
-                if (off >= 64u) m = 0;
-                j = lane - __umul24(__umul24(lane, m) >> 16, off);
-            };
             ++n_batch;
             tock(t_parse);
-            uint64_t farm = __builtin_amdgcn_ballot_w64(offk > RING - 64u) & ((1ull << nb) - 1ull);  // bare, but behind the ring
-            uint32_t k = 0;
-            // Hand-scheduled copy loop (the decoder is issue-bound, so every instruction per sequence counts): 6 vector, 6
-            // scalar and 3 LDS instructions per sequence.  What a sequence needs was computed for all 16 at once above --
-            // A = ring offset of the source, B = of the destination, T = row of the j table (lane -> lane mod off), G =
-            // source offset in the flushed output for a match behind the ring -- and is read out of lane k as scalars
-            // that feed vector adds directly.  Lanes 0..17 copy whatever the match length: the bytes past it are not
-            // yet valid output, the next sequence overwrites them (and 18 < 64 keeps the ring's oldest valid source
-            // clear of them).  The j row of sequence k + 2 is fetched while sequence k's byte is in flight, so the only
-            // wait of a step is for that byte.  Batches where a source or destination would wrap around the end of the
-            // ring (1 in ~20) take the masked loop below instead.
-            const uint32_t Avec = (opk - offk) & kRingMask, Bvec = opk & kRingMask, Gvec = opk - offk;
-            const uint32_t Tvec = kJt + 18u * (offk < 18u ? offk : 18u);
-            const uint64_t wraps = __builtin_amdgcn_ballot_w64(Avec > RING - 18u || Bvec > RING - 18u) & ((1ull << nb) - 1ull);
-            if (nb && !wraps) {
-                uint32_t d, jA, jB, la, ra, wa, wb, g, sT, sA, sB, sG, kk, k2;
-                const uint32_t farm32 = static_cast<uint32_t>(farm);
-#define LZ_STEP(JNEW, JUSE, WCUR, WNEXT, FARLABEL, BACKLABEL)                  \
-    "ds_read_u8 %[d], %[ra]\n\t"                                              \
-    "s_add_u32 %[k2], %[kk], 2\n\t"                                           \
-    "s_bitcmp1_b32 %[farm], %[kk]\n\t"                                        \
-    "v_readlane_b32 %[sT], %[T], %[k2]\n\t"                                   \
-    "s_cbranch_scc1 " FARLABEL "f\n"                                           \
-    BACKLABEL ":\n\t"                                                         \
-    "s_add_u32 %[kk], %[kk], 1\n\t"                                           \
-    "v_add_u32 %[la], %[sT], %[lane]\n\t"                                     \
-    "ds_read_u8 " JNEW ", %[la]\n\t"                                          \
-    "v_readlane_b32 %[sA], %[A], %[kk]\n\t"                                   \
-    "v_readlane_b32 %[sB], %[B], %[kk]\n\t"                                   \
-    "s_cmp_lt_u32 %[kk], %[nb]\n\t"                                           \
-    "s_waitcnt lgkmcnt(2)\n\t"                                                \
-    "v_add_u32 %[ra], %[sA], " JUSE "\n\t"                                    \
-    "v_add_u32 " WNEXT ", %[sB], %[lane]\n\t"                                 \
-    "s_waitcnt lgkmcnt(1)\n\t"                                                \
-    "ds_write_b8 " WCUR ", %[d]\n\t"                                          \
-    "s_cbranch_scc0 9f\n\t"
-#define LZ_FAR(FARLABEL, BACKLABEL)                                           \
-    FARLABEL ":\n\t"                                                          \
-    "v_readlane_b32 %[sG], %[G], %[kk]\n\t"                                   \
-    "s_nop 0\n\t"                                                             \
-    "v_add_u32 %[g], %[sG], %[lane]\n\t"                                      \
-    "global_load_ubyte %[g], %[g], %[dst] sc1\n\t"                            \
-    "s_waitcnt vmcnt(0) lgkmcnt(0)\n\t"                                       \
-    "v_mov_b32 %[d], %[g]\n\t"                                                \
-    "s_branch " BACKLABEL "b\n"
-                asm volatile(
-                    "s_mov_b64 exec, 0x3ffff\n\t"
-                    "v_readlane_b32 %[sT], %[T], 0\n\t"
-                    "v_readlane_b32 %[sA], %[A], 0\n\t"
-                    "v_readlane_b32 %[sB], %[B], 0\n\t"
-                    "v_add_u32 %[la], %[sT], %[lane]\n\t"
-                    "ds_read_u8 %[jA], %[la]\n\t"
-                    "v_readlane_b32 %[sT], %[T], 1\n\t"
-                    "s_mov_b32 %[kk], 0\n\t"
-                    "v_add_u32 %[la], %[sT], %[lane]\n\t"
-                    "ds_read_u8 %[jB], %[la]\n\t"
-                    "v_add_u32 %[wa], %[sB], %[lane]\n\t"
-                    "s_waitcnt lgkmcnt(1)\n\t"
-                    "v_add_u32 %[ra], %[sA], %[jA]\n"
-                    "1:\n\t"
-                    LZ_STEP("%[jA]", "%[jB]", "%[wa]", "%[wb]", "3", "2")
-                    LZ_STEP("%[jB]", "%[jA]", "%[wb]", "%[wa]", "5", "4")
-                    "s_branch 1b\n"
-                    LZ_FAR("3", "2")
-                    LZ_FAR("5", "4")
-                    "9:\n\t"
-                    "s_waitcnt lgkmcnt(0)\n\t"
-                    "s_mov_b64 exec, -1"
-                    : [d] "=&v"(d), [jA] "=&v"(jA), [jB] "=&v"(jB), [la] "=&v"(la), [ra] "=&v"(ra), [wa] "=&v"(wa), [wb] "=&v"(wb), [g] "=&v"(g),
-                      [sT] "=&s"(sT), [sA] "=&s"(sA), [sB] "=&s"(sB), [sG] "=&s"(sG), [kk] "=&s"(kk), [k2] "=&s"(k2)
-                    : [T] "v"(Tvec), [A] "v"(Avec), [B] "v"(Bvec), [G] "v"(Gvec), [lane] "v"(lane), [farm] "s"(farm32), [nb] "s"(nb),
-                      [dst] "s"(dst)
-                    : "memory", "scc");
-#undef LZ_STEP
-#undef LZ_FAR
-                op += __builtin_amdgcn_readlane(incl, nb - 1u);
-                nfar += static_cast<uint32_t>(__builtin_popcountll(farm));
-                k = nb;
-                tock(t_copy);
-            }
-            while (k < nb) {
-                const uint32_t kend = farm ? static_cast<uint32_t>(__builtin_ctzll(farm)) : nb;
-                if (k < kend) {
-                    // Near run [k, kend): one hand-scheduled step per sequence.  The LDS read of sequence k is issued, the
-                    // scalars and addresses of sequence k + 1 are computed while it is in flight, then the write of k;
-                    // the next read follows the write without a wait (one wave's LDS operations execute in order).
-                    uint32_t off, ml, j;
-                    unpack(k, off, ml, j);
-                    uint32_t ra = (op - off + j) & kRingMask;  // (ring_lds == 0, checked at the top)
-                    uint32_t wa = (op + lane) & kRingMask;
-                    uint64_t mask = __builtin_amdgcn_ballot_w64(lane < ml);
-                    for (; k < kend; ++k) {
-                        uint32_t d, pos, t, sp, soff, sm;
-                        uint64_t maskn;
-                        const uint32_t k1 = (k + 1u) & 15u;  // (past the end of the run: parsed but unused)
-                        asm volatile(
-                            "s_mov_b64 exec, %[mask]\n\t"
-                            "ds_read_u8 %[d], %[ra]\n\t"
-                            "s_mov_b64 exec, -1\n\t"
-                            "v_readlane_b32 %[sp], %[packed], %[k1]\n\t"
-                            "s_add_u32 %[op], %[op], %[ml]\n\t"
-                            "v_add_u32 %[pos], %[op], %[lane]\n\t"
-                            "s_and_b32 %[soff], %[sp], 0xffff\n\t"
-                            "s_lshr_b32 %[ml], %[sp], 16\n\t"
-                            "s_nop 1\n\t"
-                            "v_readlane_b32 %[sm], %[magic], %[sp]\n\t"
-                            "v_cmp_gt_u32 %[maskn], %[ml], %[lane]\n\t"
-                            "s_cmp_lt_u32 %[soff], 64\n\t"
-                            "s_cselect_b32 %[sm], %[sm], 0\n\t"
-                            "v_mul_u32_u24 %[t], %[sm], %[lane]\n\t"
-                            "v_lshrrev_b32 %[t], 16, %[t]\n\t"
-                            "v_mad_u32_u24 %[t], %[t], %[soff], %[soff]\n\t"
-                            "v_sub_u32 %[ra], %[pos], %[t]\n\t"
-                            "v_and_b32 %[ra], %[rmask], %[ra]\n\t"
-                            "s_waitcnt lgkmcnt(0)\n\t"
-                            "s_mov_b64 exec, %[mask]\n\t"
-                            "ds_write_b8 %[wa], %[d]\n\t"
-                            "s_mov_b64 exec, -1\n\t"
-                            "s_mov_b64 %[mask], %[maskn]\n\t"
-                            "v_and_b32 %[wa], %[rmask], %[pos]"
-                            : [d] "=&v"(d), [pos] "=&v"(pos), [t] "=&v"(t), [sp] "=&s"(sp), [soff] "=&s"(soff), [sm] "=&s"(sm),
-                              [maskn] "=&s"(maskn), [ra] "+v"(ra), [wa] "+v"(wa), [mask] "+s"(mask), [op] "+s"(op), [ml] "+s"(ml)
-                            : [packed] "v"(packed), [magic] "v"(magic), [lane] "v"(lane), [k1] "s"(k1), [rmask] "n"(kRingMask)
-                            : "memory", "scc");
+            // ---- the copies, in PASSES of up to four sequences (one wave decodes one block, so what bounds it is the chain of
+            // dependent LDS round trips, ~150 cycles each: one per sequence when they are copied one by one).  97 % of the
+            // sequences of a flag stream do not read what the few sequences before them wrote, so a pass takes up to four
+            // consecutive sequences whose sources all end at or before the pass's first output byte -- or lie behind the
+            // ring, in flushed output -- gives each a row of 16 lanes, and copies all of them with ONE read and ONE write
+            // (matches of 17 or 18 bytes and matches that overlap their own output, off < ml, go alone).  What a row needs
+            // -- ring offsets of source and destination, length -- is packed into one word per sequence above
+            // and read out of lanes k0..k0+3 as scalars.
+            const bool fark = offk > RING - 64u;
+            const uint32_t endk = opk + mlk;  // where sequence k's output ends
+            const uint32_t rowk = ((opk - offk) & kRingMask) | ((opk & kRingMask) << kLgRing) | (((mlk - 1u) & 15u) << (2u * kLgRing));
+            const uint32_t gsrck = opk - offk;  // source offset in the block's output (far matches read it from global memory)
+            const uint64_t farm = __builtin_amdgcn_ballot_w64(fark) & ((1ull << nb) - 1ull);
+            const uint32_t row = lane >> 4, col = lane & 15u;
+            uint32_t k0 = 0;
+            while (k0 < nb) {
+                const uint32_t P = __builtin_amdgcn_readlane(opk, k0);  // first output byte of the pass
+                // (bitwise on purpose: no short-circuit branches in the wave's critical path)
+                const uint64_t brk = __builtin_amdgcn_ballot_w64(
+                    static_cast<bool>((lane >= k0) & ((lane >= nb) | (lane >= k0 + 4u) | (mlk > 16u) | (!fark & (endk - offk > P)))));
+                const uint32_t k1 = static_cast<uint32_t>(__builtin_ctzll(brk));  // (bits nb.. are set: k1 <= nb)
+                if (PROF) { if (k1 == k0) ++n_single; else ++n_pass; }
+                if (k1 == k0) {
+                    // alone: 17..18 bytes, or a source that overlaps its own output (period off < ml)
+                    const uint32_t off = __builtin_amdgcn_readlane(offk, k0), ml = __builtin_amdgcn_readlane(mlk, k0);
+                    if (off <= RING - 64u) {
+                        uint32_t m = __builtin_amdgcn_readlane(magic, off & 63u);
+                        if (off >= 64u) m = 0;
+                        const uint32_t j = lane - __umul24(__umul24(lane, m) >> 16, off);  // lane mod off
+                        if (lane < ml) ring[(P + lane) & kRingMask] = ring[(P - off + j) & kRingMask];
+                    } else {
+                        ++nfar;
+                        if (lane < ml)
+                            ring[(P + lane) & kRingMask] = __hip_atomic_load(&dst[P - off + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
+                    ++k0;
+                    continue;
                 }
-                tock(t_copy);
-                if (k < nb) {
-                    // sequence k reaches behind the ring: its source was flushed long ago; device-scope load, past the L1
-                    const uint32_t p = __builtin_amdgcn_readlane(packed, k);
-                    const uint32_t off = p & 0xFFFFu, ml = p >> 16;
-                    if (lane < ml)
-                        ring[(op + lane) & kRingMask] = __hip_atomic_load(&dst[op - off + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    op += ml;
-                    ++nfar;
-                    ++k;
-                    farm &= farm - 1ull;
-                    if (PROF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                    tock(t_far);
+                const uint32_t s0 = __builtin_amdgcn_readlane(rowk, k0), s1 = __builtin_amdgcn_readlane(rowk, k0 + 1u);
+                const uint32_t s2 = __builtin_amdgcn_readlane(rowk, k0 + 2u), s3 = __builtin_amdgcn_readlane(rowk, k0 + 3u);
+                const uint32_t v = row == 0u ? s0 : row == 1u ? s1 : row == 2u ? s2 : s3;
+                const bool act = row < k1 - k0 && col <= (v >> (2u * kLgRing));
+                // (lanes with nothing to copy read and write a scratch byte of their own: straight-line LDS traffic, so the
+                // only wait the compiler needs is the one between this read and this write)
+                const uint32_t ra = act ? ((v & kRingMask) + col) & kRingMask : kScratch + lane;
+                const uint32_t wa = act ? (((v >> kLgRing) & kRingMask) + col) & kRingMask : kScratch + lane;
+                uint32_t d = lds[ra];
+                const uint32_t farbits = static_cast<uint32_t>(farm >> k0) & ((1u << (k1 - k0)) - 1u);
+                if (farbits) {
+                    const uint32_t g0 = __builtin_amdgcn_readlane(gsrck, k0), g1 = __builtin_amdgcn_readlane(gsrck, k0 + 1u);
+                    const uint32_t g2 = __builtin_amdgcn_readlane(gsrck, k0 + 2u), g3 = __builtin_amdgcn_readlane(gsrck, k0 + 3u);
+                    const uint32_t gv = row == 0u ? g0 : row == 1u ? g1 : row == 2u ? g2 : g3;
+                    if (act && ((farbits >> row) & 1u)) d = __hip_atomic_load(&dst[gv + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    nfar += static_cast<uint32_t>(__builtin_popcount(farbits));
                 }
+                lds[wa] = static_cast<uint8_t>(d);
+                k0 = k1;
             }
+            if (nb) op = __builtin_amdgcn_readlane(endk, nb - 1u);
+            tock(t_copy);
             ip += 3u * nb;
             nseq += nb;
             flush_to(op);
@@ -422,6 +327,8 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
             atomicAdd(&tally[10], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
             atomicAdd(&tally[11], t_lit);
             atomicAdd(&tally[12], n_lit);
+            atomicAdd(&tally[13], n_pass);
+            atomicAdd(&tally[14], n_single);
         }
     }
 }
@@ -625,10 +532,10 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         LZG_TRY(hipStreamWaitEvent(ds, landed[c], 0));
         const dim3 grid(static_cast<uint32_t>(last - first));
         if (prof)
-            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 640, true>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
+            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024, true>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
                                d_status + first, d_tally);
         else if (!big_ring)
-            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 640>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
+            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
                                d_status + first, d_tally);
         else
             hipLaunchKernelGGL((fsk::lz4_decode_wave<16384, 4096>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
@@ -666,13 +573,13 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
     LZG_TRY(hipEventElapsedTime(&pipe, ev[0], ev[3]));
     if (prof) {
         int per_cu = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fsk::lz4_decode_wave<8192, 640, true>, 64, 0);
+        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fsk::lz4_decode_wave<8192, 1024, true>, 64, 0);
         std::fprintf(stderr, "lz4 gpu profile: %d waves per CU fit\n", per_cu);
         const double tot = static_cast<double>(tally[10]) + 1e-9;
         std::fprintf(stderr, "lz4 gpu profile (ring 8 KiB): wave cycles %.3g | copy %.1f %% far %.1f %% lit %.1f %% slow %.1f %% flush %.1f %% cover %.1f %% parse %.1f %% | "
-                             "%llu batches (%.1f seq each), %llu short-literal + %llu slow sequences, %llu far\n",
+                             "%llu batches (%.1f seq each), %llu passes + %llu alone, %llu short-literal + %llu slow sequences, %llu far\n",
                      tot, 100 * tally[2] / tot, 100 * tally[3] / tot, 100 * tally[11] / tot, 100 * tally[4] / tot, 100 * tally[5] / tot, 100 * tally[6] / tot,
-                     100 * tally[7] / tot, tally[8], tally[8] ? static_cast<double>(tally[0] - tally[9] - tally[12]) / tally[8] : 0.0, tally[12], tally[9], tally[1]);
+                     100 * tally[7] / tot, tally[8], tally[8] ? static_cast<double>(tally[0] - tally[9] - tally[12]) / tally[8] : 0.0, tally[13], tally[14], tally[12], tally[9], tally[1]);
     }
     if (stats) {
         stats->bad_blocks = bad;
