@@ -66,6 +66,7 @@ def main():
                       "%.1f ms = %.1f Gflags/s" % (st.ring_kib, st.chunks, streams, rep, wall * 1e3, st.h2d_ms, st.decode_ms, st.count_ms,
                                                    st.sequences / 1e6, 100.0 * st.far_matches / max(1, st.sequences), st.pipeline_ms,
                                                    n / st.pipeline_ms / 1e6), flush=True)
+        _lib.check(lib.FLAGSTATS_hip_set(b"lz4_decoder", 0), "set lz4_decoder")   # the host-thread pipeline, whatever the size
         for rep in range(3):
             got = np.zeros(32, dtype=np.uint64)
             hs = _lib.BlockfileStats()
@@ -74,6 +75,7 @@ def main():
             assert np.array_equal(got, want), "host pipeline: counters differ from the oracle"
             print("  host pipeline rep %d: %.1f ms -> %.1f Gflags/s (%d decoder threads, waiting for copies %.0f %% of the time)"
                   % (rep, hs.wall_s * 1e3, n / hs.wall_s / 1e9, hs.threads, 100.0 * hs.wait_copy_s / max(hs.wall_s, 1e-9)), flush=True)
+        _lib.check(lib.FLAGSTATS_hip_set(b"lz4_decoder", 2), "set lz4_decoder")
 
 
 if __name__ == "__main__":
