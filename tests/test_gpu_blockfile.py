@@ -277,3 +277,97 @@ def test_gpu_decoder_is_chosen_by_size_and_fails_loudly(gpu_decoder, tmp_path):
     # ... and the library is still usable, counters untouched by the failed calls
     got, _ = blockfile.flagstat_lz4_image(img, 2)
     assert np.array_equal(got, want)
+
+
+def _synthetic_lz4_block(rs, target, style):
+    """A VALID LZ4 block that liblz4 would never write: sequences drawn at random with the parameters pushed to the
+    decoder's edges (offsets around the 8 KiB ring / its 64-byte margin / 16 KiB / 65535, offsets 1..20 that overlap
+    their own output, matches of 4, 18, 19, 20, 270+ bytes, literal runs of 0, 1, 14, 15, 16, 270+).  Returns
+    (compressed, decoded)."""
+    out = bytearray()
+    comp = bytearray()
+    edge_offs = [1, 2, 3, 4, 7, 8, 15, 16, 17, 18, 19, 20, 63, 64, 65, 8127, 8128, 8129, 8191, 8192, 8193, 16319, 16320, 16321,
+                 16384, 32768, 65534, 65535]
+    edge_ml = [4, 5, 15, 16, 17, 18, 19, 20, 21, 33, 64, 65, 255 + 19, 255 + 20, 600]
+    edge_ll = [0, 0, 0, 0, 1, 2, 13, 14, 15, 16, 17, 64, 65, 255 + 15, 255 + 16, 700]
+
+    def put_len(v):
+        while v >= 255:
+            comp.append(255)
+            v -= 255
+        comp.append(v)
+
+    while len(out) < target:
+        if style == "bare":            # long runs of bare short matches (the batch path), a literal now and then
+            ll = 0 if rs.rand() < 0.93 or not out else int(rs.randint(1, 15))
+            ml = int(rs.randint(4, 19))
+        elif style == "edges":
+            ll = int(edge_ll[rs.randint(len(edge_ll))])
+            ml = int(edge_ml[rs.randint(len(edge_ml))])
+        else:                          # mixed
+            ll = int(rs.choice([0, 0, 0, int(rs.randint(1, 40))]))
+            ml = int(rs.choice([int(rs.randint(4, 19)), int(rs.randint(4, 19)), int(rs.randint(19, 80))]))
+        if not out and ll == 0:
+            ll = 4                     # the first sequence needs something to match against
+        lits = bytes(rs.randint(0, 256, ll, dtype=np.uint8)) if style != "bare" else bytes(rs.randint(0, 4, ll, dtype=np.uint8))
+        have = len(out) + ll
+        if rs.rand() < 0.5:
+            off = int(edge_offs[rs.randint(len(edge_offs))])
+        elif rs.rand() < 0.5:
+            off = int(rs.randint(1, 300))
+        else:
+            off = int(rs.randint(1, 65536))
+        off = max(1, min(off, have, 65535))
+        token = (min(ll, 15) << 4) | min(ml - 4, 15)
+        comp.append(token)
+        if ll >= 15:
+            put_len(ll - 15)
+        comp += lits
+        out += lits
+        comp += bytes((off & 255, off >> 8))
+        if ml - 4 >= 15:
+            put_len(ml - 4 - 15)
+        for _ in range(ml):            # byte by byte: overlapping matches repeat with period off
+            out.append(out[-off])
+    # the block ends with a literals-only sequence; the last match must start at least 12 bytes before the end of the
+    # block (LZ4 block format, "parsing restrictions": liblz4 rejects anything else)
+    ll = int(rs.choice([12, 13, 14, 15, 16, 40]))
+    lits = bytes(rs.randint(0, 256, ll, dtype=np.uint8))
+    comp.append(min(ll, 15) << 4)
+    if ll >= 15:
+        put_len(ll - 15)
+    comp += lits
+    out += lits
+    return bytes(comp), bytes(out)
+
+
+@pytest.mark.parametrize("style,seed", [("bare", 1), ("bare", 2), ("edges", 3), ("edges", 4), ("mixed", 5), ("mixed", 6)])
+def test_gpu_decoder_on_synthetic_edge_streams(gpu_decoder, style, seed):
+    """The GPU decoder (and the host decoder beside it) on streams built to sit on its internal boundaries -- ring size
+    and far-match margin, flush quarters, the 16-sequence batch, rows of 16 lanes, self-overlapping matches, length
+    extension bytes, window refills -- checked against the decoded bytes the generator itself produced."""
+    import struct
+
+    import oracle
+    from libflagstats_amd import blockfile
+    hip = gpu_decoder
+    rs = np.random.RandomState(seed)
+    img = bytearray()
+    want = np.zeros(32, dtype=np.uint64)
+    n = 0
+    sizes = [40, 300, 5000, 70000, 200000, 1 << 20, 3000, 17]
+    for target in sizes:
+        comp, dec = _synthetic_lz4_block(rs, target, style)
+        img += struct.pack("<ii", len(dec), len(comp)) + comp
+        k = len(dec) >> 1
+        want += oracle.flagstat_hist(np.frombuffer(dec[:2 * k], dtype=np.uint16))
+        n += k
+        assert bt.decompress_block_ref(comp, len(dec)) == dec             # liblz4 (what the reference calls) accepts it
+        assert blockfile.lz4_block_decode(comp, len(dec)) == dec          # ... and so does the product's host decoder
+    got, st = blockfile.flagstat_lz4_image(bytes(img), 2)
+    assert st["gpu_decode"] == 1 and st["n_flags"] == n
+    assert np.array_equal(got, want), (style, seed)
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 0) == 0
+    got_host, st = blockfile.flagstat_lz4_image(bytes(img), 2)
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
+    assert st["gpu_decode"] == 0 and np.array_equal(got_host, want)
