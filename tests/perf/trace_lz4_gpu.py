@@ -1,0 +1,26 @@
+#!/usr/bin/env python3
+"""For `rocprofv3 --kernel-trace --stats -- python3 tests/perf/trace_lz4_gpu.py`: five GPU-decoded passes over one LZ4
+block image (2^31 flags by default) through the product entry, so the kernel table shows the decode launches and K1."""
+import ctypes
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests", "perf"))
+import numpy as np  # noqa: E402
+
+from libflagstats_amd import _lib  # noqa: E402
+from lz4_decoder_sweep import build_image  # noqa: E402
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 2 ** 31
+lib = _lib.lib()
+_lib.check(lib.FLAGSTATS_hip_init(0), "init")
+_lib.check(lib.FLAGSTATS_hip_set(b"lz4_decoder", 1), "set")
+img = build_image(n, "fast", 2)
+buf = np.frombuffer(img, dtype=np.uint8)
+for rep in range(5):
+    out = np.zeros(32, dtype=np.uint64)
+    st = _lib.BlockfileStats()
+    _lib.check(lib.FLAGSTATS_hip_blockimage_lz4(buf.ctypes.data, buf.size, 0, out.ctypes.data, ctypes.byref(st)), "blockimage")
+    print("pass %d: %.1f ms, %d blocks in %d pieces" % (rep, st.wall_s * 1e3, st.n_blocks, st.chunks), flush=True)
