@@ -283,6 +283,9 @@ typedef struct FLAGSTATS_gpu_lz4_stats {
                                                       decode_ms = the decode time left exposed after the last copy */
     uint64_t uncompressed_bytes, readers;          /* sum of the blocks' declared sizes; file mode: parallel preads used */
     double wall_s;                                 /* whole call: index, allocations, pipeline, results */
+    uint64_t segments;                             /* files larger than the device can hold go through in several segments
+                                                      (compressed + decoded bytes of one are resident together); the ms
+                                                      fields and `chunks` are sums over them */
 } FLAGSTATS_gpu_lz4_stats;
 int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t bytes, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats);
 /* the host LZ4 *block* decoder used above (replaces the reference's call to liblz4's

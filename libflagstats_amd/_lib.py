@@ -35,7 +35,8 @@ class GpuLz4Stats(ctypes.Structure):
                 ("h2d_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("count_ms", ctypes.c_double),
                 ("sequences", ctypes.c_uint64), ("far_matches", ctypes.c_uint64), ("ring_kib", ctypes.c_uint64),
                 ("chunks", ctypes.c_uint64), ("pipeline_ms", ctypes.c_double),
-                ("uncompressed_bytes", ctypes.c_uint64), ("readers", ctypes.c_uint64), ("wall_s", ctypes.c_double)]
+                ("uncompressed_bytes", ctypes.c_uint64), ("readers", ctypes.c_uint64), ("wall_s", ctypes.c_double),
+                ("segments", ctypes.c_uint64)]
 
 
 # name -> (restype, argtypes); mirrors include/libflagstats_hip.h one to one

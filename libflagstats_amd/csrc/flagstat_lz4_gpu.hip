@@ -343,42 +343,11 @@ namespace fsint {
 // piece's decode hides behind the copies; one K1/K2 pass then counts the whole decoded buffer.  Image mode copies
 // straight out of the caller's memory; file mode reads the file with `threads` parallel preads into the engine's three
 // pinned chunk buffers and copies from there.  e.mu must be held.
-int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
+// one segment: file bytes [file_lo, file_lo + bytes) hold `blocks` (offsets relative to the segment), dpos decoded bytes
+static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, const std::vector<fsk::GpuBlock>& blocks,
+                           uint64_t bytes, uint64_t dpos, uint64_t n_flags, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
 {
-    const auto t_start = std::chrono::steady_clock::now();
-    const uint8_t* img = in.img;
-    const uint64_t bytes = in.bytes;
-    // index: int32 uncompressed size, int32 compressed size, payload (benchmark/flagstats.cpp:119-138)
-    std::vector<fsk::GpuBlock> blocks;
-    uint64_t pos = 0, dpos = 0, n_flags = 0, usum = 0;
-    while (pos < bytes) {
-        if (bytes - pos < 8) return fail_text("block file: truncated block header");
-        int32_t us, cs;
-        uint8_t hdr[8];
-        if (img) {
-            std::memcpy(hdr, img + pos, 8);
-        } else if (pread(in.fd, hdr, 8, static_cast<off_t>(pos)) != 8) {
-            return fail_text("block file: cannot read block header");
-        }
-        std::memcpy(&us, hdr, 4);
-        std::memcpy(&cs, hdr + 4, 4);
-        if (us < 0 || cs < 0) return fail_text("block file: negative size in block header");
-        if (static_cast<uint64_t>(cs) > bytes - pos - 8) return fail_text("block file: block payload runs past end of file");
-        blocks.push_back(fsk::GpuBlock{pos + 8, dpos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us)});
-        n_flags += static_cast<uint64_t>(us) >> 1;  // as benchmark/flagstats.cpp:323
-        usum += static_cast<uint64_t>(us);
-        dpos += (static_cast<uint64_t>(us) + 15) & ~15ull;
-        pos += 8 + static_cast<uint64_t>(cs);
-    }
-    if (stats) {
-        *stats = FLAGSTATS_gpu_lz4_stats{};
-        stats->n_blocks = blocks.size();
-        stats->n_flags = n_flags;
-        stats->compressed_bytes = bytes;
-        stats->decoded_bytes = dpos;
-        stats->uncompressed_bytes = usum;
-    }
-    if (blocks.empty()) return 0;
+    const uint8_t* img = in.img ? in.img + file_lo : nullptr;
     uint8_t *d_comp = nullptr, *d_out = nullptr;
     fsk::GpuBlock* d_blocks = nullptr;
     uint32_t* d_status = nullptr;
@@ -493,7 +462,7 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
             auto read_share = [&](uint64_t o) {
                 uint64_t end = o + share < len ? o + share : len;
                 while (o < end) {
-                    const ssize_t r = pread(in.fd, pinned[pb] + o, end - o, static_cast<off_t>(at + o));
+                    const ssize_t r = pread(in.fd, pinned[pb] + o, end - o, static_cast<off_t>(file_lo + at + o));
                     if (r <= 0) {
                         failed.store(1);
                         return;
@@ -581,19 +550,16 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
                      tot, 100 * tally[2] / tot, 100 * tally[3] / tot, 100 * tally[11] / tot, 100 * tally[4] / tot, 100 * tally[5] / tot, 100 * tally[6] / tot,
                      100 * tally[7] / tot, tally[8], tally[8] ? static_cast<double>(tally[0] - tally[9] - tally[12]) / tally[8] : 0.0, tally[13], tally[14], tally[12], tally[9], tally[1]);
     }
-    if (stats) {
-        stats->bad_blocks = bad;
-        stats->h2d_ms = h2d;
-        stats->decode_ms = dec;
-        stats->count_ms = cnt;
-        stats->sequences = tally[0];
-        stats->far_matches = tally[1];
-        stats->ring_kib = (!big_ring || prof) ? 8 : 16;
-        stats->chunks = pieces_done;
-        stats->pipeline_ms = pipe;
-        stats->readers = static_cast<uint64_t>(readers);
-        stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    }
+    stats->bad_blocks += bad;
+    stats->h2d_ms += h2d;
+    stats->decode_ms += dec;
+    stats->count_ms += cnt;
+    stats->sequences += tally[0];
+    stats->far_matches += tally[1];
+    stats->ring_kib = (!big_ring || prof) ? 8 : 16;
+    stats->chunks += pieces_done;
+    stats->pipeline_ms += pipe;
+    stats->readers = static_cast<uint64_t>(readers);
     if (!bad) {
         if (in.superset) e.h_out[9] -= dpos / 2 - n_flags;  // zero flags in the slack between blocks are not reads (see run_pipeline)
         for (int k = 0; k < 32; ++k) out[k] += e.h_out[k];
@@ -607,6 +573,83 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
     }
     return 0;
 #undef LZG_TRY
+}
+
+int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
+{
+    const auto t_start = std::chrono::steady_clock::now();
+    const uint8_t* img = in.img;
+    const uint64_t bytes = in.bytes;
+    // index: int32 uncompressed size, int32 compressed size, payload (benchmark/flagstats.cpp:119-138)
+    std::vector<fsk::GpuBlock> blocks;
+    uint64_t pos = 0, dpos = 0, n_flags = 0, usum = 0;
+    while (pos < bytes) {
+        if (bytes - pos < 8) return fail_text("block file: truncated block header");
+        int32_t us, cs;
+        uint8_t hdr[8];
+        if (img) {
+            std::memcpy(hdr, img + pos, 8);
+        } else if (pread(in.fd, hdr, 8, static_cast<off_t>(pos)) != 8) {
+            return fail_text("block file: cannot read block header");
+        }
+        std::memcpy(&us, hdr, 4);
+        std::memcpy(&cs, hdr + 4, 4);
+        if (us < 0 || cs < 0) return fail_text("block file: negative size in block header");
+        if (static_cast<uint64_t>(cs) > bytes - pos - 8) return fail_text("block file: block payload runs past end of file");
+        blocks.push_back(fsk::GpuBlock{pos + 8, dpos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us)});
+        n_flags += static_cast<uint64_t>(us) >> 1;  // as benchmark/flagstats.cpp:323
+        usum += static_cast<uint64_t>(us);
+        dpos += (static_cast<uint64_t>(us) + 15) & ~15ull;
+        pos += 8 + static_cast<uint64_t>(cs);
+    }
+    FLAGSTATS_gpu_lz4_stats local;
+    if (!stats) stats = &local;
+    {
+        *stats = FLAGSTATS_gpu_lz4_stats{};
+        stats->n_blocks = blocks.size();
+        stats->n_flags = n_flags;
+        stats->compressed_bytes = bytes;
+        stats->decoded_bytes = dpos;
+        stats->uncompressed_bytes = usum;
+    }
+    if (blocks.empty()) return 0;
+    // Segments: compressed and decoded bytes of a segment are resident on the device together, so a file larger than the
+    // card can hold goes through in several of them, one after the other (each with its own pieces, decode launches and
+    // counting pass).  Default: a third of the free device memory, at most 16 GiB of decoded bytes; env
+    // FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES overrides (tests).
+    uint64_t seg_cap = 16ull << 30;
+    {
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < seg_cap) seg_cap = free_b / 3;
+        const char* sb = std::getenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES");
+        if (sb && *sb) seg_cap = std::strtoull(sb, nullptr, 0);
+    }
+    std::vector<fsk::GpuBlock> seg;
+    for (size_t b0 = 0; b0 < blocks.size();) {
+        size_t b1 = b0;
+        uint64_t dsz = 0;
+        while (b1 < blocks.size()) {
+            const uint64_t padded = (static_cast<uint64_t>(blocks[b1].dst_len) + 15) & ~15ull;
+            if (b1 > b0 && dsz + padded > seg_cap) break;
+            dsz += padded;
+            ++b1;
+        }
+        const uint64_t file_lo = blocks[b0].src_off - 8, file_hi = blocks[b1 - 1].src_off + blocks[b1 - 1].src_len;
+        const uint64_t d0 = blocks[b0].dst_off;
+        seg.assign(blocks.begin() + static_cast<std::ptrdiff_t>(b0), blocks.begin() + static_cast<std::ptrdiff_t>(b1));
+        uint64_t seg_flags = 0;
+        for (fsk::GpuBlock& g : seg) {
+            g.src_off -= file_lo;
+            g.dst_off -= d0;
+            seg_flags += static_cast<uint64_t>(g.dst_len) >> 1;
+        }
+        const int rc = lz4_gpu_segment(e, in, file_lo, seg, file_hi - file_lo, dsz, seg_flags, out, stats);
+        if (rc) return rc;
+        ++stats->segments;
+        b0 = b1;
+    }
+    stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    return 0;
 }
 
 }  // namespace fsint

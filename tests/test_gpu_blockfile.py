@@ -371,3 +371,29 @@ def test_gpu_decoder_on_synthetic_edge_streams(gpu_decoder, style, seed):
     got_host, st = blockfile.flagstat_lz4_image(bytes(img), 2)
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
     assert st["gpu_decode"] == 0 and np.array_equal(got_host, want)
+
+
+def test_gpu_decoder_goes_through_large_files_in_segments(gpu_decoder, tmp_path, monkeypatch):
+    """A file whose compressed + decoded bytes do not fit the device together is decoded in segments, one after the
+    other; forced here with a 3 MiB segment on 10 blocks (image, file, superset), and a segment smaller than a block."""
+    import oracle
+    from libflagstats_amd import blockfile
+    hip = gpu_decoder
+    flags = oracle.generate(oracle.GEN_NA12878, 31, 1, 0, 512000 * 9 + 4321)
+    img = bt.block_file_image(flags)
+    want, n = expect(flags, bt.BLOCK_BYTES)
+    rc, got, st = gpu_decode(hip, img)
+    assert rc == 0 and st.segments == 1 and np.array_equal(got, want)
+    for cap, segs in ((3 << 20, 3), (1000, 10)):          # three blocks per segment; one block per segment
+        monkeypatch.setenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES", str(cap))
+        rc, got, st = gpu_decode(hip, img)
+        assert rc == 0, hip.FLAGSTATS_hip_last_error()
+        assert np.array_equal(got, want) and st.n_flags == n and st.segments >= segs and st.bad_blocks == 0
+        path = tmp_path / "seg.lz4"
+        path.write_bytes(img)
+        got, bst = blockfile.flagstat_lz4_file(str(path), 3)
+        assert np.array_equal(got, want) and bst["gpu_decode"] == 1 and bst["n_flags"] == n
+        sup, _ = blockfile.flagstat_file(str(path), 2, superset=True)
+        monkeypatch.delenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES")
+        sup_one, _ = blockfile.flagstat_file(str(path), 2, superset=True)
+        assert np.array_equal(sup, sup_one)
