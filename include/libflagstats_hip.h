@@ -238,7 +238,8 @@ int FLAGSTATS_hip_sclk_under_load(const uint16_t* d_array, uint64_t n, int launc
  * File format written by benchmark/flagstats.cpp:119-138 and read at :311-316: a sequence of
  *   int32 uncompressed_size, int32 compressed_size, <raw LZ4 block>   (little-endian; not LZ4 frames).
  * The LZ4 path decodes blocks on `threads` host threads (<= 0: up to 24) into pinned chunk buffers,
- * overlapped with the H2D copy and K1/K2 of earlier chunks; out[32] += counters of every flag
+ * overlapped with the H2D copy and K1/K2 of earlier chunks -- or, for files of 1.5 GiB and more (knob "lz4_decoder"),
+ * sends the file over PCIe as it is and decodes the blocks on the GPU; out[32] += counters of every flag
  * (a block contributes uncompressed_size >> 1 flags, as benchmark/flagstats.cpp:323). */
 typedef struct FLAGSTATS_blockfile_stats {
     uint64_t n_flags, n_blocks, compressed_bytes, uncompressed_bytes;
@@ -270,9 +271,10 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
  * report of `bench decompress -s` (block file) / `-S` (raw file) needs, benchmark/flagstats.cpp:577-588 */
 int FLAGSTATS_hip_blockfile_superset(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 int FLAGSTATS_hip_file_raw_superset(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
-/* EXPERIMENT (flagstat_lz4_gpu.hip): the same LZ4 block image with the decode ON THE GPU -- the compressed image goes over
- * PCIe, one wave decodes one block through LDS, K1 counts the decoded buffer.  Synchronous; out[32] += counters.  Kept as
- * a measured alternative to the host pipeline above (profiles/r03/gpu_lz4_*.log), not used by the file entries. */
+/* The GPU LZ4 decoder called directly, with its own statistics (flagstat_lz4_gpu.hip): the compressed image goes over PCIe
+ * in pieces, one wave decodes one block through LDS as soon as its piece has landed, K1 counts the decoded buffer.
+ * Synchronous; out[32] += counters.  This is what FLAGSTATS_hip_blockfile* / blockimage_lz4 run for large LZ4 files
+ * (knob "lz4_decoder"); measurements: profiles/r03/gpu_lz4_4GiB.log, lz4_decoder_sweep.log. */
 typedef struct FLAGSTATS_gpu_lz4_stats {
     uint64_t n_blocks, n_flags, bad_blocks, compressed_bytes, decoded_bytes;
     double h2d_ms, decode_ms, count_ms;            /* stream-event times of the three phases */
