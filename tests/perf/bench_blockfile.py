@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--chunk-mib", default="64")
     ap.add_argument("--image", action="store_true", help="also time FLAGSTATS_hip_blockimage_lz4 on the file read into memory "
                                                          "(no pread of the compressed payload in the workers)")
+    ap.add_argument("--gpu-decode", action="store_true", help="add a row per mode with the LZ4 blocks decoded on the GPU")
     ap.add_argument("--no-serial", action="store_true", help="skip the serial host loops of the reference shape")
     args = ap.parse_args()
     import oracle
@@ -69,8 +70,15 @@ def main():
     rows = []
     image = np.fromfile(path, dtype=np.uint8) if args.image else None
     modes = ["file"] + (["image"] if args.image else [])
-    for mode, cm, th in [(m, int(c), int(t)) for m in modes for c in args.chunk_mib.split(",") for t in args.threads.split(",")]:
+    # this script measures the HOST-THREAD decode pipeline (thread counts, chunk sizes); --gpu-decode adds one row per mode
+    # with the blocks decoded on the GPU (what the entries do by default for files of 1.5 GiB and more)
+    lib.FLAGSTATS_hip_set(b"lz4_decoder", 0)
+    sweep = [(m, int(c), int(t), 0) for m in modes for c in args.chunk_mib.split(",") for t in args.threads.split(",")]
+    if args.gpu_decode and args.mode != "zstd":
+        sweep += [(m, int(args.chunk_mib.split(",")[0]), 0, 1) for m in modes]
+    for mode, cm, th, dec in sweep:
         lib.FLAGSTATS_hip_set(b"chunk_flags", cm << 19)
+        lib.FLAGSTATS_hip_set(b"lz4_decoder", dec)
         best = None
         for rep in range(3):
             t0 = time.perf_counter()
@@ -87,11 +95,12 @@ def main():
             if best is None or dt < best[0]:
                 best = (dt, st)
         dt, st = best
-        rows.append({"mode": mode, "chunk_MiB": cm, "threads": st["threads"], "wall_s": round(dt, 4), "Gflags_s": round(n / dt / 1e9, 2),
+        rows.append({"mode": mode, "decoder": "gpu" if st.get("gpu_decode") else "host threads", "chunk_MiB": cm, "threads": st["threads"], "wall_s": round(dt, 4), "Gflags_s": round(n / dt / 1e9, 2),
                      "compressed_GB_s": round(size / dt / 1e9, 2), "decode_cpu_s": round(st["decode_cpu_s"], 3), "setup_s": round(st["setup_s"], 4), "wait_decode_s": round(st["wait_decode_s"], 4), "wait_copy_s": round(st["wait_copy_s"], 4),
                      "decode_GB_s_per_thread": round(2 * n / max(st["decode_cpu_s"], 1e-9) / 1e9, 2)})
         print(rows[-1], flush=True)
 
+    lib.FLAGSTATS_hip_set(b"lz4_decoder", 2)
     if args.no_serial or args.mode == "zstd":
         print(json.dumps({"workload": "%d NA12878-like flags, %d-byte LZ4-%s-%d blocks" % (n, bt.BLOCK_BYTES, args.mode, args.level),
                           "file_bytes": size, "product": rows}))
