@@ -21,6 +21,8 @@
 #include <cstring>
 #include <vector>
 #include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <chrono>
 #include <thread>
 #include <unistd.h>
@@ -443,75 +445,130 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         if (readers > 16) readers = 16;
         if (readers < 1) readers = 1;
     }
-    uint64_t spans = 0;
-    // file bytes [lo, hi) -> d_comp[lo, hi)
-    auto send = [&](uint64_t lo, uint64_t hi) -> int {
-        if (img) {
-            hipError_t e_ = hipMemcpyAsync(d_comp + lo, img + lo, hi - lo, hipMemcpyHostToDevice, s);
-            return e_ == hipSuccess ? 0 : fail_hip("hipMemcpyAsync(block image piece)", e_);
-        }
-        for (uint64_t at = lo; at < hi; at += span_cap, ++spans) {
-            const uint64_t len = hi - at < span_cap ? hi - at : span_cap;
-            const int pb = static_cast<int>(spans % 3);
-            if (spans >= 3) {
-                hipError_t e_ = hipEventSynchronize(pin_free[pb]);  // the copy that last used this buffer has left the host
-                if (e_ != hipSuccess) return fail_hip("hipEventSynchronize(pinned span)", e_);
-            }
-            const uint64_t share = ((len + static_cast<uint64_t>(readers) - 1) / static_cast<uint64_t>(readers) + 4095) & ~4095ull;
-            std::atomic<int> failed{0};
-            auto read_share = [&](uint64_t o) {
-                uint64_t end = o + share < len ? o + share : len;
-                while (o < end) {
-                    const ssize_t r = pread(in.fd, pinned[pb] + o, end - o, static_cast<off_t>(file_lo + at + o));
-                    if (r <= 0) {
-                        failed.store(1);
-                        return;
-                    }
-                    o += static_cast<uint64_t>(r);
-                }
-            };
-            std::vector<std::thread> pool;
-            for (uint64_t o = share; o < len; o += share) pool.emplace_back(read_share, o);
-            read_share(0);
-            for (std::thread& t : pool) t.join();
-            if (failed.load()) return fail_text("block file: short read");
-            hipError_t e_ = hipMemcpyAsync(d_comp + at, pinned[pb], len, hipMemcpyHostToDevice, s);
-            if (e_ == hipSuccess) e_ = hipEventRecord(pin_free[pb], s);
-            if (e_ != hipSuccess) return fail_hip("hipMemcpyAsync(block file span)", e_);
-        }
-        return 0;
-    };
     LZG_TRY(hipEventRecord(ev[0], s));
     for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamWaitEvent(dec_stream[i], ev[0], 0));  // index on the device, status preset
-    uint64_t first = 0;
-    uint32_t pieces_done = 0;
-    for (uint32_t c = 0; c < npieces && first < blocks.size(); ++c) {
-        // piece c: blocks [first, last), split by compressed bytes
+    // pieces: blocks [first, last) = segment bytes [lo, hi), split by compressed bytes
+    struct Piece {
+        uint64_t first, last, lo, hi;
+    };
+    std::vector<Piece> pieces;
+    for (uint64_t first = 0; pieces.size() < npieces && first < blocks.size();) {
+        const uint64_t c = pieces.size();
         const uint64_t target = bytes / npieces * (c + 1);
         uint64_t last = first + 1;
         while (last < blocks.size() && (c + 1 == npieces || blocks[last].src_off + blocks[last].src_len <= target)) ++last;
-        const uint64_t lo = blocks[first].src_off - 8, hi = blocks[last - 1].src_off + blocks[last - 1].src_len;
-        rc = send(lo, hi);
-        if (rc) {
-            cleanup();
-            return rc;
-        }
-        LZG_TRY(hipEventRecord(landed[c], s));
-        hipStream_t ds = dec_stream[c % nstreams];
-        LZG_TRY(hipStreamWaitEvent(ds, landed[c], 0));
-        const dim3 grid(static_cast<uint32_t>(last - first));
-        if (prof)
-            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024, true>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
-                               d_status + first, d_tally);
-        else if (!big_ring)
-            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
-                               d_status + first, d_tally);
-        else
-            hipLaunchKernelGGL((fsk::lz4_decode_wave<16384, 4096>), grid, dim3(64), 0, ds, d_comp, d_blocks + first, d_out,
-                               d_status + first, d_tally);
-        LZG_TRY(hipGetLastError());
+        pieces.push_back(Piece{first, last, blocks[first].src_off - 8, blocks[last - 1].src_off + blocks[last - 1].src_len});
         first = last;
-        ++pieces_done;
+    }
+    const uint32_t pieces_done = static_cast<uint32_t>(pieces.size());
+    // piece c has been queued on the copy stream: decode its blocks behind it
+    auto launch_piece = [&](uint32_t c) -> int {
+        hipError_t e_ = hipEventRecord(landed[c], s);
+        hipStream_t ds = dec_stream[c % nstreams];
+        if (e_ == hipSuccess) e_ = hipStreamWaitEvent(ds, landed[c], 0);
+        if (e_ != hipSuccess) return fail_hip("hipEventRecord / hipStreamWaitEvent(piece landed)", e_);
+        const Piece& pc = pieces[c];
+        const dim3 grid(static_cast<uint32_t>(pc.last - pc.first));
+        if (prof)
+            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024, true>), grid, dim3(64), 0, ds, d_comp, d_blocks + pc.first, d_out,
+                               d_status + pc.first, d_tally);
+        else if (!big_ring)
+            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024>), grid, dim3(64), 0, ds, d_comp, d_blocks + pc.first, d_out,
+                               d_status + pc.first, d_tally);
+        else
+            hipLaunchKernelGGL((fsk::lz4_decode_wave<16384, 4096>), grid, dim3(64), 0, ds, d_comp, d_blocks + pc.first, d_out,
+                               d_status + pc.first, d_tally);
+        e_ = hipGetLastError();
+        return e_ == hipSuccess ? 0 : fail_hip("lz4_decode_wave launch", e_);
+    };
+    if (img) {
+        for (uint32_t c = 0; c < pieces.size() && !rc; ++c) {
+            hipError_t e_ = hipMemcpyAsync(d_comp + pieces[c].lo, img + pieces[c].lo, pieces[c].hi - pieces[c].lo, hipMemcpyHostToDevice, s);
+            rc = e_ == hipSuccess ? launch_piece(c) : fail_hip("hipMemcpyAsync(block image piece)", e_);
+        }
+    } else {
+        // File mode.  The pieces are cut into spans of one pinned buffer; a pool of `readers` threads preads span i + 1
+        // (every thread its share) while this thread queues the copy of span i; a buffer is refilled once the copy that
+        // last used it has left the host.  (Threads started per span cost a third of the read time: r03, 83 -> 7x ms.)
+        struct Span {
+            uint64_t at, len;
+            int ends_piece;  // piece that is complete once this span is queued, or -1
+        };
+        std::vector<Span> spans;
+        for (uint32_t c = 0; c < pieces.size(); ++c)
+            for (uint64_t at = pieces[c].lo; at < pieces[c].hi; at += span_cap) {
+                const uint64_t len = pieces[c].hi - at < span_cap ? pieces[c].hi - at : span_cap;
+                spans.push_back(Span{at, len, at + len == pieces[c].hi ? static_cast<int>(c) : -1});
+            }
+        std::mutex m;
+        std::condition_variable cv_work, cv_done;
+        size_t released = 0;                       // spans [0, released) may be read
+        std::vector<int> done(spans.size(), 0);    // reader threads finished per span
+        bool stop = false, failed = false;
+        auto reader = [&](int t) {
+            for (size_t i = 0; i < spans.size(); ++i) {
+                {
+                    std::unique_lock<std::mutex> ul(m);
+                    cv_work.wait(ul, [&] { return released > i || stop; });
+                    if (stop) return;
+                }
+                const Span& sp = spans[i];
+                const uint64_t share = ((sp.len + static_cast<uint64_t>(readers) - 1) / static_cast<uint64_t>(readers) + 4095) & ~4095ull;
+                uint64_t o = share * static_cast<uint64_t>(t);
+                const uint64_t end = o + share < sp.len ? o + share : sp.len;
+                bool ok = true;
+                uint8_t* base = pinned[i % 3];
+                while (o < end) {
+                    const ssize_t r = pread(in.fd, base + o, end - o, static_cast<off_t>(file_lo + sp.at + o));
+                    if (r <= 0) {
+                        ok = false;
+                        break;
+                    }
+                    o += static_cast<uint64_t>(r);
+                }
+                std::lock_guard<std::mutex> g(m);
+                if (!ok) failed = true;
+                if (++done[i] == readers) cv_done.notify_one();
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 0; t < readers && !spans.empty(); ++t) pool.emplace_back(reader, t);
+        auto queue_span = [&](size_t i) -> int {
+            {
+                std::unique_lock<std::mutex> ul(m);
+                cv_done.wait(ul, [&] { return done[i] == readers; });
+                if (failed) return fail_text("block file: short read");
+            }
+            hipError_t e_ = hipMemcpyAsync(d_comp + spans[i].at, pinned[i % 3], spans[i].len, hipMemcpyHostToDevice, s);
+            if (e_ == hipSuccess) e_ = hipEventRecord(pin_free[i % 3], s);
+            if (e_ != hipSuccess) return fail_hip("hipMemcpyAsync(block file span)", e_);
+            return spans[i].ends_piece >= 0 ? launch_piece(static_cast<uint32_t>(spans[i].ends_piece)) : 0;
+        };
+        for (size_t i = 0; i < spans.size() && !rc; ++i) {
+            if (i >= 3) {
+                hipError_t e_ = hipEventSynchronize(pin_free[i % 3]);  // the copy of span i - 3 has left this buffer
+                if (e_ != hipSuccess) rc = fail_hip("hipEventSynchronize(pinned span)", e_);
+            }
+            if (!rc) {
+                {
+                    std::lock_guard<std::mutex> g(m);
+                    released = i + 1;
+                }
+                cv_work.notify_all();
+                if (i >= 1) rc = queue_span(i - 1);
+            }
+        }
+        if (!rc && !spans.empty()) rc = queue_span(spans.size() - 1);
+        {
+            std::lock_guard<std::mutex> g(m);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (std::thread& t : pool) t.join();
+    }
+    if (rc) {
+        cleanup();
+        return rc;
     }
     LZG_TRY(hipEventRecord(ev[1], s));  // every piece has landed
     for (uint32_t i = 0; i < nstreams; ++i) {
