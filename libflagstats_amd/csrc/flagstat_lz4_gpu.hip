@@ -148,13 +148,15 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
             const uint32_t gsrck = opk - offk;  // source offset in the block's output (far matches read it from global memory)
             const uint64_t farm = __builtin_amdgcn_ballot_w64(fark) & ((1ull << nb) - 1ull);
             const uint32_t row = lane >> 4, col = lane & 15u;
+            const uint32_t src_end = fark ? 0u : endk - offk;  // (far sources lie in flushed output: never after P)
+            const uint64_t never = __builtin_amdgcn_ballot_w64(mlk > 16u) | (~0ull << nb);
             uint32_t k0 = 0;
             while (k0 < nb) {
                 const uint32_t P = __builtin_amdgcn_readlane(opk, k0);  // first output byte of the pass
-                // (bitwise on purpose: no short-circuit branches in the wave's critical path)
-                const uint64_t brk = __builtin_amdgcn_ballot_w64(
-                    static_cast<bool>((lane >= k0) & ((lane >= nb) | (lane >= k0 + 4u) | (mlk > 16u) | (!fark & (endk - offk > P)))));
-                const uint32_t k1 = static_cast<uint32_t>(__builtin_ctzll(brk));  // (bits nb.. are set: k1 <= nb)
+                // a pass ends at the first sequence that cannot join: a near source that ends after P, or (fixed per batch)
+                // 17..18 bytes / past the batch; four rows at most
+                const uint64_t reads_pass = __builtin_amdgcn_ballot_w64(src_end > P);
+                const uint32_t k1 = k0 + static_cast<uint32_t>(__builtin_ctz(static_cast<uint32_t>((reads_pass | never) >> k0) | 16u));
                 if (PROF) { if (k1 == k0) ++n_single; else ++n_pass; }
                 if (k1 == k0) {
                     // alone: 17..18 bytes, or a source that overlaps its own output (period off < ml)
