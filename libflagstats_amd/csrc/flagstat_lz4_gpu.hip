@@ -48,10 +48,12 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
                                                      unsigned long long* __restrict__ tally)
 {
     constexpr uint32_t kRingMask = RING - 1, kFlush = RING / 4;
-    constexpr uint32_t kLgRing = RING == 8192 ? 13 : 14;
-    static_assert(RING == 8192 || RING == 16384, "pass rows pack two ring offsets and a length into 32 bits");
+    static_assert(RING <= 65536, "pass rows keep a ring offset in 16 bits");
     constexpr uint32_t kScratch = RING + INWIN + 16;  // 64 bytes nobody reads: where idle lanes of a copy pass point
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kScratch + 64];
+    constexpr uint32_t kRows = kScratch + 64;          // 32 x 2 words + 32 words: the batch's per-sequence rows and far sources
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kRows + 384];
+    uint2* const tab_row = reinterpret_cast<uint2*>(lds + kRows);
+    uint32_t* const tab_far = reinterpret_cast<uint32_t*>(lds + kRows + 256);
     uint8_t* const ring = lds;
     uint8_t* const inw = lds + RING;
     const GpuBlock b = blocks[blockIdx.x];
@@ -139,17 +141,29 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
             // sequences of a flag stream do not read what the few sequences before them wrote, so a pass takes up to four
             // consecutive sequences whose sources all end at or before the pass's first output byte -- or lie behind the
             // ring, in flushed output -- gives each a row of 16 lanes, and copies all of them with ONE read and ONE write
-            // (matches of 17 or 18 bytes and matches that overlap their own output, off < ml, go alone).  What a row needs
+            // (matches of 17 or 18 bytes, matches that overlap their own output, off < ml, and matches within 16 bytes
+            // of the ring's end go alone).  What a row needs
             // -- ring offsets of source and destination, length -- is packed into one word per sequence above
             // and read out of lanes k0..k0+3 as scalars.
             const bool fark = offk > RING - 64u;
             const uint32_t endk = opk + mlk;  // where sequence k's output ends
-            const uint32_t rowk = ((opk - offk) & kRingMask) | ((opk & kRingMask) << kLgRing) | (((mlk - 1u) & 15u) << (2u * kLgRing));
+            // row words: ring offset of the source | (length - 1) << 16; ring offset of the destination.  A row adds its
+            // column without masking, so a sequence within 16 bytes of the end of the ring goes alone (0.4 %)
+            const uint32_t srck = (opk - offk) & kRingMask, dstk = opk & kRingMask;
+            const bool wrapk = (srck > RING - 16u) | (dstk > RING - 16u);
             const uint32_t gsrck = opk - offk;  // source offset in the block's output (far matches read it from global memory)
             const uint64_t farm = __builtin_amdgcn_ballot_w64(fark) & ((1ull << nb) - 1ull);
             const uint32_t row = lane >> 4, col = lane & 15u;
             const uint32_t src_end = fark ? 0u : endk - offk;  // (far sources lie in flushed output: never after P)
-            const uint64_t never = __builtin_amdgcn_ballot_w64(mlk > 16u) | (~0ull << nb);
+            const uint64_t never = __builtin_amdgcn_ballot_w64((mlk > 16u) | wrapk) | (~0ull << nb);
+            // Rows get their sequence's word through LDS: the batch's 16 words are stored once, and each pass's `row + k0`
+            // gather is ONE read issued a pass ahead (before the previous pass's ring read, so it returns first) instead of
+            // four v_readlane and a three-way select per pass -- the decoder is issue-bound when every wave slot is taken.
+            if (lane < 32u) {
+                tab_row[lane] = lane < 16u ? make_uint2(srck | ((mlk - 1u) << 16), dstk) : make_uint2(0u, 0u);
+                tab_far[lane] = lane < 16u ? gsrck : 0u;
+            }
+            uint2 v_next = tab_row[row];
             uint32_t k0 = 0;
             while (k0 < nb) {
                 const uint32_t P = __builtin_amdgcn_readlane(opk, k0);  // first output byte of the pass
@@ -172,22 +186,20 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
                             ring[(P + lane) & kRingMask] = __hip_atomic_load(&dst[P - off + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     }
                     ++k0;
+                    v_next = tab_row[k0 + row];
                     continue;
                 }
-                const uint32_t s0 = __builtin_amdgcn_readlane(rowk, k0), s1 = __builtin_amdgcn_readlane(rowk, k0 + 1u);
-                const uint32_t s2 = __builtin_amdgcn_readlane(rowk, k0 + 2u), s3 = __builtin_amdgcn_readlane(rowk, k0 + 3u);
-                const uint32_t v = row == 0u ? s0 : row == 1u ? s1 : row == 2u ? s2 : s3;
-                const bool act = row < k1 - k0 && col <= (v >> (2u * kLgRing));
+                const uint2 v = v_next;
+                v_next = tab_row[k1 + row];  // (k1 + row <= 19: the table has 32 entries)
+                const bool act = (row < k1 - k0) & (col <= (v.x >> 16));
                 // (lanes with nothing to copy read and write a scratch byte of their own: straight-line LDS traffic, so the
                 // only wait the compiler needs is the one between this read and this write)
-                const uint32_t ra = act ? ((v & kRingMask) + col) & kRingMask : kScratch + lane;
-                const uint32_t wa = act ? (((v >> kLgRing) & kRingMask) + col) & kRingMask : kScratch + lane;
+                const uint32_t ra = act ? (v.x & 0xFFFFu) + col : kScratch + lane;
+                const uint32_t wa = act ? v.y + col : kScratch + lane;
                 uint32_t d = lds[ra];
                 const uint32_t farbits = static_cast<uint32_t>(farm >> k0) & ((1u << (k1 - k0)) - 1u);
                 if (farbits) {
-                    const uint32_t g0 = __builtin_amdgcn_readlane(gsrck, k0), g1 = __builtin_amdgcn_readlane(gsrck, k0 + 1u);
-                    const uint32_t g2 = __builtin_amdgcn_readlane(gsrck, k0 + 2u), g3 = __builtin_amdgcn_readlane(gsrck, k0 + 3u);
-                    const uint32_t gv = row == 0u ? g0 : row == 1u ? g1 : row == 2u ? g2 : g3;
+                    const uint32_t gv = tab_far[k0 + row];
                     if (act && ((farbits >> row) & 1u)) d = __hip_atomic_load(&dst[gv + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                     nfar += static_cast<uint32_t>(__builtin_popcount(farbits));
                 }
