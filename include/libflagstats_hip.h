@@ -185,6 +185,10 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *                    chunks (decoded flags cross PCIe), 1 = decode on the GPU (the compressed bytes cross PCIe, one wave
  *                    per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default 1.5 GiB
  *                    compressed: the measured break-even, profiles/r03/lz4_decoder_sweep.log), on the host below.  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
+ *   "lz4_gpu_keep_bytes" device memory the GPU LZ4 decoder may keep between calls (default 16 GiB; its two buffers -- a
+ *                    segment's compressed and decoded bytes -- are reused by the next file: allocating them right after
+ *                    freeing them was measured to stall ~0.5 s on the driver wiping the freed memory); 0 = free after
+ *                    every call.  Read-only "lz4_gpu_kept_bytes": what is held now (FLAGSTATS_hip_shutdown frees it)
  * Read-only keys of FLAGSTATS_hip_get: "grid" (K1 workgroups), "numa_node" (of the default device),
  * "host_chunks" / "host_overlapped" (last multi-chunk host-pointer call on the default engine: chunks
  * submitted / chunks handed over while the previous chunk's copy + kernel were still in flight).

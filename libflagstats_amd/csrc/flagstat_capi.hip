@@ -200,6 +200,8 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         k.lz4_decoder = static_cast<int>(value);
     } else if (!std::strcmp(key, "lz4_gpu_min_bytes")) {
         k.lz4_gpu_min_bytes = value;
+    } else if (!std::strcmp(key, "lz4_gpu_keep_bytes")) {
+        k.lz4_gpu_keep_bytes = value;
     } else if (!std::strcmp(key, "numa")) {
         if (value > 1) return fail_text("numa must be 0 or 1");
         k.numa = static_cast<int>(value);
@@ -238,6 +240,14 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "numa")) return static_cast<uint64_t>(k.numa.load());
     if (!std::strcmp(key, "lz4_decoder")) return static_cast<uint64_t>(k.lz4_decoder.load());
     if (!std::strcmp(key, "lz4_gpu_min_bytes")) return k.lz4_gpu_min_bytes.load();
+    if (!std::strcmp(key, "lz4_gpu_keep_bytes")) return k.lz4_gpu_keep_bytes.load();
+    if (!std::strcmp(key, "lz4_gpu_kept_bytes")) {
+        if (fsint::default_device() < 0) return 0;
+        Engine* e = fsint::default_engine();
+        if (!e) return 0;
+        std::lock_guard<std::mutex> lk(e->mu);
+        return e->lz4_cap[0] + e->lz4_cap[1];
+    }
     if (!std::strcmp(key, "fence_free_events")) return static_cast<uint64_t>(k.fence_free_events.load());
     if (!std::strcmp(key, "grid")) {
         if (fsint::default_device() < 0) return 0;

@@ -47,6 +47,7 @@ struct Knobs {
     std::atomic<int> on_error{1};                 // legacy uint32 entry points: 1 = abort after the message, 0 = return non-zero
     std::atomic<int> lz4_decoder{2};              // LZ4 block files: 0 = decode on host threads, 1 = on the GPU, 2 = by size
     std::atomic<uint64_t> lz4_gpu_min_bytes{3ull << 29};  // lz4_decoder 2: GPU decode for files of at least this many bytes
+    std::atomic<uint64_t> lz4_gpu_keep_bytes{16ull << 30};  // device bytes the GPU LZ4 decoder may keep between calls
     std::atomic<int> fence_free_events{0};        // stream_wait_stream: 1 = ordering events without the system-scope fence (opt-in)
     std::atomic<int> numa{1};                     // block pipeline: 1 = pinned chunks + decoders on the GPU's NUMA node
 };
@@ -84,6 +85,8 @@ struct Engine {
     uint64_t host_chunks = 0;                      // last multi-chunk host call: chunks submitted ...
     uint64_t host_overlapped = 0;                  // ... and how many were submitted while the previous one was still in flight
     void* pinned[3] = {nullptr, nullptr, nullptr}; // block-file chunk buffers, kept across calls
+    uint8_t* lz4_buf[2] = {nullptr, nullptr};      // GPU LZ4 decoder: compressed / decoded bytes of a segment, kept across calls
+    uint64_t lz4_cap[2] = {0, 0};                  // (knob "lz4_gpu_keep_bytes": freed after a call when larger than that)
     uint64_t pinned_bytes = 0;
     static constexpr int kOrderEvents = 16;        // device-scope ordering events (no timing, no system fence), used round robin
     hipEvent_t order_ev[kOrderEvents] = {};

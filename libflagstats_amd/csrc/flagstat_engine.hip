@@ -93,6 +93,7 @@ void read_env_knobs()
         g_knobs.fence_free_events = static_cast<int>(env_u64("FLAGSTATS_HIP_FENCE_FREE_EVENTS", static_cast<uint64_t>(g_knobs.fence_free_events)));
         g_knobs.lz4_decoder = static_cast<int>(env_u64("FLAGSTATS_HIP_LZ4_DECODER", static_cast<uint64_t>(g_knobs.lz4_decoder)));
         g_knobs.lz4_gpu_min_bytes = env_u64("FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES", g_knobs.lz4_gpu_min_bytes);
+        g_knobs.lz4_gpu_keep_bytes = env_u64("FLAGSTATS_HIP_LZ4_GPU_KEEP_BYTES", g_knobs.lz4_gpu_keep_bytes);
         const char* oe = std::getenv("FLAGSTATS_HIP_ON_ERROR");
         if (oe && *oe) g_knobs.on_error = (!std::strcmp(oe, "return") || !std::strcmp(oe, "0")) ? 0 : 1;
     });
@@ -129,6 +130,11 @@ void release_engine_resources(Engine& e)
         if (e.d_out[i]) (void)hipFree(e.d_out[i]);
         if (e.stage[i]) (void)hipFree(e.stage[i]);
         if (e.stream[i]) (void)hipStreamDestroy(e.stream[i]);
+    }
+    for (int i = 0; i < 2; ++i) {
+        if (e.lz4_buf[i]) (void)hipFree(e.lz4_buf[i]);
+        e.lz4_buf[i] = nullptr;
+        e.lz4_cap[i] = 0;
     }
     for (auto& kv : e.user_ws)
         if (kv.second.partials) (void)hipFree(kv.second.partials);

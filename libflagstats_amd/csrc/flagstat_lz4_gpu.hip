@@ -379,8 +379,6 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
                 (void)hipStreamSynchronize(x);
                 (void)hipStreamDestroy(x);
             }
-        if (d_comp) (void)hipFree(d_comp);
-        if (d_out) (void)hipFree(d_out);
         if (d_blocks) (void)hipFree(d_blocks);
         if (d_status) (void)hipFree(d_status);
         if (d_tally) (void)hipFree(d_tally);
@@ -404,8 +402,19 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     } while (0)
     hipStream_t s = e.stream[0];
     for (hipEvent_t& x : ev) LZG_TRY(hipEventCreate(&x));
-    LZG_TRY(hipMalloc(&d_comp, bytes + 64));
-    LZG_TRY(hipMalloc(&d_out, dpos + 16));
+    // the two large buffers belong to the engine and are reused by the next segment / file (knob "lz4_gpu_keep_bytes")
+    const uint64_t want[2] = {bytes + 64, dpos + 16};
+    for (int i = 0; i < 2; ++i)
+        if (e.lz4_cap[i] < want[i]) {
+            if (e.lz4_buf[i]) LZG_TRY(hipFree(e.lz4_buf[i]));
+            e.lz4_buf[i] = nullptr;
+            e.lz4_cap[i] = 0;
+            const uint64_t cap = (want[i] + (64ull << 20) - 1) & ~((64ull << 20) - 1);
+            LZG_TRY(hipMalloc(&e.lz4_buf[i], cap));
+            e.lz4_cap[i] = cap;
+        }
+    d_comp = e.lz4_buf[0];
+    d_out = e.lz4_buf[1];
     LZG_TRY(hipMalloc(&d_blocks, blocks.size() * sizeof(fsk::GpuBlock)));
     LZG_TRY(hipMalloc(&d_status, blocks.size() * sizeof(uint32_t)));
     LZG_TRY(hipMalloc(&d_tally, 16 * 8));
@@ -718,6 +727,13 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         if (rc) return rc;
         ++stats->segments;
         b0 = b1;
+    }
+    if (e.lz4_cap[0] + e.lz4_cap[1] > knobs().lz4_gpu_keep_bytes.load()) {
+        for (int i = 0; i < 2; ++i) {
+            if (e.lz4_buf[i]) (void)hipFree(e.lz4_buf[i]);
+            e.lz4_buf[i] = nullptr;
+            e.lz4_cap[i] = 0;
+        }
     }
     stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     return 0;

@@ -397,3 +397,26 @@ def test_gpu_decoder_goes_through_large_files_in_segments(gpu_decoder, tmp_path,
         monkeypatch.delenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES")
         sup_one, _ = blockfile.flagstat_file(str(path), 2, superset=True)
         assert np.array_equal(sup, sup_one)
+
+
+def test_gpu_decoder_keeps_its_device_buffers_between_calls(gpu_decoder):
+    """The decoder's two large device buffers are reused by the next call (knob lz4_gpu_keep_bytes, default 16 GiB) and
+    given back when they exceed the limit; stale bytes of an earlier, larger file must not leak into a later one."""
+    import oracle
+    from libflagstats_amd import blockfile
+    hip = gpu_decoder
+    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_keep_bytes") == 16 << 30
+    big = oracle.generate(oracle.GEN_UNIFORM, 41, 0xFFFF, 0, 512000 * 6)
+    got, _ = blockfile.flagstat_lz4_image(bt.block_file_image(big), 2)
+    assert np.array_equal(got, expect(big, bt.BLOCK_BYTES)[0])
+    kept = hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes")
+    assert kept >= 2 * big.nbytes                      # compressed (incompressible: ~ raw size) + decoded
+    # a smaller file with odd block sizes in the same buffers: the dropped odd bytes and the slack between blocks count nothing
+    small = oracle.generate(oracle.GEN_UNIFORM, 42, 0xFFFF, 0, 300001)
+    got, st = blockfile.flagstat_lz4_image(bt.block_file_image(small, block_bytes=9999), 2)
+    assert st["gpu_decode"] == 1 and np.array_equal(got, expect(small, 9999)[0])
+    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == kept
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", 0) == 0
+    got, _ = blockfile.flagstat_lz4_image(bt.block_file_image(small, block_bytes=9999), 2)
+    assert np.array_equal(got, expect(small, 9999)[0]) and hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", 16 << 30) == 0
