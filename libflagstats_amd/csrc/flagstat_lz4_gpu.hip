@@ -50,10 +50,11 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
     constexpr uint32_t kRingMask = RING - 1, kFlush = RING / 4;
     static_assert(RING <= 65536, "pass rows keep a ring offset in 16 bits");
     constexpr uint32_t kScratch = RING + INWIN + 16;  // 64 bytes nobody reads: where idle lanes of a copy pass point
-    constexpr uint32_t kRows = kScratch + 64;          // 32 x 2 words + 32 words: the batch's per-sequence rows and far sources
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kRows + 384];
+    constexpr uint32_t kRows = kScratch + 64;          // 20 x 2 words + 20 words: the batch's per-sequence rows and far sources
+    constexpr uint32_t kTabN = 20;                     // (16 sequences + the 3 entries a pass may read past them; 17 waves per CU
+    __shared__ __attribute__((aligned(16))) uint8_t lds[kRows + kTabN * 12];  //  need <= 9637 bytes per wave: this is 9536)
     uint2* const tab_row = reinterpret_cast<uint2*>(lds + kRows);
-    uint32_t* const tab_far = reinterpret_cast<uint32_t*>(lds + kRows + 256);
+    uint32_t* const tab_far = reinterpret_cast<uint32_t*>(lds + kRows + kTabN * 8);
     uint8_t* const ring = lds;
     uint8_t* const inw = lds + RING;
     const GpuBlock b = blocks[blockIdx.x];
@@ -159,7 +160,7 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
             // Rows get their sequence's word through LDS: the batch's 16 words are stored once, and each pass's `row + k0`
             // gather is ONE read issued a pass ahead (before the previous pass's ring read, so it returns first) instead of
             // four v_readlane and a three-way select per pass -- the decoder is issue-bound when every wave slot is taken.
-            if (lane < 32u) {
+            if (lane < kTabN) {
                 tab_row[lane] = lane < 16u ? make_uint2(srck | ((mlk - 1u) << 16), dstk) : make_uint2(0u, 0u);
                 tab_far[lane] = lane < 16u ? gsrck : 0u;
             }
@@ -190,7 +191,7 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
                     continue;
                 }
                 const uint2 v = v_next;
-                v_next = tab_row[k1 + row];  // (k1 + row <= 19: the table has 32 entries)
+                v_next = tab_row[k1 + row];  // (k1 + row <= 19 < kTabN)
                 const bool act = (row < k1 - k0) & (col <= (v.x >> 16));
                 // (lanes with nothing to copy read and write a scratch byte of their own: straight-line LDS traffic, so the
                 // only wait the compiler needs is the one between this read and this write)
