@@ -170,7 +170,7 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
                 const uint32_t P = __builtin_amdgcn_readlane(opk, k0);  // first output byte of the pass
                 // a pass ends at the first sequence that cannot join: a near source that ends after P, or (fixed per batch)
                 // 17..18 bytes / past the batch; four rows at most
-                const uint64_t reads_pass = __builtin_amdgcn_ballot_w64(src_end > P);
+                const uint64_t reads_pass = __builtin_amdgcn_uicmp(src_end, P, 34 /* unsigned > : the lane mask straight from v_cmp */);
                 const uint32_t k1 = k0 + static_cast<uint32_t>(__builtin_ctz(static_cast<uint32_t>((reads_pass | never) >> k0) | 16u));
                 if (PROF) { if (k1 == k0) ++n_single; else ++n_pass; }
                 if (k1 == k0) {
