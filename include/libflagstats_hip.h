@@ -183,7 +183,7 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *                    system-scope fence (default 0)
  *   "lz4_decoder"    LZ4 block files (FLAGSTATS_hip_blockfile*, blockimage_lz4): 0 = decode on host threads into pinned
  *                    chunks (decoded flags cross PCIe), 1 = decode on the GPU (the compressed bytes cross PCIe, one wave
- *                    per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default 1.5 GiB
+ *                    per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default 1 GiB
  *                    compressed: the measured break-even, profiles/r03/lz4_decoder_sweep.log), on the host below.  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
  *   "lz4_gpu_keep_bytes" device memory the GPU LZ4 decoder may keep between calls (default 16 GiB; its two buffers -- a
  *                    segment's compressed and decoded bytes -- are reused by the next file: allocating them right after
@@ -242,7 +242,7 @@ int FLAGSTATS_hip_sclk_under_load(const uint16_t* d_array, uint64_t n, int launc
  * File format written by benchmark/flagstats.cpp:119-138 and read at :311-316: a sequence of
  *   int32 uncompressed_size, int32 compressed_size, <raw LZ4 block>   (little-endian; not LZ4 frames).
  * The LZ4 path decodes blocks on `threads` host threads (<= 0: up to 24) into pinned chunk buffers,
- * overlapped with the H2D copy and K1/K2 of earlier chunks -- or, for files of 1.5 GiB and more (knob "lz4_decoder"),
+ * overlapped with the H2D copy and K1/K2 of earlier chunks -- or, for files of 1 GiB and more (knob "lz4_decoder"),
  * sends the file over PCIe as it is and decodes the blocks on the GPU; out[32] += counters of every flag
  * (a block contributes uncompressed_size >> 1 flags, as benchmark/flagstats.cpp:323). */
 typedef struct FLAGSTATS_blockfile_stats {

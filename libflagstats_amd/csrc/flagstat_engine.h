@@ -46,7 +46,7 @@ struct Knobs {
     std::atomic<uint64_t> chunk_flags{32ull << 20};  // host streaming chunk: 32 Mi flags = 64 MiB
     std::atomic<int> on_error{1};                 // legacy uint32 entry points: 1 = abort after the message, 0 = return non-zero
     std::atomic<int> lz4_decoder{2};              // LZ4 block files: 0 = decode on host threads, 1 = on the GPU, 2 = by size
-    std::atomic<uint64_t> lz4_gpu_min_bytes{3ull << 29};  // lz4_decoder 2: GPU decode for files of at least this many bytes
+    std::atomic<uint64_t> lz4_gpu_min_bytes{1ull << 30};  // lz4_decoder 2: GPU decode for files of at least this many bytes
     std::atomic<uint64_t> lz4_gpu_keep_bytes{16ull << 30};  // device bytes the GPU LZ4 decoder may keep between calls
     std::atomic<int> fence_free_events{0};        // stream_wait_stream: 1 = ordering events without the system-scope fence (opt-in)
     std::atomic<int> numa{1};                     // block pipeline: 1 = pinned chunks + decoders on the GPU's NUMA node

@@ -71,7 +71,7 @@ def main():
     image = np.fromfile(path, dtype=np.uint8) if args.image else None
     modes = ["file"] + (["image"] if args.image else [])
     # this script measures the HOST-THREAD decode pipeline (thread counts, chunk sizes); --gpu-decode adds one row per mode
-    # with the blocks decoded on the GPU (what the entries do by default for files of 1.5 GiB and more)
+    # with the blocks decoded on the GPU (what the entries do by default for files of 1 GiB and more)
     lib.FLAGSTATS_hip_set(b"lz4_decoder", 0)
     sweep = [(m, int(c), int(t), 0) for m in modes for c in args.chunk_mib.split(",") for t in args.threads.split(",")]
     if args.gpu_decode and args.mode != "zstd":
