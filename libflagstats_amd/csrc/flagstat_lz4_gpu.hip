@@ -1,19 +1,25 @@
-// flagstat_lz4_gpu.hip -- EXPERIMENT: the LZ4 block decode of row f1 moved to the GPU.
+// flagstat_lz4_gpu.hip -- the LZ4 block decode of row f1 ON the GPU (behind the block-file entries
+// for large files, knob "lz4_decoder").
 //
 // The reference's block reader decodes every block with liblz4's LZ4_decompress_safe on the host
-// (benchmark/flagstats.cpp:311-316); this repo's product path (flagstat_blocks.hip) does the same on N host threads and
-// is PCIe-bound on the DECODED bytes.  Sending the compressed bytes instead (4.2x fewer for NA12878-like flags) only pays
-// if the GPU can decode fast enough, and an LZ4 block is one serial chain of ~156,000 sequences per 1,024,000-byte block.
-// DESIGN.md (r02) rejected the idea on an estimate; this file is the measurement: ONE WAVE PER BLOCK,
-//   * compressed bytes staged through a 4 KiB LDS window (coalesced 16-byte loads),
-//   * the last 16 KiB of output kept in an LDS ring, so a match copy is ds_read -> ds_write for every offset up to
-//     16,320; farther matches read the already flushed output back from global memory,
-//   * the ring flushed to global memory 4 KiB at a time with coalesced 16-byte stores,
+// (benchmark/flagstats.cpp:311-316); the host pipeline of this repo (flagstat_blocks.hip) does the same on N host threads
+// and is PCIe-bound on the DECODED bytes (27 Gflags/s).  Here the file crosses PCIe as it is (2.1-3.4x fewer bytes) and is
+// decoded on the device.  An LZ4 block is one serial chain of ~156,000 sequences per 1,024,000-byte block, so it is ONE
+// WAVE PER BLOCK -- a wave decodes ~35 MB/s, but 4,352 of them are resident at once:
+//   * compressed bytes staged through a 1 KiB LDS window (coalesced 16-byte loads),
+//   * the last 8 KiB of output kept in an LDS ring, so a match copy is ds_read -> ds_write for every offset up to
+//     8,128; farther matches read the already flushed output back from global memory,
+//   * up to 16 bare sequences (3 input bytes each) parsed AT ONCE by 16 lanes, output positions by a DPP prefix sum,
+//   * copied in PASSES of up to four sequences that do not read each other's output: one LDS read and one write for
+//     all of them, each on a row of 16 lanes, their words gathered through a small LDS table read one pass ahead,
+//   * the ring flushed to global memory 2 KiB at a time with coalesced 16-byte stores,
 //   * every index masked or checked: a malformed block sets its status word and stops, it cannot fault.
-// 20.5 KiB of LDS per wave = 7 waves per CU = 1792 blocks in flight on the chip.
-// Entry: FLAGSTATS_hip_blockimage_lz4_gpu (H2D of the image, decode kernel, K1 over the decoded buffer, timings).
-// Result (profiles/r03/gpu_lz4_*.log) decides whether it replaces the host pipeline; it is not wired into
-// FLAGSTATS_hip_blockfile*.
+// 9.3 KiB of LDS per wave = 17 waves per CU.  The decoder is bound by the chain of dependent LDS round trips of a wave
+// when the chip is half empty and by instruction issue when every wave slot is taken: both reward fewer instructions
+// per sequence, which is what every step from the first version (161 ms for a 4 GiB file) to this one (30 ms) did.
+// Host side: lz4_gpu_run (pieces of the file on the copy stream, one decode launch per piece on its own stream, one
+// K1/K2 pass; file mode with a reader pool; segments for files larger than the device).  Measurements:
+// profiles/r03/gpu_lz4_4GiB.log, lz4_decoder_sweep.log; DESIGN.md section 4.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -40,8 +46,8 @@ struct GpuBlock {
 };
 
 // RING: bytes of recent output kept in LDS (matches up to RING - 64 back are LDS -> LDS); INWIN: staged input window.
-// 16 KiB + 4 KiB = 7 waves per CU (1792 blocks in flight); 8 KiB + 1 KiB = 17 per CU (4352: a 4 GiB file's 4195 blocks
-// all at once), at the price of more matches that reach behind the ring.
+// 8 KiB + 1 KiB (the default) = 17 waves per CU (4352 blocks in flight: a 4 GiB file's 4195 blocks all at once);
+// 16 KiB + 4 KiB (env FLAGSTATS_HIP_GPU_LZ4_RING=16, tuning) = 7 per CU, fewer matches behind the ring, measured slower.
 template <uint32_t RING, uint32_t INWIN, bool PROF = false>
 __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks,
                                                      uint8_t* __restrict__ out, uint32_t* __restrict__ status,
