@@ -119,9 +119,9 @@ __global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict_
         // ---- fast path: batches of up to 16 "bare" sequences -- no literals, match of 4..18 bytes -- which is 95 % of an
         // LZ4-fast FLAG stream.  A bare sequence is exactly 3 input bytes, so lanes 0..15 parse 16 of them AT ONCE (one
         // unaligned LDS read each), a 16-lane prefix sum of the match lengths gives every sequence its output position,
-        // and one ballot says how many leading sequences of the batch are bare and valid.  Only the copies themselves
-        // run in order, one per step, steered by scalars read out of the parsed lanes; a match behind the ring reads the
-        // flushed output (RING - 64 > kFlush + 16 * 18: that source always lies below `flushed`).
+        // and one ballot says how many leading sequences of the batch are bare and valid.  The copies follow in passes
+        // (below); a match behind the ring reads the flushed output (RING - 64 > kFlush + 16 * 18: that source always
+        // lies below `flushed`).
         for (;;) {
             tick();
             cover(64);
