@@ -168,8 +168,10 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *   "numa"           1 (default): pinned buffers and block-decoder threads are placed on the GPU's host NUMA node
  *   "group_min_grid" K1's atomic epilogue goes through the workspace's 8 per-XCD copies (8 x 2 contended adds on the
  *                    caller's counters per launch instead of one pair per workgroup) from this many workgroups on
- *                    (default 64; 0 = any grid), as long as a workgroup has at most 24 steps (arrays up to ~192 MiB:
- *                    beyond that the workgroups finish too far apart for the contention to matter)
+ *                    (default 64; 0 = any grid), as long as a workgroup has at most "group_max_steps" steps
+ *   "group_max_steps" (default 24 = arrays up to ~192 MiB on 256 CUs; beyond that the workgroups finish too far apart
+ *                    for the contention to matter and the one-level form is 0.5-1.6 % faster).  Read-only key
+ *                    "last_k1_two_level": 1 if the most recent K1 launch took the two-level form
  *   "small_flags"    host-pointer calls of up to this many flags (default 1048576, maximum 4194304) are copied by the CPU --
  *                    no copy call -- into the engine's input buffer: fine-grained device memory written through the PCIe BAR
  *                    (knob "small_bar", default 1, needs a large-BAR device; read-only key "small_in_is_device" says which), else

@@ -173,6 +173,9 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         if (value > 0xFFFFFFFFull) return fail_text("group_min_grid must fit 32 bits");
         k.group_min_grid = static_cast<uint32_t>(value);
         fsk_set_group_min_grid(k.group_min_grid.load());
+    } else if (!std::strcmp(key, "group_max_steps")) {
+        k.group_max_steps = value;
+        fsk_set_group_max_steps(value);
     } else if (!std::strcmp(key, "dyn_lg_queues")) {
         if (value > 4) return fail_text("dyn_lg_queues must be 0..4");
         k.dyn_lgq = static_cast<uint32_t>(value);
@@ -224,6 +227,8 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "dyn_min_steps")) return k.dyn_min_steps.load();
     if (!std::strcmp(key, "dyn_lg_queues")) return k.dyn_lgq.load();
     if (!std::strcmp(key, "group_min_grid")) return k.group_min_grid.load();
+    if (!std::strcmp(key, "group_max_steps")) return k.group_max_steps.load();
+    if (!std::strcmp(key, "last_k1_two_level")) return (fsk_last_mode() >> 3) & 1;
     if (!std::strcmp(key, "small_flags")) return k.small_flags.load();
     if (!std::strcmp(key, "small_bar")) return static_cast<uint64_t>(k.small_bar.load());
     if (!std::strcmp(key, "small_in_is_device")) {

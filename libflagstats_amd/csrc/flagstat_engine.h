@@ -40,6 +40,7 @@ struct Knobs {
     std::atomic<int> poll{1};                     // single-launch host calls wait by polling a completion word the kernel writes
     std::atomic<int> epoch_stagger{1};            // K1: waves of a workgroup flush their epochs at different steps
     std::atomic<uint32_t> group_min_grid{64};     // K1's atomic epilogue goes through per-XCD copies from this many workgroups on
+    std::atomic<uint64_t> group_max_steps{24};    // ... and only up to this many steps per workgroup (they finish together)
     std::atomic<int> fuse{0};                     // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
     std::atomic<int> epilogue{1};                 // accumulate form into device memory: 1 = K1 adds its workgroup totals to
                                                   // out[] with atomics (one launch), 0 = partials + K2

@@ -84,6 +84,8 @@ void read_env_knobs()
         fsk_set_epoch_stagger(g_knobs.epoch_stagger.load());
         g_knobs.group_min_grid = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_GROUP_MIN_GRID", g_knobs.group_min_grid));
         fsk_set_group_min_grid(g_knobs.group_min_grid.load());
+        g_knobs.group_max_steps = env_u64("FLAGSTATS_HIP_GROUP_MAX_STEPS", g_knobs.group_max_steps);
+        fsk_set_group_max_steps(g_knobs.group_max_steps.load());
         g_knobs.dyn_lgq = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_LG_QUEUES", g_knobs.dyn_lgq));
         fsk_set_dyn_queues(g_knobs.dyn_lgq.load());
         fsk_set_dyn(g_knobs.dyn_first_pct.load(), g_knobs.dyn_div.load(), g_knobs.dyn_cmax.load(), g_knobs.dyn_min_steps.load());

@@ -1034,10 +1034,17 @@ static std::atomic<int> g_epoch_stagger{1};          // K1 mode bit 4: waves of 
 
 extern "C" void fsk_set_epoch_stagger(int on) { g_epoch_stagger = on ? 1 : 0; }
 
-constexpr uint64_t kGroupMaxStepsPerWorkgroup = 24;  // <= 192 MiB on a 256-CU chip
-static std::atomic<uint32_t> g_group_min_grid{64};  // grids below this add straight to out[] (one level)
+// The two-level (per-XCD copies) epilogue pays where the workgroups of a launch finish together: many of them, few steps
+// each.  With more steps per workgroup the finish times drift apart by more than the adds take and the one-level form is
+// 0.5-1.6 % faster (profiles/r03/ab_two_level_epilogue.log, profiles/r04/ab_two_level_epilogue.log).
+static std::atomic<uint32_t> g_group_min_grid{64};   // grids below this add straight to out[] (one level)
+static std::atomic<uint64_t> g_group_max_steps{24};  // ... and so do launches with more steps per workgroup (24: <= 192 MiB on 256 CUs)
 
 extern "C" void fsk_set_group_min_grid(uint32_t min_grid) { g_group_min_grid = min_grid; }
+extern "C" void fsk_set_group_max_steps(uint64_t max_steps) { g_group_max_steps = max_steps; }
+
+static std::atomic<int> g_last_mode{0};  // K1 mode word of the most recent launch (tests: which epilogue form ran)
+extern "C" int fsk_last_mode(void) { return g_last_mode.load(); }
 
 static std::atomic<uint32_t> g_dyn_first_pct{75}, g_dyn_div{4}, g_dyn_cmax{32}, g_dyn_min_steps{32}, g_dyn_lgq{3};
 
@@ -1119,7 +1126,9 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     a.sig = fsk::HostSignal{signal_word, signal_value};
     if (signal_word && !(a.mode & 1)) return hipErrorInvalidValue;  // pairs carry "=" results only
     if (signal_word && (a.mode & 1) && !(a.mode & 4) && grid == 1 && !((variant >> 9) & 1)) a.mode |= 32;
-    if ((a.mode & 4) && grid >= g_group_min_grid.load() && d_ticket != nullptr && !(a.mode & 4096)) a.mode |= 8;
+    if ((a.mode & 4) && grid >= g_group_min_grid.load() && (a.nsteps + grid - 1) / grid <= g_group_max_steps.load() &&
+        d_ticket != nullptr && !(a.mode & 4096))
+        a.mode |= 8;
     if (variant & 128) {
         // round 0 takes first_pct of the full steps; too few steps per workgroup to be worth balancing: all of them
         const uint64_t full = a.fast_end - a.fast_begin;
@@ -1141,6 +1150,7 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
         a.dyn.lgq = lgq;
     }
     if (((variant >> 9) & 1) && d_ticket == nullptr) return hipErrorInvalidValue;
+    g_last_mode.store(a.mode, std::memory_order_relaxed);
     hipError_t e;
     // variant bits: 1 = non-temporal loads, 2 = chain depth 7 (else 8), 4 = register prefetch,
     // 8 = waves interleaved at 1 KiB within a step, 16 = rolling re-issue of load registers,

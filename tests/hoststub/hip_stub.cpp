@@ -471,6 +471,8 @@ int fsk_tuning_build(void) { return 0; }
 void fsk_set_dyn(uint32_t, uint32_t, uint32_t, uint32_t) {}
 void fsk_set_dyn_queues(uint32_t) {}
 void fsk_set_group_min_grid(uint32_t) {}
+void fsk_set_group_max_steps(uint64_t) {}
+int fsk_last_mode(void) { return 0; }
 void fsk_set_epoch_stagger(int) {}
 
 }  // extern "C"

@@ -177,6 +177,43 @@ def test_two_level_atomic_epilogue(hip, knob, group_knob, min_grid, n):
     assert not got[[i for i in range(32) if i not in LIVE]].any()
 
 
+@pytest.fixture()
+def steps_knob(hip):
+    old = hip.FLAGSTATS_hip_get(b"group_max_steps")
+    yield lambda v: hip.FLAGSTATS_hip_set(b"group_max_steps", v)
+    hip.FLAGSTATS_hip_set(b"group_max_steps", old)
+
+
+def test_two_level_epilogue_step_limit_default(hip):
+    """The shipped rule (flagstat_kernels.hip fsk_launch): per-XCD copies only for grids >= 64 workgroups of <= 24 steps."""
+    assert hip.FLAGSTATS_hip_get(b"group_min_grid") == 64
+    assert hip.FLAGSTATS_hip_get(b"group_max_steps") == 24
+
+
+@pytest.mark.parametrize("steps_per_wg, max_steps, two_level", [
+    (3, 2, 0), (3, 3, 1), (3, 24, 1), (24, 24, 1), (25, 24, 0), (25, 2 ** 40, 1), (1, 0, 0)])
+def test_two_level_epilogue_each_side_of_the_step_limit(hip, knob, group_knob, steps_knob, steps_per_wg, max_steps, two_level):
+    """A launch on each side of group_max_steps: the form the rule picks is the one that ran (read back from the
+    launcher), and both give the oracle's counters three launches in a row on one workspace."""
+    import torch
+
+    import oracle
+    from libflagstats_amd import device
+    grid = hip.FLAGSTATS_hip_get(b"grid")
+    assert grid >= 64
+    assert knob(1) == 0 and group_knob(64) == 0 and steps_knob(max_steps) == 0
+    n = 16384 * grid * (steps_per_wg - 1) + 16384 * (grid - 1) + 4097   # ceil(steps / grid) == steps_per_wg, ragged last step
+    t = torch.empty(n, dtype=torch.int16, device="cuda:0")
+    device.generate_torch(t, device.GEN_UNIFORM, seed=5 + steps_per_wg, mask=0xFFFF)
+    out = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+    for _ in range(3):
+        device.count_torch(t, out)
+        assert hip.FLAGSTATS_hip_get(b"last_k1_two_level") == two_level, (steps_per_wg, max_steps)
+    torch.cuda.synchronize()
+    want = oracle.flagstat_generated(oracle.GEN_UNIFORM, 5 + steps_per_wg, 0xFFFF, 0, n)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), 3 * want)
+
+
 def test_two_level_epilogue_two_streams_one_counter_array(hip, knob, group_knob):
     """Each stream has its own workspace (copies, tickets); both add to ONE out[32] through their group leaders."""
     import torch
