@@ -169,8 +169,8 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *   "group_min_grid" K1's atomic epilogue goes through the workspace's 8 per-XCD copies (8 x 2 contended adds on the
  *                    caller's counters per launch instead of one pair per workgroup) from this many workgroups on
  *                    (default 64; 0 = any grid), as long as a workgroup has at most "group_max_steps" steps
- *   "group_max_steps" (default 24 = arrays up to ~192 MiB on 256 CUs; beyond that the workgroups finish too far apart
- *                    for the contention to matter and the one-level form is 0.5-1.6 % faster).  Read-only key
+ *   "group_max_steps" (default 40 = arrays up to ~320 MiB on 256 CUs; the two forms measure equal at 48 steps, and beyond
+ *                    that the workgroups finish too far apart for the contention to matter: one level is 0.3-0.8 % faster).  Read-only key
  *                    "last_k1_two_level": 1 if the most recent K1 launch took the two-level form
  *   "small_flags"    host-pointer calls of up to this many flags (default 1048576, maximum 4194304) are copied by the CPU --
  *                    no copy call -- into the engine's input buffer: fine-grained device memory written through the PCIe BAR

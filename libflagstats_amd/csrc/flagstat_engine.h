@@ -40,13 +40,14 @@ struct Knobs {
     std::atomic<int> poll{1};                     // single-launch host calls wait by polling a completion word the kernel writes
     std::atomic<int> epoch_stagger{1};            // K1: waves of a workgroup flush their epochs at different steps
     std::atomic<uint32_t> group_min_grid{64};     // K1's atomic epilogue goes through per-XCD copies from this many workgroups on
-    std::atomic<uint64_t> group_max_steps{24};    // ... and only up to this many steps per workgroup (they finish together)
+    std::atomic<uint64_t> group_max_steps{40};    // ... and only up to this many steps per workgroup (they finish together)
     std::atomic<int> fuse{0};                     // 1: K1 finalises itself (last-arriving workgroup), no K2 launch
     std::atomic<int> epilogue{1};                 // accumulate form into device memory: 1 = K1 adds its workgroup totals to
                                                   // out[] with atomics (one launch), 0 = partials + K2
     std::atomic<uint64_t> chunk_flags{32ull << 20};  // host streaming chunk: 32 Mi flags = 64 MiB
     std::atomic<int> on_error{1};                 // legacy uint32 entry points: 1 = abort after the message, 0 = return non-zero
     std::atomic<int> lz4_decoder{2};              // LZ4 block files: 0 = decode on host threads, 1 = on the GPU, 2 = by size
+    std::atomic<int> lz4_gpu_kernel{0};           // GPU LZ4 decode kernel: 0 = workgroup pipeline (r04), 1 = one wave per block (r03)
     std::atomic<uint64_t> lz4_gpu_min_bytes{1ull << 30};  // lz4_decoder 2: GPU decode for files of at least this many bytes
     std::atomic<uint64_t> lz4_gpu_keep_bytes{16ull << 30};  // device bytes the GPU LZ4 decoder may keep between calls
     std::atomic<int> fence_free_events{0};        // stream_wait_stream: 1 = ordering events without the system-scope fence (opt-in)

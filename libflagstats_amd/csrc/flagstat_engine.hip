@@ -94,6 +94,7 @@ void read_env_knobs()
         g_knobs.numa = static_cast<int>(env_u64("FLAGSTATS_HIP_NUMA", static_cast<uint64_t>(g_knobs.numa)));
         g_knobs.fence_free_events = static_cast<int>(env_u64("FLAGSTATS_HIP_FENCE_FREE_EVENTS", static_cast<uint64_t>(g_knobs.fence_free_events)));
         g_knobs.lz4_decoder = static_cast<int>(env_u64("FLAGSTATS_HIP_LZ4_DECODER", static_cast<uint64_t>(g_knobs.lz4_decoder)));
+        g_knobs.lz4_gpu_kernel = static_cast<int>(env_u64("FLAGSTATS_HIP_LZ4_GPU_KERNEL", static_cast<uint64_t>(g_knobs.lz4_gpu_kernel)));
         g_knobs.lz4_gpu_min_bytes = env_u64("FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES", g_knobs.lz4_gpu_min_bytes);
         g_knobs.lz4_gpu_keep_bytes = env_u64("FLAGSTATS_HIP_LZ4_GPU_KEEP_BYTES", g_knobs.lz4_gpu_keep_bytes);
         const char* oe = std::getenv("FLAGSTATS_HIP_ON_ERROR");

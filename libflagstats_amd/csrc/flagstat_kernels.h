@@ -75,7 +75,7 @@ void fsk_set_dyn(uint32_t first_pct, uint32_t div, uint32_t cmax, uint32_t min_s
 void fsk_set_dyn_queues(uint32_t lg_queues);
 // K1's direct epilogue adds to per-XCD copies first when the grid has at least this many workgroups (0: always)
 void fsk_set_group_min_grid(uint32_t min_grid);
-// ... and at most this many steps per workgroup (default 24); beyond that workgroups finish apart and add straight to out[]
+// ... and at most this many steps per workgroup (default 40); beyond that workgroups finish apart and add straight to out[]
 void fsk_set_group_max_steps(uint64_t max_steps_per_workgroup);
 int fsk_last_mode(void);                  // K1 mode word of the most recent fsk_launch (bit 3 = two-level epilogue); tests
 void fsk_set_epoch_stagger(int on);            // 1 (default): wave w of a workgroup starts its first epoch at step count 64 * w   // 2^lg_queues (<= 16) counters

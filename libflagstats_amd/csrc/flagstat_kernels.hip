@@ -1036,9 +1036,10 @@ extern "C" void fsk_set_epoch_stagger(int on) { g_epoch_stagger = on ? 1 : 0; }
 
 // The two-level (per-XCD copies) epilogue pays where the workgroups of a launch finish together: many of them, few steps
 // each.  With more steps per workgroup the finish times drift apart by more than the adds take and the one-level form is
-// 0.5-1.6 % faster (profiles/r03/ab_two_level_epilogue.log, profiles/r04/ab_two_level_epilogue.log).
+// 0.5-0.8 % faster (profiles/r04/ab_two_level_epilogue.log, ab_two_level_epilogue_crossover.log).
 static std::atomic<uint32_t> g_group_min_grid{64};   // grids below this add straight to out[] (one level)
-static std::atomic<uint64_t> g_group_max_steps{24};  // ... and so do launches with more steps per workgroup (24: <= 192 MiB on 256 CUs)
+static std::atomic<uint64_t> g_group_max_steps{40};  // ... and so do launches with more steps per workgroup (40: <= 320 MiB on 256 CUs;
+                                                     // the forms cross at 48, profiles/r04/ab_two_level_epilogue_crossover.log)
 
 extern "C" void fsk_set_group_min_grid(uint32_t min_grid) { g_group_min_grid = min_grid; }
 extern "C" void fsk_set_group_max_steps(uint64_t max_steps) { g_group_max_steps = max_steps; }

@@ -35,328 +35,8 @@
 
 #include "../../include/libflagstats_hip.h"
 #include "flagstat_engine.h"
+#include "flagstat_lz4_kernels.h"
 
-namespace fsk {
-
-struct GpuBlock {
-    uint64_t src_off;  // payload offset in the image
-    uint64_t dst_off;  // offset in the decoded buffer (multiple of 16)
-    uint32_t src_len;
-    uint32_t dst_len;
-};
-
-// RING: bytes of recent output kept in LDS (matches up to RING - 64 back are LDS -> LDS); INWIN: staged input window.
-// 8 KiB + 1 KiB (the default) = 17 waves per CU (4352 blocks in flight: a 4 GiB file's 4195 blocks all at once);
-// 16 KiB + 4 KiB (env FLAGSTATS_HIP_GPU_LZ4_RING=16, tuning) = 7 per CU, fewer matches behind the ring, measured slower.
-template <uint32_t RING, uint32_t INWIN, bool PROF = false>
-__global__ __launch_bounds__(64) void lz4_decode_wave(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks,
-                                                     uint8_t* __restrict__ out, uint32_t* __restrict__ status,
-                                                     unsigned long long* __restrict__ tally)
-{
-    constexpr uint32_t kRingMask = RING - 1, kFlush = RING / 4;
-    static_assert(RING <= 65536, "pass rows keep a ring offset in 16 bits");
-    constexpr uint32_t kScratch = RING + INWIN + 16;  // 64 bytes nobody reads: where idle lanes of a copy pass point
-    constexpr uint32_t kRows = kScratch + 64;          // 20 x 2 words + 20 words: the batch's per-sequence rows and far sources
-    constexpr uint32_t kTabN = 20;                     // (16 sequences + the 3 entries a pass may read past them; 17 waves per CU
-    __shared__ __attribute__((aligned(16))) uint8_t lds[kRows + kTabN * 12];  //  need <= 9637 bytes per wave: this is 9536)
-    uint2* const tab_row = reinterpret_cast<uint2*>(lds + kRows);
-    uint32_t* const tab_far = reinterpret_cast<uint32_t*>(lds + kRows + kTabN * 8);
-    uint8_t* const ring = lds;
-    uint8_t* const inw = lds + RING;
-    const GpuBlock b = blocks[blockIdx.x];
-    const uint8_t* src = comp + b.src_off;
-    uint8_t* dst = out + b.dst_off;
-    const uint32_t iend = b.src_len, oend = b.dst_len;
-    const uint32_t lane = threadIdx.x;
-    uint32_t ip = 0, op = 0, in_base = 0, in_valid = 0, flushed = 0;
-    uint32_t err = 0, nseq = 0, nfar = 0;
-    // PROF: wave cycles per phase (s_memtime), summed over all waves into tally[2..]
-    unsigned long long n_pass = 0, n_single = 0, t_lit = 0, n_lit = 0, t_copy = 0, t_far = 0, t_slow = 0, t_flush = 0, t_cover = 0, t_parse = 0, n_batch = 0, n_slow = 0, t_mark = 0;
-    auto tick = [&]() { if (PROF) t_mark = __builtin_readcyclecounter(); };
-    auto tock = [&](unsigned long long& acc) { if (PROF) { const unsigned long long now = __builtin_readcyclecounter(); acc += now - t_mark; t_mark = now; } };
-    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
-    const uint32_t magic = lane ? 65535u / lane + 1u : 0u;  // ceil(2^16 / lane): (j * magic) >> 16 == j / lane for j < 64
-
-    // make inw[] cover [ip, ip + need) (need <= 80) unless the block ends first
-    auto cover = [&](uint32_t need) {
-        if (ip + need <= in_base + in_valid || in_base + in_valid >= iend) return;
-        in_base = ip & ~15u;
-        uint32_t n = iend - in_base;
-        if (n > INWIN) n = INWIN;
-        for (uint32_t k = 0; k < INWIN; k += 1024) {
-            const uint32_t o = k + lane * 16;
-            if (o < n) *reinterpret_cast<uint4*>(&inw[o]) = *reinterpret_cast<const uint4*>(src + in_base + o);  // image is padded by 64 B
-        }
-        in_valid = n;  // (one wave: LDS operations execute in program order, no barrier needed)
-    };
-    auto in_byte = [&](uint32_t pos) -> uint32_t {
-        uint32_t i = pos - in_base;
-        if (i > INWIN + 15) i = INWIN + 15;  // cannot happen after cover(); keeps a logic error inside the array
-        return __builtin_amdgcn_readfirstlane(inw[i]);
-    };
-    // token and the two bytes behind it with ONE wait (the usual sequence of these streams has no literals, so they
-    // are its offset)
-    auto in_3bytes = [&](uint32_t pos) -> uint32_t {
-        uint32_t i = pos - in_base;
-        if (i > INWIN + 13) i = INWIN + 13;
-        const uint32_t v = inw[i] | (static_cast<uint32_t>(inw[i + 1]) << 8) | (static_cast<uint32_t>(inw[i + 2]) << 16);
-        return __builtin_amdgcn_readfirstlane(v);
-    };
-    // write the finished part of the ring to global memory, a quarter of the ring at a time
-    auto flush_to = [&](uint32_t upto) {
-        while (upto - flushed >= kFlush) {
-            for (uint32_t k = 0; k < kFlush; k += 1024) {
-                const uint32_t o = flushed + k + lane * 16;
-                *reinterpret_cast<uint4*>(dst + o) = *reinterpret_cast<const uint4*>(&ring[o & kRingMask]);
-            }
-            flushed += kFlush;
-            // a far match may read these bytes back through another lane: they must have left this wave first
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-    };
-
-    while (ip < iend && !err) {
-        // ---- fast path: batches of up to 16 "bare" sequences -- no literals, match of 4..18 bytes -- which is 95 % of an
-        // LZ4-fast FLAG stream.  A bare sequence is exactly 3 input bytes, so lanes 0..15 parse 16 of them AT ONCE (one
-        // unaligned LDS read each), a 16-lane prefix sum of the match lengths gives every sequence its output position,
-        // and one ballot says how many leading sequences of the batch are bare and valid.  The copies follow in passes
-        // (below); a match behind the ring reads the flushed output (RING - 64 > kFlush + 16 * 18: that source always
-        // lies below `flushed`).
-        for (;;) {
-            tick();
-            cover(64);
-            tock(t_cover);
-            const uint32_t in_limit = in_base + in_valid;
-            const uint32_t pos = ip + 3u * lane;
-            bool ok = lane < 16u && pos + 3u <= in_limit;
-            uint32_t w = 0xFFu;
-            if (ok) __builtin_memcpy(&w, &inw[pos - in_base], 4);               // token, offset lo, offset hi, (next token)
-            const uint32_t tok = w & 255u, offk = (w >> 8) & 0xFFFFu, mlk = tok + 4u;
-            uint32_t incl = ok ? mlk : 0u;
-            incl += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(incl), 0x111, 0xF, 0xF, false));  // row_shr:1
-            incl += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(incl), 0x112, 0xF, 0xF, false));  // row_shr:2
-            incl += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(incl), 0x114, 0xF, 0xF, false));  // row_shr:4
-            incl += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(incl), 0x118, 0xF, 0xF, false));  // row_shr:8
-            const uint32_t opk = op + incl - mlk;                                // where sequence k writes (if all before it are bare)
-            ok = ok && tok < 15u && offk != 0u && offk <= opk && opk + mlk <= oend;
-            const uint64_t bad = __builtin_amdgcn_ballot_w64(!ok);               // lanes >= 16 are never ok: bad != 0
-            const uint32_t nb = static_cast<uint32_t>(__builtin_ctzll(bad));     // leading bare sequences of this batch, 0..16
-            ++n_batch;
-            tock(t_parse);
-            // ---- the copies, in PASSES of up to four sequences (one wave decodes one block, so what bounds it is the chain of
-            // dependent LDS round trips, ~150 cycles each: one per sequence when they are copied one by one).  97 % of the
-            // sequences of a flag stream do not read what the few sequences before them wrote, so a pass takes up to four
-            // consecutive sequences whose sources all end at or before the pass's first output byte -- or lie behind the
-            // ring, in flushed output -- gives each a row of 16 lanes, and copies all of them with ONE read and ONE write
-            // (matches of 17 or 18 bytes, matches that overlap their own output, off < ml, and matches within 16 bytes
-            // of the ring's end go alone).  What a row needs
-            // -- ring offsets of source and destination, length -- is packed into one word per sequence above
-            // and read out of lanes k0..k0+3 as scalars.
-            const bool fark = offk > RING - 64u;
-            const uint32_t endk = opk + mlk;  // where sequence k's output ends
-            // row words: ring offset of the source | (length - 1) << 16; ring offset of the destination.  A row adds its
-            // column without masking, so a sequence within 16 bytes of the end of the ring goes alone (0.4 %)
-            const uint32_t srck = (opk - offk) & kRingMask, dstk = opk & kRingMask;
-            const bool wrapk = (srck > RING - 16u) | (dstk > RING - 16u);
-            const uint32_t gsrck = opk - offk;  // source offset in the block's output (far matches read it from global memory)
-            const uint64_t farm = __builtin_amdgcn_ballot_w64(fark) & ((1ull << nb) - 1ull);
-            const uint32_t row = lane >> 4, col = lane & 15u;
-            const uint32_t src_end = fark ? 0u : endk - offk;  // (far sources lie in flushed output: never after P)
-            const uint64_t never = __builtin_amdgcn_ballot_w64((mlk > 16u) | wrapk) | (~0ull << nb);
-            // Rows get their sequence's word through LDS: the batch's 16 words are stored once, and each pass's `row + k0`
-            // gather is ONE read issued a pass ahead (before the previous pass's ring read, so it returns first) instead of
-            // four v_readlane and a three-way select per pass -- the decoder is issue-bound when every wave slot is taken.
-            if (lane < kTabN) {
-                tab_row[lane] = lane < 16u ? make_uint2(srck | ((mlk - 1u) << 16), dstk) : make_uint2(0u, 0u);
-                tab_far[lane] = lane < 16u ? gsrck : 0u;
-            }
-            uint2 v_next = tab_row[row];
-            uint32_t k0 = 0;
-            while (k0 < nb) {
-                const uint32_t P = __builtin_amdgcn_readlane(opk, k0);  // first output byte of the pass
-                // a pass ends at the first sequence that cannot join: a near source that ends after P, or (fixed per batch)
-                // 17..18 bytes / past the batch; four rows at most
-                const uint64_t reads_pass = __builtin_amdgcn_uicmp(src_end, P, 34 /* unsigned > : the lane mask straight from v_cmp */);
-                const uint32_t k1 = k0 + static_cast<uint32_t>(__builtin_ctz(static_cast<uint32_t>((reads_pass | never) >> k0) | 16u));
-                if (PROF) { if (k1 == k0) ++n_single; else ++n_pass; }
-                if (k1 == k0) {
-                    // alone: 17..18 bytes, or a source that overlaps its own output (period off < ml)
-                    const uint32_t off = __builtin_amdgcn_readlane(offk, k0), ml = __builtin_amdgcn_readlane(mlk, k0);
-                    if (off <= RING - 64u) {
-                        uint32_t m = __builtin_amdgcn_readlane(magic, off & 63u);
-                        if (off >= 64u) m = 0;
-                        const uint32_t j = lane - __umul24(__umul24(lane, m) >> 16, off);  // lane mod off
-                        if (lane < ml) ring[(P + lane) & kRingMask] = ring[(P - off + j) & kRingMask];
-                    } else {
-                        ++nfar;
-                        if (lane < ml)
-                            ring[(P + lane) & kRingMask] = __hip_atomic_load(&dst[P - off + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    }
-                    ++k0;
-                    v_next = tab_row[k0 + row];
-                    continue;
-                }
-                const uint2 v = v_next;
-                v_next = tab_row[k1 + row];  // (k1 + row <= 19 < kTabN)
-                const bool act = (row < k1 - k0) & (col <= (v.x >> 16));
-                // (lanes with nothing to copy read and write a scratch byte of their own: straight-line LDS traffic, so the
-                // only wait the compiler needs is the one between this read and this write)
-                const uint32_t ra = act ? (v.x & 0xFFFFu) + col : kScratch + lane;
-                const uint32_t wa = act ? v.y + col : kScratch + lane;
-                uint32_t d = lds[ra];
-                const uint32_t farbits = static_cast<uint32_t>(farm >> k0) & ((1u << (k1 - k0)) - 1u);
-                if (farbits) {
-                    const uint32_t gv = tab_far[k0 + row];
-                    if (act && ((farbits >> row) & 1u)) d = __hip_atomic_load(&dst[gv + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    nfar += static_cast<uint32_t>(__builtin_popcount(farbits));
-                }
-                lds[wa] = static_cast<uint8_t>(d);
-                k0 = k1;
-            }
-            if (nb) op = __builtin_amdgcn_readlane(endk, nb - 1u);
-            tock(t_copy);
-            ip += 3u * nb;
-            nseq += nb;
-            flush_to(op);
-            tock(t_flush);
-            if (nb == 16u) continue;
-            // The sequence that ended the batch.  The usual one has 1..14 literals and a short match: its token is
-            // already here (lane nb's word), ONE LDS read brings the literals and the offset behind them into lanes, the
-            // literals go from those lanes to the ring, then the match as above.  Everything else -- long literal runs,
-            // long matches, the end of the block or of the staged window -- goes to the general code below.
-            const uint32_t tq = __builtin_amdgcn_readlane(w, nb) & 255u;        // (0xFF when lane nb had nothing to read)
-            const uint32_t ll = tq >> 4, mq = (tq & 15u) + 4u;
-            if (ll == 0u || ll == 15u || mq == 19u || ip + 3u + ll > in_limit || ll + mq > oend - op) break;
-            uint32_t lb = 0;
-            if (lane < ll + 2u) lb = inw[ip + 1u + lane - in_base];
-            const uint32_t offq = __builtin_amdgcn_readlane(lb, ll) | (__builtin_amdgcn_readlane(lb, ll + 1u) << 8);
-            if (lane < ll) ring[(op + lane) & kRingMask] = static_cast<uint8_t>(lb);
-            op += ll;
-            if (offq == 0u || offq > op) { err = 5; break; }
-            if (offq <= RING - 64u) {
-                uint32_t m = __builtin_amdgcn_readlane(magic, offq & 63u);
-                if (offq >= 64u) m = 0;
-                const uint32_t jq = lane - __umul24(__umul24(lane, m) >> 16, offq);
-                if (lane < mq) ring[(op + lane) & kRingMask] = ring[(op - offq + jq) & kRingMask];
-            } else {
-                ++nfar;
-                if (lane < mq)
-                    ring[(op + lane) & kRingMask] = __hip_atomic_load(&dst[op - offq + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            op += mq;
-            ip += 3u + ll;
-            ++nseq;
-            ++n_lit;
-            flush_to(op);
-            tock(t_lit);
-        }
-        if (ip >= iend) break;
-        cover(24);
-        tick();
-        ++n_slow;
-        const uint32_t t3 = in_3bytes(ip);
-        const uint32_t token = t3 & 255u;
-        ++ip;
-        ++nseq;
-        // ---- literals
-        uint32_t ll = token >> 4;
-        if (ll == 15) {
-            uint32_t e;
-            do {
-                cover(1);
-                if (ip >= iend) { err = 1; break; }
-                e = in_byte(ip);
-                ++ip;
-                ll += e;
-            } while (e == 255);
-            if (err) break;
-        }
-        if (ll > iend - ip || ll > oend - op) { err = 2; break; }
-        const bool bare = ll == 0;
-        while (ll) {
-            const uint32_t n = ll < 64 ? ll : 64;
-            cover(n);
-            if (lane < n) ring[(op + lane) & kRingMask] = inw[ip + lane - in_base];
-            ip += n;
-            op += n;
-            ll -= n;
-            flush_to(op);
-        }
-        if (ip >= iend) break;  // the last sequence has no match
-        // ---- match
-        uint32_t off;
-        if (bare) {
-            off = t3 >> 8;  // already here
-            if (ip + 2 > iend) { err = 3; break; }
-        } else {
-            cover(2);
-            if (ip + 2 > iend) { err = 3; break; }
-            off = in_byte(ip) | (in_byte(ip + 1) << 8);
-        }
-        ip += 2;
-        uint32_t ml = token & 15u;
-        if (ml == 15) {
-            uint32_t e;
-            do {
-                cover(1);
-                if (ip >= iend) { err = 4; break; }
-                e = in_byte(ip);
-                ++ip;
-                ml += e;
-            } while (e == 255);
-            if (err) break;
-        }
-        ml += 4;
-        if (off == 0 || off > op || ml > oend - op) { err = 5; break; }
-        const bool near = off <= RING - 64;
-        nfar += near ? 0u : 1u;
-        while (ml) {
-            const uint32_t n = ml < 64 ? ml : 64;
-            // out[op + j] = out[op + j - off]; for off < n the source repeats with period off
-            const uint32_t j = (off >= n) ? lane : lane % off;
-            uint32_t v = 0;
-            if (near) {
-                if (lane < n) v = ring[(op - off + j) & kRingMask];
-            } else {
-                // farther back than the ring: already flushed (op - off + n <= flushed); device-scope load, past the L1
-                if (lane < n) v = __hip_atomic_load(&dst[op - off + j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-            if (lane < n) ring[(op + lane) & kRingMask] = static_cast<uint8_t>(v);
-            op += n;
-            ml -= n;
-            flush_to(op);
-        }
-        tock(t_slow);
-    }
-    if (!err && op != oend) err = 6;
-    // tail of the ring.  An odd trailing byte of a block is dropped like the reference's N = size >> 1
-    // (benchmark/flagstats.cpp:323): it stays zero in the padded slot, so the counting kernel sees no stray flag.
-    if (!err) {
-        for (uint32_t o = flushed + lane; o < (op & ~1u); o += 64) dst[o] = ring[o & kRingMask];
-    }
-    if (lane == 0) {
-        status[blockIdx.x] = err;
-        atomicAdd(&tally[0], static_cast<unsigned long long>(nseq));
-        atomicAdd(&tally[1], static_cast<unsigned long long>(nfar));
-        if (PROF) {
-            atomicAdd(&tally[2], t_copy);
-            atomicAdd(&tally[3], t_far);
-            atomicAdd(&tally[4], t_slow);
-            atomicAdd(&tally[5], t_flush);
-            atomicAdd(&tally[6], t_cover);
-            atomicAdd(&tally[7], t_parse);
-            atomicAdd(&tally[8], n_batch);
-            atomicAdd(&tally[9], n_slow);
-            atomicAdd(&tally[10], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
-            atomicAdd(&tally[11], t_lit);
-            atomicAdd(&tally[12], n_lit);
-            atomicAdd(&tally[13], n_pass);
-            atomicAdd(&tally[14], n_single);
-        }
-    }
-}
-
-}  // namespace fsk
 
 namespace fsint {
 
@@ -424,18 +104,20 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     d_out = e.lz4_buf[1];
     LZG_TRY(hipMalloc(&d_blocks, blocks.size() * sizeof(fsk::GpuBlock)));
     LZG_TRY(hipMalloc(&d_status, blocks.size() * sizeof(uint32_t)));
-    LZG_TRY(hipMalloc(&d_tally, 16 * 8));
+    LZG_TRY(hipMalloc(&d_tally, fsk::kLz4TallyWords * 8));
     // only the slack between blocks (16-byte slots) and behind dropped odd bytes needs zero flags: blocks of the reference's
     // writer are whole multiples of 16 bytes, so this is normally nothing at all
     bool ragged = false;
     for (const fsk::GpuBlock& b : blocks) ragged = ragged || (b.dst_len & 15u);
     if (ragged) LZG_TRY(hipMemsetAsync(d_out, 0, dpos + 16, s));
     LZG_TRY(hipMemsetAsync(d_status, 0xFF, blocks.size() * sizeof(uint32_t), s));
-    LZG_TRY(hipMemsetAsync(d_tally, 0, 16 * 8, s));
+    LZG_TRY(hipMemsetAsync(d_tally, 0, fsk::kLz4TallyWords * 8, s));
     LZG_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(fsk::GpuBlock), hipMemcpyHostToDevice, s));
     // env FLAGSTATS_HIP_GPU_LZ4_RING = 8 (default) | 16: KiB of recent output per wave in LDS (see lz4_decode_wave)
     const char* rk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_RING");
     const bool big_ring = rk && std::atoi(rk) == 16;
+    // knob "lz4_gpu_kernel": 0 = the workgroup pipeline (three waves per block, 64 KiB window in LDS), 1 = r03's wave per block
+    const int kernel = knobs().lz4_gpu_kernel.load() == 0 ? fsk::LZ4K_WORKGROUP : (big_ring ? fsk::LZ4K_WAVE_RING16 : fsk::LZ4K_WAVE);
     const char* pk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");  // tuning: per-phase wave cycles on stderr
     const bool prof = pk && std::atoi(pk) != 0;
     // pieces: a decode launch lasts as long as its slowest block whatever its size (one wave decodes ~35 MB/s), and
@@ -498,18 +180,9 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         if (e_ == hipSuccess) e_ = hipStreamWaitEvent(ds, landed[c], 0);
         if (e_ != hipSuccess) return fail_hip("hipEventRecord / hipStreamWaitEvent(piece landed)", e_);
         const Piece& pc = pieces[c];
-        const dim3 grid(static_cast<uint32_t>(pc.last - pc.first));
-        if (prof)
-            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024, true>), grid, dim3(64), 0, ds, d_comp, d_blocks + pc.first, d_out,
-                               d_status + pc.first, d_tally);
-        else if (!big_ring)
-            hipLaunchKernelGGL((fsk::lz4_decode_wave<8192, 1024>), grid, dim3(64), 0, ds, d_comp, d_blocks + pc.first, d_out,
-                               d_status + pc.first, d_tally);
-        else
-            hipLaunchKernelGGL((fsk::lz4_decode_wave<16384, 4096>), grid, dim3(64), 0, ds, d_comp, d_blocks + pc.first, d_out,
-                               d_status + pc.first, d_tally);
-        e_ = hipGetLastError();
-        return e_ == hipSuccess ? 0 : fail_hip("lz4_decode_wave launch", e_);
+        e_ = fsk_lz4_decode(kernel, d_comp, d_blocks + pc.first, static_cast<uint32_t>(pc.last - pc.first), d_out, d_status + pc.first,
+                            d_tally, prof ? 1 : 0, ds);
+        return e_ == hipSuccess ? 0 : fail_hip("LZ4 decode kernel launch", e_);
     };
     if (img) {
         for (uint32_t c = 0; c < pieces.size() && !rc; ++c) {
@@ -615,7 +288,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     }
     LZG_TRY(hipEventRecord(ev[3], s));
     LZG_TRY(hipMemcpyAsync(e.h_out, e.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
-    unsigned long long tally[16] = {0};
+    unsigned long long tally[fsk::kLz4TallyWords] = {0};
     LZG_TRY(hipMemcpyAsync(tally, d_tally, sizeof tally, hipMemcpyDeviceToHost, s));
     std::vector<uint32_t> st(blocks.size());
     LZG_TRY(hipMemcpyAsync(st.data(), d_status, st.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
@@ -628,14 +301,23 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     LZG_TRY(hipEventElapsedTime(&cnt, ev[2], ev[3]));
     LZG_TRY(hipEventElapsedTime(&pipe, ev[0], ev[3]));
     if (prof) {
-        int per_cu = 0;
-        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fsk::lz4_decode_wave<8192, 1024, true>, 64, 0);
-        std::fprintf(stderr, "lz4 gpu profile: %d waves per CU fit\n", per_cu);
-        const double tot = static_cast<double>(tally[10]) + 1e-9;
-        std::fprintf(stderr, "lz4 gpu profile (ring 8 KiB): wave cycles %.3g | copy %.1f %% far %.1f %% lit %.1f %% slow %.1f %% flush %.1f %% cover %.1f %% parse %.1f %% | "
-                             "%llu batches (%.1f seq each), %llu passes + %llu alone, %llu short-literal + %llu slow sequences, %llu far\n",
-                     tot, 100 * tally[2] / tot, 100 * tally[3] / tot, 100 * tally[11] / tot, 100 * tally[4] / tot, 100 * tally[5] / tot, 100 * tally[6] / tot,
-                     100 * tally[7] / tot, tally[8], tally[8] ? static_cast<double>(tally[0] - tally[9] - tally[12]) / tally[8] : 0.0, tally[13], tally[14], tally[12], tally[9], tally[1]);
+        std::fprintf(stderr, "lz4 gpu profile: kernel %d, %d block(s) per CU fit\n", kernel, fsk_lz4_blocks_per_cu(kernel));
+        if (kernel == fsk::LZ4K_WORKGROUP) {
+            const double nb = static_cast<double>(blocks.size());
+            std::fprintf(stderr, "lz4 gpu profile (workgroup pipeline), cycles per block: parse %.3g (waiting %.1f %%, scalar sequences %.1f %%), "
+                                 "scan %.3g (waiting %.1f %%), copy %.3g (waiting %.1f %%) | per block: %.0f windows (%.1f sequences, %.2f walk steps each), "
+                                 "%.0f scalar sequences, %.0f chunks, %.1f %% with pointers inside (%.2f doubling rounds each)\n",
+                         tally[2] / nb, 100.0 * tally[3] / (tally[2] + 1e-9), 100.0 * tally[4] / (tally[2] + 1e-9), tally[8] / nb,
+                         100.0 * tally[9] / (tally[8] + 1e-9), tally[12] / nb, 100.0 * tally[13] / (tally[12] + 1e-9), tally[5] / nb,
+                         tally[5] ? static_cast<double>(tally[0] - tally[6]) / tally[5] : 0.0, tally[5] ? static_cast<double>(tally[7]) / tally[5] : 0.0,
+                         tally[6] / nb, tally[14] / nb, 100.0 * tally[11] / (tally[14] + 1e-9), tally[11] ? static_cast<double>(tally[10]) / tally[11] : 0.0);
+        } else {
+            const double tot = static_cast<double>(tally[10]) + 1e-9;
+            std::fprintf(stderr, "lz4 gpu profile (wave per block, ring 8 KiB): wave cycles %.3g | copy %.1f %% far %.1f %% lit %.1f %% slow %.1f %% flush %.1f %% cover %.1f %% parse %.1f %% | "
+                                 "%llu batches (%.1f seq each), %llu passes + %llu alone, %llu short-literal + %llu slow sequences, %llu far\n",
+                         tot, 100 * tally[2] / tot, 100 * tally[3] / tot, 100 * tally[11] / tot, 100 * tally[4] / tot, 100 * tally[5] / tot, 100 * tally[6] / tot,
+                         100 * tally[7] / tot, tally[8], tally[8] ? static_cast<double>(tally[0] - tally[9] - tally[12]) / tally[8] : 0.0, tally[13], tally[14], tally[12], tally[9], tally[1]);
+        }
     }
     stats->bad_blocks += bad;
     stats->h2d_ms += h2d;
@@ -643,7 +325,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     stats->count_ms += cnt;
     stats->sequences += tally[0];
     stats->far_matches += tally[1];
-    stats->ring_kib = (!big_ring || prof) ? 8 : 16;
+    stats->ring_kib = kernel == fsk::LZ4K_WORKGROUP ? 68 : (kernel == fsk::LZ4K_WAVE ? 8 : 16);
     stats->chunks += pieces_done;
     stats->pipeline_ms += pipe;
     stats->readers = static_cast<uint64_t>(readers);

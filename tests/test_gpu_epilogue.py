@@ -185,9 +185,9 @@ def steps_knob(hip):
 
 
 def test_two_level_epilogue_step_limit_default(hip):
-    """The shipped rule (flagstat_kernels.hip fsk_launch): per-XCD copies only for grids >= 64 workgroups of <= 24 steps."""
+    """The shipped rule (flagstat_kernels.hip fsk_launch): per-XCD copies only for grids >= 64 workgroups of <= 40 steps."""
     assert hip.FLAGSTATS_hip_get(b"group_min_grid") == 64
-    assert hip.FLAGSTATS_hip_get(b"group_max_steps") == 24
+    assert hip.FLAGSTATS_hip_get(b"group_max_steps") == 40
 
 
 @pytest.mark.parametrize("steps_per_wg, max_steps, two_level", [
