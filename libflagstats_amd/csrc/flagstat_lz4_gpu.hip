@@ -304,11 +304,11 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         std::fprintf(stderr, "lz4 gpu profile: kernel %d, %d block(s) per CU fit\n", kernel, fsk_lz4_blocks_per_cu(kernel));
         if (kernel == fsk::LZ4K_WORKGROUP) {
             const double nb = static_cast<double>(blocks.size());
-            std::fprintf(stderr, "lz4 gpu profile (workgroup pipeline), cycles per block: parse %.3g (waiting %.1f %%, scalar sequences %.1f %%), "
-                                 "scan %.3g (waiting %.1f %%), copy %.3g (waiting %.1f %%) | per block: %.0f windows (%.1f sequences, %.2f walk steps each), "
+            std::fprintf(stderr, "lz4 gpu profile (workgroup pipeline), cycles per block and wave: walk %.3g (waiting %.1f %%), emit %.3g x %d (waiting %.1f %%), "
+                                 "scan %.3g x %d (waiting %.1f %%), copy %.3g (waiting %.1f %%) | per block: %.0f windows (%.1f sequences, %.2f walk steps each), "
                                  "%.0f scalar sequences, %.0f chunks, %.1f %% with pointers inside (%.2f doubling rounds each)\n",
-                         tally[2] / nb, 100.0 * tally[3] / (tally[2] + 1e-9), 100.0 * tally[4] / (tally[2] + 1e-9), tally[8] / nb,
-                         100.0 * tally[9] / (tally[8] + 1e-9), tally[12] / nb, 100.0 * tally[13] / (tally[12] + 1e-9), tally[5] / nb,
+                         tally[2] / nb, 100.0 * tally[3] / (tally[2] + 1e-9), tally[15] / nb / 2, 2, 100.0 * tally[16] / (tally[15] + 1e-9),
+                         tally[8] / nb / 3, 3, 100.0 * tally[9] / (tally[8] + 1e-9), tally[12] / nb, 100.0 * tally[13] / (tally[12] + 1e-9), tally[5] / nb,
                          tally[5] ? static_cast<double>(tally[0] - tally[6]) / tally[5] : 0.0, tally[5] ? static_cast<double>(tally[7]) / tally[5] : 0.0,
                          tally[6] / nb, tally[14] / nb, 100.0 * tally[11] / (tally[14] + 1e-9), tally[11] ? static_cast<double>(tally[10]) / tally[11] : 0.0);
         } else {
@@ -325,7 +325,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     stats->count_ms += cnt;
     stats->sequences += tally[0];
     stats->far_matches += tally[1];
-    stats->ring_kib = kernel == fsk::LZ4K_WORKGROUP ? 68 : (kernel == fsk::LZ4K_WAVE ? 8 : 16);
+    stats->ring_kib = kernel == fsk::LZ4K_WORKGROUP ? 66 : (kernel == fsk::LZ4K_WAVE ? 8 : 16);
     stats->chunks += pieces_done;
     stats->pipeline_ms += pipe;
     stats->readers = static_cast<uint64_t>(readers);

@@ -40,26 +40,39 @@
 namespace fsk {
 
 // ------------------------------------------------------------------------------------------------ lz4_decode_wg
-constexpr uint32_t kWgNR = 69632;                  // output ring: 64 KiB window + 4 KiB of write-ahead (17 x 4096, 272 x 256)
+// waves of a workgroup: 0 walk (token chain), 1-2 emit (even / odd records), 3-5 scan (chunks k mod 3), 6 copy
+constexpr uint32_t kWgEmit = 2, kWgScan = 3;
+constexpr uint32_t kWgThreads = 64u * (1u + kWgEmit + kWgScan + 1u);
+constexpr uint32_t kWgNR = 67584;                  // output ring: 64 KiB window + 2 KiB of write-ahead (66 x 1024, 264 x 256)
 constexpr uint32_t kWgChunk = 256;                 // output bytes per scan / copy step (4 per lane)
-constexpr uint32_t kWgAhead = kWgNR - 65536 - kWgChunk;  // the parser's position may lead the copier's by this much
-constexpr uint32_t kWgMR = 2048;                   // marker slots: the parser may lead the scanner by this many output bytes
-constexpr uint32_t kWgK = 1024;                    // final-source slots: the scanner may lead the copier by this many
-constexpr uint32_t kWgInw = 2048, kWgInPad = 96;   // input window ring + mirror of its first bytes behind its end
-constexpr uint32_t kWgSpan = 22 * 32;              // most output bytes one parse window yields (22 sequences of <= 14 + 18)
-constexpr uint32_t kWgFlush = 4096;
-constexpr uint32_t kWgSpinLimit = 1u << 22;        // polls before a wait gives up (a logic error must not hang the GPU)
+constexpr uint32_t kWgAhead = kWgNR - 65536 - kWgChunk;  // the emitters' position may lead the copier's by this much
+constexpr uint32_t kWgMR = 1024;                   // marker slots: the emitters may lead the scanners by this many output bytes
+constexpr uint32_t kWgK = 512;                     // final-source slots: the scanners may lead the copier by this many
+constexpr uint32_t kWgInw = 4096, kWgInPad = 96;   // input window ring + mirror of its first bytes behind its end
+constexpr uint32_t kWgQ = 16;                      // records the walker may lead the emitters by (each <= 82 input bytes)
+constexpr uint32_t kWgSpan = 384;                  // most output bytes the emitters write before publishing (more: in batches)
+constexpr uint32_t kWgFlush = 1024;
+constexpr uint32_t kWgSpinLimit = 1u << 19;        // polls before a wait gives up (a logic error must not hang the GPU)
+constexpr uint32_t kMarkLiteral = 0x10000u;        // marker: a literal run starts here (matches: their offset, 1..65535)
+constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kStride3 = 0x9249249249249249ull;  // bits 0, 3, 6, ..., 63
+enum { REC_WINDOW = 0, REC_SEQ = 1, REC_END = 2 };
 static_assert(kWgNR % kWgFlush == 0 && kWgNR % kWgChunk == 0 && kWgMR % kWgChunk == 0 && kWgK % kWgChunk == 0, "grids");
 static_assert(kWgSpan + kWgChunk <= kWgMR && kWgSpan + kWgChunk + kWgK <= kWgAhead + kWgChunk, "no cyclic wait");
+static_assert(kWgQ * 96u + 1024u + 96u < kWgInw - 1024u, "the walker cannot overwrite input an emitter still reads");
 
 struct __attribute__((aligned(16))) WgLds {
     uint8_t ring[kWgNR];
+    uint32_t mark[kWgMR];          // per output byte: 0, the offset of the match that starts there, or kMarkLiteral
     uint32_t fsrc[kWgK];           // per output byte: ring index of the byte it is a copy of (final before its chunk starts)
-    uint16_t mark[kWgMR];          // per output byte: 0, or the offset of the match that starts there
-    uint32_t litbits[kWgMR / 32];  // per output byte: 1 = literal (already in the ring)
     uint8_t inw[kWgInw + kWgInPad + 16];
-    uint32_t p_op, s_op, d_op, err;  // output positions parsed / scanned / copied; first error
+    uint4 q[kWgQ];                 // walker -> emitters: x = kind, then WINDOW: y = input position, z / w = member lanes;
+                                   // SEQ: y = position of the literals | their count (<= 64) << 24, z = offset, w = match length (0: no match)
+    uint32_t q_head, q_tail[kWgEmit];   // records pushed; per emitter the next record it will take
+    uint32_t h_seq, h_op;               // records whose output has been accounted for, and the output position behind them
+    uint32_t p_safe[kWgEmit];           // per emitter: every marker it owes below this position is written
+    uint32_t s_clr[kWgScan], s_done[kWgScan];  // per scanner: start of the next chunk it will clear / end of the last chunk it has finished
+    uint32_t d_op, c_ready, s_carry[4], err;
 };
 
 __device__ __forceinline__ uint32_t wg_ld(const uint32_t* p)
@@ -72,21 +85,39 @@ __device__ __forceinline__ void wg_st(uint32_t* p, uint32_t v)
     asm volatile("" ::: "memory");
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
-// poll until cond() holds; false if the block failed (here or in another wave) or the wait ran out
+// poll until cond() holds; false if the block failed (here or in another wave) or the wait ran out.  The naps grow:
+// ten waiting waves per CU polling every ~150 cycles took the LDS pipeline away from the waves that had work.
 template <class F>
 __device__ __forceinline__ bool wg_wait(WgLds& L, F cond)
 {
     for (uint32_t spins = 0;; ++spins) {
         if (cond()) break;
-        if (wg_ld(&L.err)) return false;
+        if ((spins & 3u) == 3u && wg_ld(&L.err)) return false;
         if (spins > kWgSpinLimit) {
             wg_st(&L.err, 9u);
             return false;
         }
-        __builtin_amdgcn_s_sleep(1);
+        if (spins < 2u)
+            __builtin_amdgcn_s_sleep(2);
+        else if (spins < 6u)
+            __builtin_amdgcn_s_sleep(6);
+        else
+            __builtin_amdgcn_s_sleep(16);
     }
     asm volatile("" ::: "memory");
     return true;
+}
+template <bool PROF, class F>
+__device__ __forceinline__ bool wg_wait_timed(WgLds& L, unsigned long long& t_wait, F cond)
+{
+    if (cond()) {
+        asm volatile("" ::: "memory");
+        return true;
+    }
+    const unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0ull;
+    const bool ok = wg_wait(L, cond);
+    if (PROF) t_wait += __builtin_readcyclecounter() - t0;
+    return ok;
 }
 
 // inclusive prefix sum over the 64 lanes
@@ -101,8 +132,9 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x)
     return x;
 }
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
-// EXCLUSIVE prefix maximum over the 64 lanes (lane 0 gets 0)
-__device__ __forceinline__ uint32_t wave_scan_max_excl(uint32_t x)
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+// inclusive prefix maximum over the 64 lanes
+__device__ __forceinline__ uint32_t wave_scan_max(uint32_t x)
 {
     x = umax(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x111, 0xF, 0xF, false)));
     x = umax(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x112, 0xF, 0xF, false)));
@@ -110,252 +142,370 @@ __device__ __forceinline__ uint32_t wave_scan_max_excl(uint32_t x)
     x = umax(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x118, 0xF, 0xF, false)));
     x = umax(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x142, 0xA, 0xF, false)));
     x = umax(x, static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xC, 0xF, false)));
-    return static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x138, 0xF, 0xF, false));  // wave_shr:1
+    return x;
 }
 
-// ---- wave 0: tokens -> markers + literal bytes
+// ---- wave 0: the token chain.  Stages the input, finds which byte positions are tokens, hands the emitters one record
+// per 64-byte window (its member lanes) or per sequence the window form does not cover.
 template <bool PROF>
-__device__ void lz4wg_parse(WgLds& L, const uint8_t* __restrict__ src, const uint32_t iend, const uint32_t oend,
-                            const uint32_t lane, unsigned long long* __restrict__ tally)
+__device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint32_t iend, const uint32_t oend,
+                           const uint32_t lane, unsigned long long* __restrict__ tally)
 {
-    uint32_t ip = 0, op = 0, op_idx = 0, in_hi = 0, err = 0, nseq = 0;
-    uint32_t s_seen = 0, d_seen = 0;
-    unsigned long long t_wait = 0, t_slow = 0, n_win = 0, n_slow = 0, n_walk = 0;
+    uint32_t ip = 0, in_hi = 0, err = 0, nrec = 0, tail_seen = 0;
+    unsigned long long t_wait = 0, n_win = 0, n_seq = 0, n_walk = 0;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     uint4 pend = make_uint4(0, 0, 0, 0);
-    // input: a ring of 2 KiB filled 1 KiB at a time, the NEXT KiB always in flight in registers (a parse window needs
-    // [ip, ip + 96) staged; a KiB is committed once ip is within 1 KiB of the staged end, i.e. ~16 windows after its load
-    // was issued).  The ring's first 96 bytes are mirrored behind its end, so a read never wraps.
-    auto issue = [&]() {
-        const uint32_t o = in_hi + lane * 16u;
-        pend = o < iend ? *reinterpret_cast<const uint4*>(src + o) : make_uint4(0, 0, 0, 0);  // <= 15 B past iend: the image is padded by 64
-    };
+    // input: a ring of 4 KiB filled 1 KiB at a time, the NEXT KiB always in flight in registers.  A KiB is committed
+    // once ip is within 1 KiB of the staged end; what it overwrites lies > 2 KiB behind ip, and the emitters are at most
+    // kWgQ records (of <= 82 input bytes) behind.  The ring's first 96 bytes are mirrored behind its end: no read wraps.
+    // (unconditional, the offset clamped instead: a load under a condition made the compiler wait for it on the spot.
+    // At most 16 bytes from iend on are read: the image is padded by 64)
+    auto issue = [&]() { pend = *reinterpret_cast<const uint4*>(src + umin(in_hi + lane * 16u, iend)); };
     auto cover = [&]() {
         while (in_hi < iend && ip + 1024u >= in_hi) {
             const uint32_t r = in_hi & (kWgInw - 1u);
             *reinterpret_cast<uint4*>(&L.inw[r + lane * 16u]) = pend;
             if (r == 0u && lane < kWgInPad / 16u) *reinterpret_cast<uint4*>(&L.inw[kWgInw + lane * 16u]) = pend;
             in_hi += 1024u;
-            if (in_hi < iend) issue();
+            issue();
         }
     };
     auto inb = [&](uint32_t pos) -> uint32_t { return __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(L.inw[pos & (kWgInw - 1u)])); };
-    // room for output positions [op, op + n): marker slots the scanner has cleared, ring bytes the copier no longer reads
-    auto room = [&](uint32_t n) -> bool {
-        if (op + n <= s_seen + kWgMR && op + n <= d_seen + kWgAhead) return true;
-        const unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0ull;
-        const bool ok = wg_wait(L, [&] {
-            s_seen = wg_ld(&L.s_op);
-            d_seen = wg_ld(&L.d_op);
-            return op + n <= s_seen + kWgMR && op + n <= d_seen + kWgAhead;
-        });
-        if (PROF) t_wait += __builtin_readcyclecounter() - t0;
-        return ok;
+    auto push = [&](uint32_t kind, uint32_t y, uint32_t z, uint32_t w) -> bool {
+        if (nrec >= tail_seen + kWgQ) {
+            const bool ok = wg_wait_timed<PROF>(L, t_wait, [&] {
+                tail_seen = umin(wg_ld(&L.q_tail[0]), wg_ld(&L.q_tail[1]));
+                return nrec < tail_seen + kWgQ;
+            });
+            if (!ok) return false;
+        }
+        if (lane == 0u) L.q[nrec & (kWgQ - 1u)] = make_uint4(kind, y, z, w);
+        ++nrec;
+        wg_st(&L.q_head, nrec);
+        return true;
     };
-    auto advance = [&](uint32_t n) {
-        op += n;
-        op_idx = (op_idx + n) % kWgNR;  // (n may be a whole long match)
+    // every queued record has been taken (before the walker runs far ahead of input that a record still refers to)
+    auto drain = [&]() -> bool {
+        return wg_wait_timed<PROF>(L, t_wait, [&] { return umin(wg_ld(&L.q_tail[0]), wg_ld(&L.q_tail[1])) >= nrec; });
     };
-    // one sequence of any shape at ip, scalar (long literal runs, long matches, the block's last sequences)
+    // one sequence of any shape at ip, scalar: its literals in pieces of <= 64 bytes (by reference), the last piece with
+    // the match (offset and length by value).  No record makes the walker advance more than 96 input bytes.
     auto slow_sequence = [&]() {
-        const unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0ull;
-        ++n_slow;
+        ++n_seq;
         cover();
         const uint32_t token = inb(ip);
         ++ip;
-        ++nseq;
         uint32_t ll = token >> 4;
         if (ll == 15u) {
-            uint32_t e;
+            uint32_t e, n = 0;
             do {
                 cover();
                 if (ip >= iend) { err = 1; return; }
+                if (++n == 8u && !drain()) { err = 8; return; }
                 e = inb(ip);
                 ++ip;
                 ll += e;
                 if (ll > oend) { err = 2; return; }
             } while (e == 255u);
         }
-        if (ll > iend - ip || ll > oend - op) { err = 2; return; }
-        while (ll) {
-            const uint32_t n = ll < 64u ? ll : 64u;
+        if (ll > iend - ip) { err = 2; return; }
+        while (ll > 64u) {
             cover();
-            if (!room(n)) { err = 8; return; }
-            if (lane < n) {
-                const uint32_t q = op + lane;
-                uint32_t ri = op_idx + lane;
-                if (ri >= kWgNR) ri -= kWgNR;
-                L.ring[ri] = L.inw[(ip + lane) & (kWgInw - 1u)];
-                __hip_atomic_fetch_or(&L.litbits[(q & (kWgMR - 1u)) >> 5], 1u << (q & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            ip += n;
-            ll -= n;
-            advance(n);
-            wg_st(&L.p_op, op);
+            if (!push(REC_SEQ, ip | (64u << 24), 0u, 0u)) { err = 8; return; }
+            ip += 64u;
+            ll -= 64u;
         }
-        if (ip >= iend) return;  // the last sequence has no match
+        const uint32_t lit_at = ip;
+        ip += ll;
         cover();
+        if (ip >= iend) {  // the last sequence has no match
+            if (!push(REC_SEQ, lit_at | (ll << 24), 0u, 0u)) err = 8;
+            return;
+        }
         if (ip + 2u > iend) { err = 3; return; }
         const uint32_t off = inb(ip) | (inb(ip + 1u) << 8);
         ip += 2u;
+        if (off == 0u) { err = 5; return; }
         uint32_t ml = token & 15u;
         if (ml == 15u) {
-            uint32_t e;
+            // (the literals of this sequence go first: the length bytes may be many)
+            if (ll && !push(REC_SEQ, lit_at | (ll << 24), 0u, 0u)) { err = 8; return; }
+            ll = 0;
+            uint32_t e, n = 0;
             do {
                 cover();
                 if (ip >= iend) { err = 4; return; }
+                if (++n == 8u && !drain()) { err = 8; return; }
                 e = inb(ip);
                 ++ip;
                 ml += e;
                 if (ml > oend) { err = 5; return; }
             } while (e == 255u);
         }
-        ml += 4u;
-        if (off == 0u || off > op || ml > oend - op) { err = 5; return; }
-        if (!room(1u)) { err = 8; return; }
-        if (lane == 0u) L.mark[op & (kWgMR - 1u)] = static_cast<uint16_t>(off);
-        advance(ml);
-        wg_st(&L.p_op, op);
-        if (PROF) t_slow += __builtin_readcyclecounter() - t0;
+        if (!push(REC_SEQ, lit_at | (ll << 24), off, ml + 4u)) err = 8;
     };
 
+    if (iend >= (1u << 24)) err = 10;  // (records carry input positions in 24 bits; the format's blocks are 1,024,000 bytes)
     issue();
     while (!err) {
         cover();
         if (ip + 96u > iend) break;  // the block's last bytes: one sequence at a time below
         ++n_win;
-        // ---- every byte position of [ip, ip + 64) as if it were a token
+        // ---- every byte position of [ip, ip + 64) as if it were a token: where would the next token be
         const uint32_t wi = (ip + lane) & (kWgInw - 1u);
-        uint32_t w;
-        __builtin_memcpy(&w, &L.inw[wi], 4);
-        const uint32_t tok = w & 255u, ll = tok >> 4, mlc = tok & 15u;
-        const bool simple = (ll < 15u) & (mlc < 15u);
-        uint16_t off16;
-        __builtin_memcpy(&off16, &L.inw[wi + 1u + ll], 2);  // (issued before the walk, used after it)
-        const uint32_t offv = off16;
+        const uint32_t tok = L.inw[wi];
+        const uint32_t ll = tok >> 4, mlc = tok & 15u;
+        const bool simple = (ll < 15u) & (mlc < 15u);      // no length continues in further bytes
         const uint32_t nxt = lane + 3u + ll;
-        const uint64_t b_simple = __builtin_amdgcn_ballot_w64(simple);
-        const uint64_t b_bare = __builtin_amdgcn_ballot_w64(simple & (ll == 0u));
-        // ---- which positions ARE tokens: lane 0 is; a run of bare sequences (3 bytes each) is one ctz, anything else one readlane
+        // not bare (bare = token, offset and nothing else); position 63 counts as not bare so that a run's ctz always ends
+        const int64_t nb = static_cast<int64_t>(~__builtin_amdgcn_ballot_w64(simple & (ll == 0u)) | (1ull << 63));
+        // per position, data-parallel: g = where the run of bare sequences that starts here ends (the first position on the
+        // 3-byte stride that is not bare; may lie behind the window), h = where the chain is after the sequence at g
+        const uint64_t x = static_cast<uint64_t>(nb >> lane) & kStride3;
+        const uint32_t g = lane + static_cast<uint32_t>(__builtin_ctzll(x));  // (x != 0: bit 63 of nb)
+        const uint32_t at_g = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((g & 63u) << 2), static_cast<int>(simple ? nxt : 0x80u + lane)));
+        const uint32_t h = g < 64u ? at_g : g;             // >= 0x80: the sequence at h - 0x80 is not simple
+        // ---- the chain itself: from lane 0, one step per run of bare sequences + the sequence behind it
         uint64_t members = 0;
-        uint32_t p = 0;
-        bool stop = false;
-        while (p < 64u) {
-            const uint64_t x = ~(b_bare >> p) & kStride3;
-            const uint32_t t = x ? static_cast<uint32_t>(__builtin_ctzll(x)) : 66u;  // 3 x (bare sequences in a row from p)
-            members |= (t >= 64u ? kStride3 : (kStride3 & ((1ull << t) - 1ull))) << p;
-            p += t;
-            ++n_walk;
-            if (p >= 64u) break;
-            if (!((b_simple >> p) & 1ull)) {
-                stop = true;  // a length that continues in further bytes: the scalar code takes this sequence
+        uint32_t p = 0, stop_at = kNone;
+        for (;;) {
+            const uint32_t gp = __builtin_amdgcn_readlane(g, p), hp = __builtin_amdgcn_readlane(h, p);
+            const uint32_t run = gp - p;                    // 3 x bare sequences from p; p + run <= 65
+            members |= (kStride3 & ((1ull << run) - 1ull)) << p;
+            if (PROF) ++n_walk;
+            if (gp >= 64u) {
+                p = gp;
                 break;
             }
-            members |= 1ull << p;
-            p = __builtin_amdgcn_readlane(nxt, p);
+            if (hp >= 0x80u) {
+                stop_at = gp;
+                p = gp;
+                break;
+            }
+            members |= 1ull << gp;
+            p = hp;
+            if (p >= 64u) break;
         }
-        if (members) {
-            const bool member = (members >> lane) & 1ull;
-            const uint32_t ml = mlc + 4u;
-            const uint32_t len = member ? ll + ml : 0u;
-            const uint32_t incl = wave_scan_add(len);
-            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
+        if (members && !push(REC_WINDOW, ip, static_cast<uint32_t>(members), static_cast<uint32_t>(members >> 32))) {
+            err = 8;
+            break;
+        }
+        ip += p;
+        if (stop_at != kNone) slow_sequence();
+    }
+    while (!err && ip < iend) slow_sequence();
+    if (!err && ip != iend) err = 6;
+    if (err) wg_st(&L.err, err);
+    if (!err) {
+        (void)push(REC_END, 0u, 0u, 0u);  // one for each emitter
+        (void)push(REC_END, 0u, 0u, 0u);
+    }
+    if (PROF && lane == 0u) {
+        atomicAdd(&tally[2], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
+        atomicAdd(&tally[3], t_wait);
+        atomicAdd(&tally[5], n_win);
+        atomicAdd(&tally[6], n_seq);
+        atomicAdd(&tally[7], n_walk);
+    }
+}
+
+// ---- waves 1 and 2: records -> output positions, markers, literal bytes.  Emitter `which` takes records which, which + 2, ...
+template <bool PROF>
+__device__ void lz4wg_emit(WgLds& L, const uint32_t oend, const uint32_t lane, const uint32_t which,
+                           unsigned long long* __restrict__ tally)
+{
+    uint32_t err = 0, nseq = 0, s_seen = 0, d_seen = 0;
+    unsigned long long t_wait = 0;
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    // room for output positions [at, at + n): marker slots the scanners have cleared, ring bytes the copier no longer reads
+    auto room = [&](uint32_t at, uint32_t n) -> bool {
+        if (at + n <= s_seen + kWgMR && at + n <= d_seen + kWgAhead) return true;
+        return wg_wait_timed<PROF>(L, t_wait, [&] {
+            s_seen = umin(umin(wg_ld(&L.s_clr[0]), wg_ld(&L.s_clr[1])), wg_ld(&L.s_clr[2]));
+            d_seen = wg_ld(&L.d_op);
+            return at + n <= s_seen + kWgMR && at + n <= d_seen + kWgAhead;
+        });
+    };
+    for (uint32_t r = which;; r += kWgEmit) {
+        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.q_head) > r; })) break;
+        const uint4 rec = L.q[r & (kWgQ - 1u)];
+        const uint32_t kind = __builtin_amdgcn_readfirstlane(rec.x), ry = __builtin_amdgcn_readfirstlane(rec.y);
+        const uint32_t rz = __builtin_amdgcn_readfirstlane(rec.z), rw = __builtin_amdgcn_readfirstlane(rec.w);
+        asm volatile("" ::: "memory");
+        // what this record adds to the output; then its place in the output, from the record before it
+        uint32_t total = 0, ll = 0, ml = 0, len = 0, incl = 0, offv = 0;
+        uint64_t lits = 0;
+        bool member = false;
+        uint32_t wi = 0;
+        if (kind == REC_WINDOW) {
+            wi = (ry + lane) & (kWgInw - 1u);
+            uint64_t q;
+            __builtin_memcpy(&q, &L.inw[wi], 8);  // token + the first 7 bytes behind it (all the literals of most sequences)
+            const uint32_t tok = static_cast<uint32_t>(q) & 255u;
+            ll = tok >> 4;
+            ml = (tok & 15u) + 4u;
+            uint16_t o16;
+            __builtin_memcpy(&o16, &L.inw[wi + 1u + ll], 2);
+            offv = o16;
+            lits = q >> 8;
+            member = ((static_cast<uint64_t>(rz) | (static_cast<uint64_t>(rw) << 32)) >> lane) & 1ull;
+            len = member ? ll + ml : 0u;
+            incl = wave_scan_add(len);
+            total = __builtin_amdgcn_readlane(incl, 63);
+        } else if (kind == REC_SEQ) {
+            ll = ry >> 24;
+            ml = rw;
+            total = ll + ml;
+        }
+        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.h_seq) >= r; })) break;
+        const uint32_t op = wg_ld(&L.h_op);
+        wg_st(&L.p_safe[which], op);  // everything this emitter owes below its current record is written
+        if (kind == REC_END) {
+            if (op != oend) err = 6;
+            wg_st(&L.h_seq, r + 1u);
+            wg_st(&L.p_safe[which], kNone);
+            wg_st(&L.q_tail[which], r + kWgEmit);
+            break;
+        }
+        if (total > oend - op) {
+            err = 5;
+            break;
+        }
+        if (lane == 0u) L.h_op = op + total;
+        wg_st(&L.h_seq, r + 1u);
+        uint32_t op_idx = op % kWgNR;
+        if (kind == REC_WINDOW) {
+            nseq += static_cast<uint32_t>(__builtin_popcount(rz) + __builtin_popcount(rw));
             const uint32_t rel = incl - len;           // this sequence's first output byte, relative to op
             const uint32_t mpos = op + rel + ll;       // ... and its match's
-            if (__builtin_amdgcn_ballot_w64(member & ((offv == 0u) | (offv > mpos) | (mpos + ml > oend)))) {
+            if (__builtin_amdgcn_ballot_w64(member & ((offv == 0u) | (offv > mpos)))) {
                 err = 5;
                 break;
             }
-            if (!room(total)) {
-                err = 8;
+            // in batches of <= kWgSpan output bytes (one, but for windows full of long matches)
+            uint32_t done = 0;
+            bool failed = false;
+            while (done < total) {
+                const uint32_t upto = done + kWgSpan;
+                const bool now = member & (rel >= done) & (incl <= upto);
+                const uint64_t nowm = __builtin_amdgcn_ballot_w64(now);
+                const uint32_t last = 63u - static_cast<uint32_t>(__builtin_clzll(nowm));   // (never empty: one sequence is <= 32 bytes)
+                const uint32_t end = __builtin_amdgcn_readlane(incl, last);
+                if (!room(op + done, end - done)) {
+                    failed = true;
+                    break;
+                }
+                if (now) L.mark[mpos & (kWgMR - 1u)] = offv;
+                const bool haslit = now & (ll > 0u);
+                if (__builtin_amdgcn_ballot_w64(haslit)) {
+                    if (haslit) L.mark[(op + rel) & (kWgMR - 1u)] = kMarkLiteral;
+                    uint32_t ri = op_idx + rel;
+                    if (ri >= kWgNR) ri -= kWgNR;
+                    uint64_t lb = lits;
+                    for (uint32_t j = 0; j < 7u; ++j) {
+                        const bool a = haslit & (j < ll);
+                        if (!__builtin_amdgcn_ballot_w64(a)) break;
+                        if (a) L.ring[ri] = static_cast<uint8_t>(lb);
+                        lb >>= 8;
+                        ri = ri + 1u == kWgNR ? 0u : ri + 1u;
+                    }
+                    if (__builtin_amdgcn_ballot_w64(haslit & (ll > 7u))) {
+                        for (uint32_t j = 7; j < 14u; ++j) {
+                            const bool a = haslit & (j < ll);
+                            if (!__builtin_amdgcn_ballot_w64(a)) break;
+                            if (a) L.ring[ri] = L.inw[wi + 1u + j];
+                            ri = ri + 1u == kWgNR ? 0u : ri + 1u;
+                        }
+                    }
+                }
+                done = end;
+                wg_st(&L.p_safe[which], op + done);
+            }
+            if (failed) break;
+        } else {
+            ++nseq;
+            // literals [ry & 0xFFFFFF, + ll) (ll <= 64), then a match of ml bytes at distance rz (none: ml == 0)
+            const uint32_t off = rz;
+            if (ml && (off == 0u || off > op + ll)) {
+                err = 5;
                 break;
             }
-            if (member) L.mark[mpos & (kWgMR - 1u)] = static_cast<uint16_t>(offv);
-            for (uint32_t j = 0; j < 14u; ++j) {
-                const bool a = member & (j < ll);
-                if (!__builtin_amdgcn_ballot_w64(a)) break;
-                if (a) {
-                    const uint32_t q = op + rel + j;
-                    uint32_t ri = op_idx + rel + j;
-                    if (ri >= kWgNR) ri -= kWgNR;
-                    L.ring[ri] = L.inw[wi + 1u + j];
-                    __hip_atomic_fetch_or(&L.litbits[(q & (kWgMR - 1u)) >> 5], 1u << (q & 31u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                }
+            if (!room(op, ll + 1u)) break;
+            if (lane < ll) {
+                uint32_t ri = op_idx + lane;
+                if (ri >= kWgNR) ri -= kWgNR;
+                L.ring[ri] = L.inw[((ry & 0xFFFFFFu) + lane) & (kWgInw - 1u)];
             }
-            advance(total);
-            nseq += static_cast<uint32_t>(__builtin_popcountll(members));
-            ip += p;
-            wg_st(&L.p_op, op);
+            if (lane == 0u) {
+                if (ll) L.mark[op & (kWgMR - 1u)] = kMarkLiteral;
+                if (ml) L.mark[(op + ll) & (kWgMR - 1u)] = off;
+            }
+            wg_st(&L.p_safe[which], op + total);
         }
-        if (stop && !err) slow_sequence();
+        wg_st(&L.q_tail[which], r + kWgEmit);
     }
-    while (!err && ip < iend) slow_sequence();
-    if (!err && (op != oend || ip != iend)) err = 6;
     if (err) wg_st(&L.err, err);
     if (lane == 0u) {
         atomicAdd(&tally[0], static_cast<unsigned long long>(nseq));
         if (PROF) {
-            atomicAdd(&tally[2], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
-            atomicAdd(&tally[3], t_wait);
-            atomicAdd(&tally[4], t_slow);
-            atomicAdd(&tally[5], n_win);
-            atomicAdd(&tally[6], n_slow);
-            atomicAdd(&tally[7], n_walk);
+            atomicAdd(&tally[15], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
+            atomicAdd(&tally[16], t_wait);
         }
     }
 }
 
-// ---- wave 1: markers -> one final source per output byte
+// ---- waves 3 to 5: markers -> one final source per output byte; scanner `which` takes chunks which, which + 3, ...
 template <bool PROF>
-__device__ void lz4wg_scan(WgLds& L, const uint32_t oend, const uint32_t lane, unsigned long long* __restrict__ tally)
+__device__ void lz4wg_scan(WgLds& L, const uint32_t oend, const uint32_t lane, const uint32_t which,
+                           unsigned long long* __restrict__ tally)
 {
-    uint32_t carry = 0;  // offset of the match that runs into this chunk (0: none)
-    uint32_t cidx = 0;   // ring index of the chunk's first byte
     unsigned long long t_wait = 0, n_rounds = 0, n_inchunk = 0;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
-    for (uint32_t c = 0; c < oend; c += kWgChunk) {
+    for (uint32_t kc = which; kc * kWgChunk < oend; kc += kWgScan) {
+        const uint32_t c = kc * kWgChunk;
         const uint32_t need = c + kWgChunk < oend ? c + kWgChunk : oend;
-        {
-            const unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0ull;
-            const bool ok = wg_wait(L, [&] { return wg_ld(&L.p_op) >= need && c + kWgChunk <= wg_ld(&L.d_op) + kWgK; });
-            if (PROF) t_wait += __builtin_readcyclecounter() - t0;
-            if (!ok) break;
-        }
+        const uint32_t cidx = c % kWgNR;  // ring index of the chunk's first byte
+        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return umin(wg_ld(&L.p_safe[0]), wg_ld(&L.p_safe[1])) >= need; })) break;
         const uint32_t mslot = c & (kWgMR - 1u);
-        const uint2 mk = *reinterpret_cast<const uint2*>(&L.mark[mslot + 4u * lane]);
-        uint32_t lb = reinterpret_cast<const uint8_t*>(L.litbits)[(mslot >> 3) + (lane >> 1)];
-        asm volatile("" ::: "memory");  // (both lanes of a pair have read the byte: one instruction)
-        *reinterpret_cast<uint2*>(&L.mark[mslot + 4u * lane]) = make_uint2(0u, 0u);
-        if (!(lane & 1u)) reinterpret_cast<uint8_t*>(L.litbits)[(mslot >> 3) + (lane >> 1)] = 0;
-        lb = (lb >> ((lane & 1u) * 4u)) & 15u;
+        const uint4 mk = *reinterpret_cast<const uint4*>(&L.mark[mslot + 4u * lane]);
+        asm volatile("" ::: "memory");
+        *reinterpret_cast<uint4*>(&L.mark[mslot + 4u * lane]) = make_uint4(0u, 0u, 0u, 0u);
+        wg_st(&L.s_clr[which], c + kWgScan * kWgChunk);
         const uint32_t r0 = 4u * lane;
-        const uint32_t m[4] = {mk.x & 0xFFFFu, mk.x >> 16, mk.y & 0xFFFFu, mk.y >> 16};
         // "the last marker at or before this byte": keys grow with the position, so it is a maximum
         uint32_t k[4];
-        k[0] = m[0] ? ((r0 + 1u) << 16) | m[0] : 0u;
-        k[1] = m[1] ? ((r0 + 2u) << 16) | m[1] : k[0];
-        k[2] = m[2] ? ((r0 + 3u) << 16) | m[2] : k[1];
-        k[3] = m[3] ? ((r0 + 4u) << 16) | m[3] : k[2];
-        const uint32_t before = wave_scan_max_excl(k[3]);
-        uint32_t off[4], ptr[4], ext[4];
+        k[0] = mk.x ? ((r0 + 1u) << 17) | mk.x : 0u;
+        k[1] = mk.y ? ((r0 + 2u) << 17) | mk.y : k[0];
+        k[2] = mk.z ? ((r0 + 3u) << 17) | mk.z : k[1];
+        k[3] = mk.w ? ((r0 + 4u) << 17) | mk.w : k[2];
+        const uint32_t upto = wave_scan_max(k[3]);
+        const uint32_t before = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(upto), 0x138, 0xF, 0xF, false));  // wave_shr:1
+        const uint32_t last = __builtin_amdgcn_readlane(upto, 63);
+        // the marker that runs into this chunk comes from the scanner of chunk kc - 1, and ours goes to the next one
+        uint32_t carry = 0;
+        if (kc) {
+            if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.c_ready) >= kc; })) break;
+            carry = wg_ld(&L.s_carry[kc & 3u]);
+        }
+        if (lane == 0u) L.s_carry[(kc + 1u) & 3u] = last ? (last & 0x1FFFFu) : carry;
+        wg_st(&L.c_ready, kc + 1u);
+        uint32_t ptr[4], ext[4];
         bool any_in = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const uint32_t kk = k[j] ? k[j] : before;
-            off[j] = kk ? (kk & 0xFFFFu) : carry;
+            const uint32_t m = kk ? (kk & 0x1FFFFu) : carry;
+            const uint32_t off = m & 0xFFFFu;
             const uint32_t rel = r0 + static_cast<uint32_t>(j);
-            const bool lit = (((lb >> j) & 1u) != 0u) | (off[j] == 0u);
-            const bool in = !lit & (off[j] <= rel);
+            const bool lit = ((m >> 16) != 0u) | (m == 0u);
+            const bool in = !lit & (off <= rel);
             any_in |= in;
-            ptr[j] = in ? rel - off[j] : rel;
-            // where a root's byte comes from: itself (a literal the parser wrote) or the ring at distance off
+            ptr[j] = in ? rel - off : rel;
+            // where a root's byte comes from: itself (a literal an emitter wrote) or the ring at distance off
             uint32_t s = cidx + rel;
-            if (!lit) s = s >= off[j] ? s - off[j] : s + kWgNR - off[j];
+            if (!lit) s = s >= off ? s - off : s + kWgNR - off;
             ext[j] = s;
         }
-        carry = __builtin_amdgcn_readlane(off[3], 63);
-        const uint32_t fslot = (c & (kWgK - 1u)) + r0;
-        *reinterpret_cast<uint4*>(&L.fsrc[fslot]) = make_uint4(ext[0], ext[1], ext[2], ext[3]);
         if (__builtin_amdgcn_ballot_w64(any_in)) {
             // pointers inside the chunk: chase to the roots, doubling (<= 255 hops -> <= 8 rounds), four byte indices a dword
             ++n_inchunk;
@@ -372,17 +522,19 @@ __device__ void lz4wg_scan(WgLds& L, const uint32_t oend, const uint32_t lane, u
                 p4 = n4;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) ptr[j] = n[j];
-                ++n_rounds;
+                if (PROF) ++n_rounds;
                 if (!__builtin_amdgcn_ballot_w64(changed)) break;
             }
-            const uint32_t base = c & (kWgK - 1u);
+        }
+        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return c + kWgChunk <= wg_ld(&L.d_op) + kWgK; })) break;
+        const uint32_t base = c & (kWgK - 1u);
+        *reinterpret_cast<uint4*>(&L.fsrc[base + r0]) = make_uint4(ext[0], ext[1], ext[2], ext[3]);
+        if (__builtin_amdgcn_ballot_w64(any_in)) {
             const uint4 f = make_uint4(L.fsrc[base + ptr[0]], L.fsrc[base + ptr[1]], L.fsrc[base + ptr[2]], L.fsrc[base + ptr[3]]);
             asm volatile("" ::: "memory");  // (every lane's reads are one instruction each, all before this write)
-            *reinterpret_cast<uint4*>(&L.fsrc[fslot]) = f;
+            *reinterpret_cast<uint4*>(&L.fsrc[base + r0]) = f;
         }
-        wg_st(&L.s_op, c + kWgChunk);
-        cidx += kWgChunk;
-        if (cidx == kWgNR) cidx = 0;
+        wg_st(&L.s_done[which], c + kWgChunk);
     }
     if (PROF && lane == 0u) {
         atomicAdd(&tally[8], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
@@ -392,7 +544,7 @@ __device__ void lz4wg_scan(WgLds& L, const uint32_t oend, const uint32_t lane, u
     }
 }
 
-// ---- wave 2: gather, write, flush
+// ---- wave 6: gather, write, flush
 template <bool PROF>
 __device__ void lz4wg_copy(WgLds& L, uint8_t* __restrict__ dst, const uint32_t oend, const uint32_t lane,
                            unsigned long long* __restrict__ tally)
@@ -403,12 +555,8 @@ __device__ void lz4wg_copy(WgLds& L, uint8_t* __restrict__ dst, const uint32_t o
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     bool ok = true;
     for (uint32_t c = 0; c < oend; c += kWgChunk) {
-        {
-            const unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0ull;
-            ok = wg_wait(L, [&] { return wg_ld(&L.s_op) >= c + kWgChunk; });
-            if (PROF) t_wait += __builtin_readcyclecounter() - t0;
-            if (!ok) break;
-        }
+        ok = wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.s_done[(c / kWgChunk) % kWgScan]) >= c + kWgChunk; });
+        if (!ok) break;
         ++n_chunks;
         const uint4 f = *reinterpret_cast<const uint4*>(&L.fsrc[(c & (kWgK - 1u)) + 4u * lane]);
         const uint32_t b0 = L.ring[f.x < kWgNR ? f.x : kWgNR - 1u], b1 = L.ring[f.y < kWgNR ? f.y : kWgNR - 1u];
@@ -418,26 +566,24 @@ __device__ void lz4wg_copy(WgLds& L, uint8_t* __restrict__ dst, const uint32_t o
         cidx += kWgChunk;
         if (cidx == kWgNR) cidx = 0;
         if (c + kWgChunk - flushed == kWgFlush && c + kWgChunk <= oend_even) {
-#pragma unroll
-            for (uint32_t k = 0; k < kWgFlush; k += 1024u)
-                *reinterpret_cast<uint4*>(dst + flushed + k + lane * 16u) = *reinterpret_cast<const uint4*>(&L.ring[fidx + k + lane * 16u]);
+            *reinterpret_cast<uint4*>(dst + flushed + lane * 16u) = *reinterpret_cast<const uint4*>(&L.ring[fidx + lane * 16u]);
             flushed += kWgFlush;
             fidx += kWgFlush;
             if (fidx == kWgNR) fidx = 0;
         }
     }
     if (ok && !wg_ld(&L.err)) {
-        // what is left in the ring: < 2 x 4 KiB, contiguous from fidx (a flush unit never wraps, the rest may)
+        // what is left in the ring: < 2 KiB, contiguous from fidx (a flush unit never wraps, the rest may)
         uint32_t o = flushed;
         for (; o + 1024u <= oend_even; o += 1024u) {
             uint32_t ri = fidx + (o - flushed) + lane * 16u;
             if (ri >= kWgNR) ri -= kWgNR;  // (16-byte groups stay whole: kWgNR and the group starts are multiples of 16)
             *reinterpret_cast<uint4*>(dst + o + lane * 16u) = *reinterpret_cast<const uint4*>(&L.ring[ri]);
         }
-        for (uint32_t q = o + lane; q < oend_even; q += 64u) {
-            uint32_t ri = fidx + (q - flushed);
+        for (uint32_t b = o + lane; b < oend_even; b += 64u) {
+            uint32_t ri = fidx + (b - flushed);
             if (ri >= kWgNR) ri -= kWgNR;
-            dst[q] = L.ring[ri];
+            dst[b] = L.ring[ri];
         }
     }
     if (PROF && lane == 0u) {
@@ -448,29 +594,40 @@ __device__ void lz4wg_copy(WgLds& L, uint8_t* __restrict__ dst, const uint32_t o
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(192) void lz4_decode_wg(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks,
-                                                     uint8_t* __restrict__ out, uint32_t* __restrict__ status,
-                                                     unsigned long long* __restrict__ tally)
+__global__ __launch_bounds__(kWgThreads) void lz4_decode_wg(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks,
+                                                            uint8_t* __restrict__ out, uint32_t* __restrict__ status,
+                                                            unsigned long long* __restrict__ tally)
 {
     __shared__ WgLds L;
     const GpuBlock b = blocks[blockIdx.x];
     const uint32_t lane = threadIdx.x & 63u;
     const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    // marker slots and literal bits must start out zero (the scanner leaves them zero, but LDS is not cleared between
-    // workgroups); the positions too
-    for (uint32_t i = threadIdx.x; i < kWgMR / 2u; i += 192u) reinterpret_cast<uint32_t*>(L.mark)[i] = 0u;
-    for (uint32_t i = threadIdx.x; i < kWgMR / 32u; i += 192u) L.litbits[i] = 0u;
+    // marker slots must start out zero (the scanners leave them zero, but LDS is not cleared between workgroups); the
+    // positions too
+    for (uint32_t i = threadIdx.x; i < kWgMR; i += kWgThreads) L.mark[i] = 0u;
     if (threadIdx.x == 0u) {
-        L.p_op = 0u;
-        L.s_op = 0u;
+        L.q_head = 0u;
+        L.h_seq = 0u;
+        L.h_op = 0u;
+        for (uint32_t i = 0; i < kWgEmit; ++i) {
+            L.q_tail[i] = i;
+            L.p_safe[i] = 0u;
+        }
+        for (uint32_t i = 0; i < kWgScan; ++i) {
+            L.s_clr[i] = i * kWgChunk;
+            L.s_done[i] = 0u;
+        }
         L.d_op = 0u;
+        L.c_ready = 0u;
         L.err = 0u;
     }
     __syncthreads();
     if (role == 0u)
-        lz4wg_parse<PROF>(L, comp + b.src_off, b.src_len, b.dst_len, lane, tally);
-    else if (role == 1u)
-        lz4wg_scan<PROF>(L, b.dst_len, lane, tally);
+        lz4wg_walk<PROF>(L, comp + b.src_off, b.src_len, b.dst_len, lane, tally);
+    else if (role <= kWgEmit)
+        lz4wg_emit<PROF>(L, b.dst_len, lane, role - 1u, tally);
+    else if (role <= kWgEmit + kWgScan)
+        lz4wg_scan<PROF>(L, b.dst_len, lane, role - 1u - kWgEmit, tally);
     else
         lz4wg_copy<PROF>(L, out + b.dst_off, b.dst_len, lane, tally);
     __syncthreads();  // every wave comes here, failed block or not
@@ -810,9 +967,9 @@ extern "C" hipError_t fsk_lz4_decode(int kernel, const uint8_t* comp, const fsk:
     switch (kernel) {
     case fsk::LZ4K_WORKGROUP:
         if (prof)
-            hipLaunchKernelGGL((fsk::lz4_decode_wg<true>), grid, dim3(192), 0, stream, comp, blocks, out, status, tally);
+            hipLaunchKernelGGL((fsk::lz4_decode_wg<true>), grid, dim3(fsk::kWgThreads), 0, stream, comp, blocks, out, status, tally);
         else
-            hipLaunchKernelGGL((fsk::lz4_decode_wg<false>), grid, dim3(192), 0, stream, comp, blocks, out, status, tally);
+            hipLaunchKernelGGL((fsk::lz4_decode_wg<false>), grid, dim3(fsk::kWgThreads), 0, stream, comp, blocks, out, status, tally);
         break;
     case fsk::LZ4K_WAVE:
         if (prof)
@@ -832,7 +989,7 @@ extern "C" int fsk_lz4_blocks_per_cu(int kernel)
 {
     int n = 0;
     hipError_t e = hipErrorInvalidValue;
-    if (kernel == fsk::LZ4K_WORKGROUP) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fsk::lz4_decode_wg<false>, 192, 0);
+    if (kernel == fsk::LZ4K_WORKGROUP) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fsk::lz4_decode_wg<false>, fsk::kWgThreads, 0);
     if (kernel == fsk::LZ4K_WAVE) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fsk::lz4_decode_wave<8192, 1024>, 64, 0);
     if (kernel == fsk::LZ4K_WAVE_RING16) e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fsk::lz4_decode_wave<16384, 4096>, 64, 0);
     if (e != hipSuccess) {
