@@ -293,8 +293,16 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     std::vector<uint32_t> st(blocks.size());
     LZG_TRY(hipMemcpyAsync(st.data(), d_status, st.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LZG_TRY(hipStreamSynchronize(s));
-    uint64_t bad = 0;
-    for (uint32_t x : st) bad += x != 0;
+    uint64_t bad = 0, first_bad = 0;
+    uint32_t first_code = 0;
+    for (size_t i = 0; i < st.size(); ++i)
+        if (st[i] != 0) {
+            if (!bad) {
+                first_bad = i;
+                first_code = st[i];
+            }
+            ++bad;
+        }
     float h2d = 0, dec = 0, cnt = 0, pipe = 0;
     LZG_TRY(hipEventElapsedTime(&h2d, ev[0], ev[1]));
     LZG_TRY(hipEventElapsedTime(&dec, ev[1], ev[2]));
@@ -304,13 +312,18 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         std::fprintf(stderr, "lz4 gpu profile: kernel %d, %d block(s) per CU fit\n", kernel, fsk_lz4_blocks_per_cu(kernel));
         if (kernel == fsk::LZ4K_WORKGROUP) {
             const double nb = static_cast<double>(blocks.size());
+            const int ne = fsk::kLz4WgEmitters, ns = fsk::kLz4WgScanners;
             std::fprintf(stderr, "lz4 gpu profile (workgroup pipeline), cycles per block and wave: walk %.3g (waiting %.1f %%), emit %.3g x %d (waiting %.1f %%), "
-                                 "scan %.3g x %d (waiting %.1f %%), copy %.3g (waiting %.1f %%) | per block: %.0f windows (%.1f sequences, %.2f walk steps each), "
+                                 "scan %.3g x %d (waiting %.1f %%), copy %.3g (waiting %.1f %%) | per block: %.0f tiles, %.0f windows (%.1f sequences each), "
                                  "%.0f scalar sequences, %.0f chunks, %.1f %% with pointers inside (%.2f doubling rounds each)\n",
-                         tally[2] / nb, 100.0 * tally[3] / (tally[2] + 1e-9), tally[15] / nb / 2, 2, 100.0 * tally[16] / (tally[15] + 1e-9),
-                         tally[8] / nb / 3, 3, 100.0 * tally[9] / (tally[8] + 1e-9), tally[12] / nb, 100.0 * tally[13] / (tally[12] + 1e-9), tally[5] / nb,
-                         tally[5] ? static_cast<double>(tally[0] - tally[6]) / tally[5] : 0.0, tally[5] ? static_cast<double>(tally[7]) / tally[5] : 0.0,
+                         tally[2] / nb, 100.0 * tally[3] / (tally[2] + 1e-9), tally[15] / nb / ne, ne, 100.0 * tally[16] / (tally[15] + 1e-9),
+                         tally[8] / nb / ns, ns, 100.0 * tally[9] / (tally[8] + 1e-9), tally[12] / nb, 100.0 * tally[13] / (tally[12] + 1e-9), tally[7] / nb,
+                         tally[5] / nb, tally[5] ? static_cast<double>(tally[0] - tally[6]) / tally[5] : 0.0,
                          tally[6] / nb, tally[14] / nb, 100.0 * tally[11] / (tally[14] + 1e-9), tally[11] ? static_cast<double>(tally[10]) / tally[11] : 0.0);
+            if (tally[7])
+                std::fprintf(stderr, "lz4 gpu profile, walker cycles per tile: exits %.0f, chain %.0f, members %.0f, records (incl. waiting for the emitters) %.0f\n",
+                             static_cast<double>(tally[17]) / tally[7], static_cast<double>(tally[18]) / tally[7], static_cast<double>(tally[19]) / tally[7],
+                             static_cast<double>(tally[20]) / tally[7]);
         } else {
             const double tot = static_cast<double>(tally[10]) + 1e-9;
             std::fprintf(stderr, "lz4 gpu profile (wave per block, ring 8 KiB): wave cycles %.3g | copy %.1f %% far %.1f %% lit %.1f %% slow %.1f %% flush %.1f %% cover %.1f %% parse %.1f %% | "
@@ -335,9 +348,9 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     }
     cleanup();
     if (bad) {
-        char buf[128];
-        std::snprintf(buf, sizeof buf, "block file: %llu block(s) failed to decode to their declared size (GPU LZ4 decoder)",
-                      static_cast<unsigned long long>(bad));
+        char buf[192];
+        std::snprintf(buf, sizeof buf, "block file: %llu block(s) failed to decode to their declared size (GPU LZ4 decoder; first: block %llu, code %u)",
+                      static_cast<unsigned long long>(bad), static_cast<unsigned long long>(first_bad), first_code);
         return fail_text(buf);
     }
     return 0;

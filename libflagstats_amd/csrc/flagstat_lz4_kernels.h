@@ -21,6 +21,7 @@ struct GpuBlock {
 // yardstick the new one is measured against; knob "lz4_gpu_kernel")
 enum { LZ4K_WORKGROUP = 0, LZ4K_WAVE = 1, LZ4K_WAVE_RING16 = 2 };
 
+constexpr int kLz4WgEmitters = 3, kLz4WgScanners = 3;  // waves per role of the workgroup kernel (profile output divides by them)
 constexpr int kLz4TallyWords = 32;  // unsigned long long words of the tally the kernels add to (see flagstat_lz4_kernels.hip)
 
 }  // namespace fsk

@@ -40,16 +40,18 @@
 namespace fsk {
 
 // ------------------------------------------------------------------------------------------------ lz4_decode_wg
-// waves of a workgroup: 0 walk (token chain), 1-2 emit (even / odd records), 3-5 scan (chunks k mod 3), 6 copy
-constexpr uint32_t kWgEmit = 2, kWgScan = 3;
+// waves of a workgroup: 0 walk (token chain), then kWgEmit emitters (records r mod kWgEmit), kWgScan scanners (chunks k mod
+// kWgScan), one copier
+constexpr uint32_t kWgEmit = kLz4WgEmitters, kWgScan = kLz4WgScanners;
 constexpr uint32_t kWgThreads = 64u * (1u + kWgEmit + kWgScan + 1u);
 constexpr uint32_t kWgNR = 67584;                  // output ring: 64 KiB window + 2 KiB of write-ahead (66 x 1024, 264 x 256)
 constexpr uint32_t kWgChunk = 256;                 // output bytes per scan / copy step (4 per lane)
 constexpr uint32_t kWgAhead = kWgNR - 65536 - kWgChunk;  // the emitters' position may lead the copier's by this much
 constexpr uint32_t kWgMR = 1024;                   // marker slots: the emitters may lead the scanners by this many output bytes
 constexpr uint32_t kWgK = 512;                     // final-source slots: the scanners may lead the copier by this many
-constexpr uint32_t kWgInw = 4096, kWgInPad = 96;   // input window ring + mirror of its first bytes behind its end
-constexpr uint32_t kWgQ = 16;                      // records the walker may lead the emitters by (each <= 82 input bytes)
+constexpr uint32_t kWgInw = 6144, kWgInPad = 96;   // input ring (6 x 1 KiB) + mirror of its first bytes behind its end
+constexpr uint32_t kWgSeg = 32, kWgTileSegs = 64;  // the walker's tile: 64 segments of 32 input bytes, one lane each
+constexpr uint32_t kWgQ = 16;                      // records the walker may lead the emitters by (each <= 96 input bytes)
 constexpr uint32_t kWgSpan = 384;                  // most output bytes the emitters write before publishing (more: in batches)
 constexpr uint32_t kWgFlush = 1024;
 constexpr uint32_t kWgSpinLimit = 1u << 19;        // polls before a wait gives up (a logic error must not hang the GPU)
@@ -57,24 +59,28 @@ constexpr uint32_t kMarkLiteral = 0x10000u;        // marker: a literal run star
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kStride3 = 0x9249249249249249ull;  // bits 0, 3, 6, ..., 63
 enum { REC_WINDOW = 0, REC_SEQ = 1, REC_END = 2 };
+static_assert(kWgThreads == 512, "two waves per SIMD");
 static_assert(kWgNR % kWgFlush == 0 && kWgNR % kWgChunk == 0 && kWgMR % kWgChunk == 0 && kWgK % kWgChunk == 0, "grids");
 static_assert(kWgSpan + kWgChunk <= kWgMR && kWgSpan + kWgChunk + kWgK <= kWgAhead + kWgChunk, "no cyclic wait");
-static_assert(kWgQ * 96u + 1024u + 96u < kWgInw - 1024u, "the walker cannot overwrite input an emitter still reads");
+static_assert(kWgSeg * kWgTileSegs + kWgInPad + 1023u + kWgQ * 96u < kWgInw - 1024u, "the walker cannot overwrite input an emitter still reads");
 
 struct __attribute__((aligned(16))) WgLds {
     uint8_t ring[kWgNR];
     uint32_t mark[kWgMR];          // per output byte: 0, the offset of the match that starts there, or kMarkLiteral
     uint32_t fsrc[kWgK];           // per output byte: ring index of the byte it is a copy of (final before its chunk starts)
     uint8_t inw[kWgInw + kWgInPad + 16];
-    uint4 q[kWgQ];                 // walker -> emitters: x = kind, then WINDOW: y = input position, z / w = member lanes;
+    uint4 q[kWgQ];                 // walker -> emitters: x = kind << 28 | output position, then WINDOW: y = input position, z / w = member lanes;
                                    // SEQ: y = position of the literals | their count (<= 64) << 24, z = offset, w = match length (0: no match)
+                                   // (input positions as indices into inw)
     uint32_t q_head, q_tail[kWgEmit];   // records pushed; per emitter the next record it will take
-    uint32_t h_seq, h_op;               // records whose output has been accounted for, and the output position behind them
-    uint32_t p_safe[kWgEmit];           // per emitter: every marker it owes below this position is written
+    uint32_t scratch[64];               // where the emitters' idle lanes write (straight-line stores instead of branches)
+    uint32_t p_walk;                    // output position of the first record not pushed yet (written after q_head)
     uint32_t s_clr[kWgScan], s_done[kWgScan];  // per scanner: start of the next chunk it will clear / end of the last chunk it has finished
-    uint32_t d_op, c_ready, s_carry[4], err;
+    uint32_t d_op, c_ready, s_carry[8], err;
 };
 
+__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
+__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 __device__ __forceinline__ uint32_t wg_ld(const uint32_t* p)
 {
     return __builtin_amdgcn_readfirstlane(__hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
@@ -120,6 +126,15 @@ __device__ __forceinline__ bool wg_wait_timed(WgLds& L, unsigned long long& t_wa
     return ok;
 }
 
+template <uint32_t N>
+__device__ __forceinline__ uint32_t wg_ld_min(const uint32_t* p)
+{
+    uint32_t m = wg_ld(p);
+#pragma unroll
+    for (uint32_t i = 1; i < N; ++i) m = umin(m, wg_ld(p + i));
+    return m;
+}
+
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x)
 {
@@ -131,8 +146,6 @@ __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x)
     x += static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(x), 0x143, 0xC, 0xF, false));  // row_bcast:31
     return x;
 }
-__device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
-__device__ __forceinline__ uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
 // inclusive prefix maximum over the 64 lanes
 __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x)
 {
@@ -145,302 +158,450 @@ __device__ __forceinline__ uint32_t wave_scan_max(uint32_t x)
     return x;
 }
 
-// ---- wave 0: the token chain.  Stages the input, finds which byte positions are tokens, hands the emitters one record
-// per 64-byte window (its member lanes) or per sequence the window form does not cover.
+// ---- wave 0: the token chain.  Stages the input and finds which byte positions are tokens -- with ONE LANE PER 32-BYTE
+// SEGMENT of a 2 KiB tile, so that all 64 lanes work on every step (a lane per byte position, as the emitters sit, leaves
+// two lanes in three idle and pays ~100 scalar instructions per 64 bytes):
+//   (1) backward over the 32 positions of its segment, every lane computes where a chain that enters the segment at
+//       position e = 0..19 leaves it ("exit": the position in the NEXT segment it lands on), from a sliding 18-entry
+//       window of 5-bit exits held in three registers -- no memory, no dependence on where the chain really is;
+//   (2) the real chain through the tile is then 64 scalar table lookups (entry of segment s + 1 = exit table of s at the
+//       entry of s);
+//   (3) forward over the 32 positions again, every lane marks the tokens reachable from its segment's entry: the members.
+// Two segments make one 64-byte WINDOW record for the emitters.  A token whose literal length continues in further bytes
+// (or whose match length needs more than one further byte) ends the tile there and goes through the scalar code.
 template <bool PROF>
 __device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint32_t iend, const uint32_t oend,
                            const uint32_t lane, unsigned long long* __restrict__ tally)
 {
-    uint32_t ip = 0, in_hi = 0, err = 0, nrec = 0, tail_seen = 0;
-    unsigned long long t_wait = 0, n_win = 0, n_seq = 0, n_walk = 0;
-    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
-    uint4 pend = make_uint4(0, 0, 0, 0);
-    // input: a ring of 4 KiB filled 1 KiB at a time, the NEXT KiB always in flight in registers.  A KiB is committed
-    // once ip is within 1 KiB of the staged end; what it overwrites lies > 2 KiB behind ip, and the emitters are at most
-    // kWgQ records (of <= 82 input bytes) behind.  The ring's first 96 bytes are mirrored behind its end: no read wraps.
-    // (unconditional, the offset clamped instead: a load under a condition made the compiler wait for it on the spot.
-    // At most 16 bytes from iend on are read: the image is padded by 64)
-    auto issue = [&]() { pend = *reinterpret_cast<const uint4*>(src + umin(in_hi + lane * 16u, iend)); };
-    auto cover = [&]() {
-        while (in_hi < iend && ip + 1024u >= in_hi) {
-            const uint32_t r = in_hi & (kWgInw - 1u);
-            *reinterpret_cast<uint4*>(&L.inw[r + lane * 16u]) = pend;
-            if (r == 0u && lane < kWgInPad / 16u) *reinterpret_cast<uint4*>(&L.inw[kWgInw + lane * 16u]) = pend;
-            in_hi += 1024u;
-            issue();
+    uint32_t ip = 0, ip_r = 0, in_hi = 0, in_hi_r = 0, err = 0, nrec = 0, tail_seen = 0, op = 0;
+    unsigned long long t_wait = 0, n_win = 0, n_seq = 0, n_tile = 0, t_dp = 0, t_chain = 0, t_reach = 0, t_push = 0, t_mark = 0;
+    auto tock = [&](unsigned long long& acc) {
+        if (PROF) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            acc += now - t_mark;
+            t_mark = now;
         }
     };
-    auto inb = [&](uint32_t pos) -> uint32_t { return __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(L.inw[pos & (kWgInw - 1u)])); };
-    auto push = [&](uint32_t kind, uint32_t y, uint32_t z, uint32_t w) -> bool {
-        if (nrec >= tail_seen + kWgQ) {
-            const bool ok = wg_wait_timed<PROF>(L, t_wait, [&] {
-                tail_seen = umin(wg_ld(&L.q_tail[0]), wg_ld(&L.q_tail[1]));
-                return nrec < tail_seen + kWgQ;
-            });
-            if (!ok) return false;
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    // input: a ring of six KiB filled one KiB at a time, the next TWO KiB always in flight in registers.  What a commit
+    // overwrites lies > 4 KiB behind the staged end, i.e. > 1.9 KiB behind ip, and the emitters are at most kWgQ records
+    // (of <= 96 input bytes) behind.  The ring's first 96 bytes are mirrored behind its end: no read wraps.
+    // (loads unconditional, the offset clamped instead: a load under a condition made the compiler wait for it on the
+    // spot.  At most 16 bytes from iend on are read: the image is padded by 64)
+    uint4 pend_a = *reinterpret_cast<const uint4*>(src + umin(lane * 16u, iend));
+    uint4 pend_b = *reinterpret_cast<const uint4*>(src + umin(1024u + lane * 16u, iend));
+    auto cover = [&](uint32_t need) {
+        while (in_hi < iend && in_hi < ip + need) {
+            *reinterpret_cast<uint4*>(&L.inw[in_hi_r + lane * 16u]) = pend_a;
+            if (in_hi_r == 0u && lane < kWgInPad / 16u) *reinterpret_cast<uint4*>(&L.inw[kWgInw + lane * 16u]) = pend_a;
+            in_hi += 1024u;
+            in_hi_r = in_hi_r + 1024u == kWgInw ? 0u : in_hi_r + 1024u;
+            pend_a = pend_b;
+            pend_b = *reinterpret_cast<const uint4*>(src + umin(in_hi + 1024u + lane * 16u, iend));
         }
-        if (lane == 0u) L.q[nrec & (kWgQ - 1u)] = make_uint4(kind, y, z, w);
+    };
+    auto ridx = [&](uint32_t pos) -> uint32_t {  // index into inw of input position pos (ip <= pos < ip + kWgInw)
+        const uint32_t r = ip_r + (pos - ip);
+        return r >= kWgInw ? r - kWgInw : r;
+    };
+    auto advance = [&](uint32_t n) {
+        ip += n;
+        ip_r += n;
+        while (ip_r >= kWgInw) ip_r -= kWgInw;
+    };
+    auto inb = [&]() -> uint32_t { return __builtin_amdgcn_readfirstlane(static_cast<uint32_t>(L.inw[ip_r])); };
+    auto have = [&](uint32_t n) -> bool {
+        if (nrec + n <= tail_seen + kWgQ) return true;
+        return wg_wait_timed<PROF>(L, t_wait, [&] {
+            tail_seen = wg_ld_min<kWgEmit>(L.q_tail);
+            return nrec + n <= tail_seen + kWgQ;
+        });
+    };
+    auto push = [&](uint32_t kind, uint32_t at, uint32_t y, uint32_t z, uint32_t w) -> bool {
+        if (!have(1u)) return false;
+        if (lane == 0u) L.q[nrec & (kWgQ - 1u)] = make_uint4((kind << 28) | at, y, z, w);
         ++nrec;
         wg_st(&L.q_head, nrec);
+        wg_st(&L.p_walk, kind == REC_SEQ ? at + (y >> 24) + w : at);  // (where this record's output ends)
         return true;
     };
     // every queued record has been taken (before the walker runs far ahead of input that a record still refers to)
     auto drain = [&]() -> bool {
-        return wg_wait_timed<PROF>(L, t_wait, [&] { return umin(wg_ld(&L.q_tail[0]), wg_ld(&L.q_tail[1])) >= nrec; });
+        return wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld_min<kWgEmit>(L.q_tail) >= nrec; });
     };
     // one sequence of any shape at ip, scalar: its literals in pieces of <= 64 bytes (by reference), the last piece with
     // the match (offset and length by value).  No record makes the walker advance more than 96 input bytes.
     auto slow_sequence = [&]() {
         ++n_seq;
-        cover();
-        const uint32_t token = inb(ip);
-        ++ip;
+        cover(96u);
+        const uint32_t token = inb();
+        advance(1u);
         uint32_t ll = token >> 4;
         if (ll == 15u) {
             uint32_t e, n = 0;
             do {
-                cover();
+                cover(96u);
                 if (ip >= iend) { err = 1; return; }
                 if (++n == 8u && !drain()) { err = 8; return; }
-                e = inb(ip);
-                ++ip;
+                e = inb();
+                advance(1u);
                 ll += e;
                 if (ll > oend) { err = 2; return; }
             } while (e == 255u);
         }
-        if (ll > iend - ip) { err = 2; return; }
+        if (ll > iend - ip || ll > oend - op) { err = 2; return; }
         while (ll > 64u) {
-            cover();
-            if (!push(REC_SEQ, ip | (64u << 24), 0u, 0u)) { err = 8; return; }
-            ip += 64u;
+            cover(96u);
+            if (!push(REC_SEQ, op, ip_r | (64u << 24), 0u, 0u)) { err = 8; return; }
+            advance(64u);
+            op += 64u;
             ll -= 64u;
         }
-        const uint32_t lit_at = ip;
-        ip += ll;
-        cover();
+        cover(96u);
+        const uint32_t lit_at = ip_r;
+        advance(ll);
         if (ip >= iend) {  // the last sequence has no match
-            if (!push(REC_SEQ, lit_at | (ll << 24), 0u, 0u)) err = 8;
+            if (!push(REC_SEQ, op, lit_at | (ll << 24), 0u, 0u)) err = 8;
+            op += ll;
             return;
         }
         if (ip + 2u > iend) { err = 3; return; }
-        const uint32_t off = inb(ip) | (inb(ip + 1u) << 8);
-        ip += 2u;
+        uint32_t off = inb();
+        advance(1u);
+        off |= inb() << 8;
+        advance(1u);
         if (off == 0u) { err = 5; return; }
         uint32_t ml = token & 15u;
         if (ml == 15u) {
             // (the literals of this sequence go first: the length bytes may be many)
-            if (ll && !push(REC_SEQ, lit_at | (ll << 24), 0u, 0u)) { err = 8; return; }
+            if (ll && !push(REC_SEQ, op, lit_at | (ll << 24), 0u, 0u)) { err = 8; return; }
+            op += ll;
             ll = 0;
             uint32_t e, n = 0;
             do {
-                cover();
+                cover(96u);
                 if (ip >= iend) { err = 4; return; }
                 if (++n == 8u && !drain()) { err = 8; return; }
-                e = inb(ip);
-                ++ip;
+                e = inb();
+                advance(1u);
                 ml += e;
                 if (ml > oend) { err = 5; return; }
             } while (e == 255u);
         }
-        if (!push(REC_SEQ, lit_at | (ll << 24), off, ml + 4u)) err = 8;
+        ml += 4u;
+        if (ll + ml > oend - op) { err = 5; return; }
+        if (!push(REC_SEQ, op, lit_at | (ll << 24), off, ml)) err = 8;
+        op += ll + ml;
     };
 
-    if (iend >= (1u << 24)) err = 10;  // (records carry input positions in 24 bits; the format's blocks are 1,024,000 bytes)
-    issue();
+    if (iend >= (1u << 24) || oend >= (1u << 28)) err = 10;  // (records carry 24-bit input and 28-bit output positions; the format's blocks are 1,024,000 bytes)
     while (!err) {
-        cover();
-        if (ip + 96u > iend) break;  // the block's last bytes: one sequence at a time below
-        ++n_win;
-        // ---- every byte position of [ip, ip + 64) as if it were a token: where would the next token be
-        const uint32_t wi = (ip + lane) & (kWgInw - 1u);
-        const uint32_t tok = L.inw[wi];
-        const uint32_t ll = tok >> 4, mlc = tok & 15u;
-        const bool simple = (ll < 15u) & (mlc < 15u);      // no length continues in further bytes
-        const uint32_t nxt = lane + 3u + ll;
-        // not bare (bare = token, offset and nothing else); position 63 counts as not bare so that a run's ctz always ends
-        const int64_t nb = static_cast<int64_t>(~__builtin_amdgcn_ballot_w64(simple & (ll == 0u)) | (1ull << 63));
-        // per position, data-parallel: g = where the run of bare sequences that starts here ends (the first position on the
-        // 3-byte stride that is not bare; may lie behind the window), h = where the chain is after the sequence at g
-        const uint64_t x = static_cast<uint64_t>(nb >> lane) & kStride3;
-        const uint32_t g = lane + static_cast<uint32_t>(__builtin_ctzll(x));  // (x != 0: bit 63 of nb)
-        const uint32_t at_g = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((g & 63u) << 2), static_cast<int>(simple ? nxt : 0x80u + lane)));
-        const uint32_t h = g < 64u ? at_g : g;             // >= 0x80: the sequence at h - 0x80 is not simple
-        // ---- the chain itself: from lane 0, one step per run of bare sequences + the sequence behind it
-        uint64_t members = 0;
-        uint32_t p = 0, stop_at = kNone;
-        for (;;) {
-            const uint32_t gp = __builtin_amdgcn_readlane(g, p), hp = __builtin_amdgcn_readlane(h, p);
-            const uint32_t run = gp - p;                    // 3 x bare sequences from p; p + run <= 65
-            members |= (kStride3 & ((1ull << run) - 1ull)) << p;
-            if (PROF) ++n_walk;
-            if (gp >= 64u) {
-                p = gp;
-                break;
+        // segments whose every position, were it a token of a sequence with all its lengths in the token (<= 19 bytes),
+        // would have its offset inside the block: such a sequence cannot be the block's last one
+        const uint32_t nseg = iend >= ip + 50u ? umin(kWgTileSegs, (iend - ip - 50u) / kWgSeg + 1u) : 0u;
+        if (nseg == 0u) break;  // the block's last bytes: one sequence at a time below
+        cover(nseg * kWgSeg + kWgInPad);
+        ++n_tile;
+        uint32_t base = ip_r + lane * kWgSeg;
+        if (base >= kWgInw) base -= kWgInw;
+        uint32_t w[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) __builtin_memcpy(&w[k], &L.inw[base + 4u * k], 4);
+        // ---- (1) exits: ex(i) = where a chain through position i lands in the next segment; 31 = through a token the
+        // window form does not cover.  win0..2 = ex(i + 1 .. i + 18), 5 bits each; tab0..3 = ex(0 .. 19).
+        uint32_t win0 = 0, win1 = 0, win2 = 0, tab0 = 0, tab1 = 0, tab2 = 0, tab3 = 0;
+        if (PROF) t_mark = __builtin_readcyclecounter();
+#pragma unroll
+        for (int i = 31; i >= 0; --i) {
+            const uint32_t tok = (w[i >> 2] >> ((i & 3) * 8)) & 255u;
+            const uint32_t ll = tok >> 4;
+            const uint32_t d = 3u + ll + ((tok & 15u) == 15u ? 1u : 0u);  // length of the sequence, if its lengths end here (3..18)
+            const uint32_t j = d - 1u;
+            const uint32_t word = j < 6u ? win0 : (j < 12u ? win1 : win2);
+            const uint32_t slot = j < 6u ? j : (j < 12u ? j - 6u : j - 12u);
+            uint32_t ex = (word >> (slot * 5u)) & 31u;
+            if (d >= 32u - static_cast<uint32_t>(i)) ex = static_cast<uint32_t>(i) + d - 32u;
+            if (ll == 15u) ex = 31u;
+            win2 = ((win2 << 5) | (win1 >> 25)) & 0x3FFFFFFFu;
+            win1 = ((win1 << 5) | (win0 >> 25)) & 0x3FFFFFFFu;
+            win0 = ((win0 << 5) | ex) & 0x3FFFFFFFu;
+            if (i < 20) {
+                const uint32_t put = ex << ((i % 6) * 5);
+                if (i / 6 == 0) tab0 |= put;
+                if (i / 6 == 1) tab1 |= put;
+                if (i / 6 == 2) tab2 |= put;
+                if (i / 6 == 3) tab3 |= put;
             }
-            if (hp >= 0x80u) {
-                stop_at = gp;
-                p = gp;
-                break;
-            }
-            members |= 1ull << gp;
-            p = hp;
-            if (p >= 64u) break;
         }
-        if (members && !push(REC_WINDOW, ip, static_cast<uint32_t>(members), static_cast<uint32_t>(members >> 32))) {
+        // (the two unrolled passes share nothing but w[]: without this the compiler keeps 32 decoded tokens alive, 149 VGPRs)
+#pragma unroll
+        for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(w[k]));
+        tock(t_dp);
+        // ---- (2) the chain through the tile: entry of every segment.  Straight-line (a taken branch costs this wave ~50
+        // cycles, four of them per segment made this loop the most expensive part of the tile): selects instead of
+        // branches, one exit test per 8 segments; segments behind nseg compute garbage that nothing uses.
+        uint32_t ent = 0, e = 0, nvalid = nseg, e_last = 0;
+#pragma unroll
+        for (uint32_t sg = 0; sg < kWgTileSegs; ++sg) {
+            if ((sg & 7u) == 0u && sg >= nseg) break;
+            ent = lane == sg ? e : ent;
+            const uint64_t ta = static_cast<uint64_t>(__builtin_amdgcn_readlane(tab0, sg)) | (static_cast<uint64_t>(__builtin_amdgcn_readlane(tab1, sg)) << 30);
+            const uint64_t tb = static_cast<uint64_t>(__builtin_amdgcn_readlane(tab2, sg)) | (static_cast<uint64_t>(__builtin_amdgcn_readlane(tab3, sg)) << 30);
+            const bool lo = e < 12u;
+            const uint32_t e2 = static_cast<uint32_t>((lo ? ta : tb) >> ((lo ? e : e - 12u) * 5u)) & 31u;
+            const bool special = e2 >= 20u;  // the chain meets a token for the scalar code inside this segment
+            nvalid = umin(nvalid, special ? sg + 1u : kWgTileSegs);
+            e = special ? 0u : e2;
+            e_last = sg + 1u == nseg ? e : e_last;  // entry of the segment behind the tile
+        }
+        tock(t_chain);
+        // ---- (3) members: the positions reachable from the entry; their output bytes; straight-line
+        uint32_t r_lo = lane < nvalid ? 1u << ent : 0u, r_hi = 0;  // reach: bit i = position i is a token (bits >= 32: in the next segment)
+        uint32_t stop_pos = 32u, olen = 0, c15m = 0;
+#pragma unroll
+        for (int i = 0; i < 32; ++i) {
+            const uint32_t tok = (w[i >> 2] >> ((i & 3) * 8)) & 255u;
+            const uint32_t ll = tok >> 4, mlc = tok & 15u;
+            const uint32_t d = 3u + ll + (mlc == 15u ? 1u : 0u);
+            const bool on = (r_lo >> i) & 1u;
+            const bool go = on & (ll != 15u);
+            stop_pos = (on & (ll == 15u)) ? umin(stop_pos, static_cast<uint32_t>(i)) : stop_pos;
+            c15m |= (go & (mlc == 15u)) ? 1u << i : 0u;
+            olen += go ? ll + mlc + 4u : 0u;
+            const uint32_t step = go ? 1u << d : 0u;  // bit d <= 18
+            r_lo |= step << i;
+            if (i > 13) r_hi |= step >> (32 - i);
+        }
+        (void)r_hi;
+        // a match length byte was taken to be the only one: it is if it is not 255 (and it adds to the output)
+        {
+            uint32_t chk = c15m;
+            while (__builtin_amdgcn_ballot_w64(chk != 0u)) {
+                const uint32_t i = chk ? static_cast<uint32_t>(__builtin_ctz(chk)) : 0u;
+                const uint32_t tk = L.inw[base + i];
+                const uint32_t extb = L.inw[base + i + 3u + (tk >> 4)];  // (<= 31 + 17 behind base: inside the mirror)
+                if (chk) {
+                    if (extb == 255u) stop_pos = umin(stop_pos, i);
+                    olen += extb;  // (19 + ext; the 19 = 15 + 4 is counted above)
+                }
+                chk &= chk - 1u;
+            }
+        }
+        uint32_t members = r_lo;
+        tock(t_reach);
+        const uint64_t stopm = __builtin_amdgcn_ballot_w64((stop_pos < 32u) & (lane < nvalid));
+        uint32_t adv;
+        bool slow = false;
+        if (stopm) {
+            // the tile ends inside segment ls: its sequences before the stop are still taken here; what the passes above
+            // counted for this lane behind the stop, and for all later lanes, is void
+            const uint32_t ls = static_cast<uint32_t>(__builtin_ctzll(stopm));
+            nvalid = ls + 1u;
+            adv = ls * kWgSeg + __builtin_amdgcn_readlane(stop_pos, ls);
+            slow = true;
+            if (lane == ls) {
+                // recount this lane's output up to the stop
+                members &= (1u << stop_pos) - 1u;
+                olen = 0;
+                uint32_t m = members;
+                while (m) {
+                    const uint32_t i = static_cast<uint32_t>(__builtin_ctz(m));
+                    const uint32_t tk = L.inw[base + i];
+                    const uint32_t ll = tk >> 4, mlc = tk & 15u;
+                    olen += ll + (mlc == 15u ? 19u + static_cast<uint32_t>(L.inw[base + i + 3u + ll]) : mlc + 4u);
+                    m &= m - 1u;
+                }
+            }
+        } else if (nvalid < nseg) {
+            err = 7;  // (cannot happen: the chain saw a token for the scalar code that the members pass did not)
+            break;
+        } else {
+            adv = nseg * kWgSeg + e_last;
+        }
+        if (lane >= nvalid) {
+            members = 0u;
+            olen = 0u;
+        }
+        // ---- output positions: a prefix sum over the segments; window t = segments 2t, 2t + 1 starts where 2t does
+        const uint32_t oincl = wave_scan_add(olen);
+        const uint32_t tile_out = __builtin_amdgcn_readlane(oincl, 63);
+        if (tile_out > oend - op) {
+            err = 5;
+            break;
+        }
+        const uint32_t wop = op + oincl - olen;
+        // ---- records, eight at a time
+        const uint32_t hi = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(members), 0xF5, 0xF, 0xF, false));  // quad_perm:[1,1,3,3]
+        const uint32_t nw = (nvalid + 1u) / 2u;
+        bool ok = true;
+        for (uint32_t g0 = 0; g0 < nw; g0 += 8u) {
+            const uint32_t cnt = umin(8u, nw - g0);
+            if (!have(cnt)) {
+                ok = false;
+                break;
+            }
+            const uint32_t t = (lane >> 1) - g0;
+            if (!(lane & 1u) && (lane >> 1) >= g0 && t < cnt)
+                L.q[(nrec + t) & (kWgQ - 1u)] = make_uint4((static_cast<uint32_t>(REC_WINDOW) << 28) | wop, base, members, hi);
+            nrec += cnt;
+            wg_st(&L.q_head, nrec);
+            wg_st(&L.p_walk, g0 + cnt < nw ? __builtin_amdgcn_readlane(wop, 2u * (g0 + cnt)) : op + tile_out);
+        }
+        if (!ok) {
             err = 8;
             break;
         }
-        ip += p;
-        if (stop_at != kNone) slow_sequence();
+        if (PROF) n_win += nw;
+        op += tile_out;
+        tock(t_push);
+        advance(adv);
+        if (slow) slow_sequence();
     }
     while (!err && ip < iend) slow_sequence();
-    if (!err && ip != iend) err = 6;
+    if (!err && (ip != iend || op != oend)) err = 6;
     if (err) wg_st(&L.err, err);
-    if (!err) {
-        (void)push(REC_END, 0u, 0u, 0u);  // one for each emitter
-        (void)push(REC_END, 0u, 0u, 0u);
-    }
+    if (!err)
+        for (uint32_t i = 0; i < kWgEmit; ++i) (void)push(REC_END, op, 0u, 0u, 0u);  // one for each emitter
     if (PROF && lane == 0u) {
         atomicAdd(&tally[2], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
         atomicAdd(&tally[3], t_wait);
         atomicAdd(&tally[5], n_win);
         atomicAdd(&tally[6], n_seq);
-        atomicAdd(&tally[7], n_walk);
+        atomicAdd(&tally[7], n_tile);
+        atomicAdd(&tally[17], t_dp);
+        atomicAdd(&tally[18], t_chain);
+        atomicAdd(&tally[19], t_reach);
+        atomicAdd(&tally[20], t_push);
     }
 }
 
-// ---- waves 1 and 2: records -> output positions, markers, literal bytes.  Emitter `which` takes records which, which + 2, ...
+// ---- emitters: records -> markers, literal bytes.  Emitter `which` takes records which, which + kWgEmit, ...; a record
+// carries its output position, so the emitters do not depend on each other.  The window path is straight-line: lanes
+// with nothing to store write to a scratch word of their own instead of branching around the store.
 template <bool PROF>
 __device__ void lz4wg_emit(WgLds& L, const uint32_t oend, const uint32_t lane, const uint32_t which,
                            unsigned long long* __restrict__ tally)
 {
-    uint32_t err = 0, nseq = 0, s_seen = 0, d_seen = 0;
+    uint32_t err = 0, nseq = 0, s_seen = 0, d_seen = 0, head_seen = 0;
     unsigned long long t_wait = 0;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     // room for output positions [at, at + n): marker slots the scanners have cleared, ring bytes the copier no longer reads
     auto room = [&](uint32_t at, uint32_t n) -> bool {
-        if (at + n <= s_seen + kWgMR && at + n <= d_seen + kWgAhead) return true;
+        if (__builtin_expect(at + n <= s_seen + kWgMR && at + n <= d_seen + kWgAhead, 1)) return true;
         return wg_wait_timed<PROF>(L, t_wait, [&] {
-            s_seen = umin(umin(wg_ld(&L.s_clr[0]), wg_ld(&L.s_clr[1])), wg_ld(&L.s_clr[2]));
+            s_seen = wg_ld_min<kWgScan>(L.s_clr);
             d_seen = wg_ld(&L.d_op);
             return at + n <= s_seen + kWgMR && at + n <= d_seen + kWgAhead;
         });
     };
+    uint32_t* const idle = &L.scratch[lane];
     for (uint32_t r = which;; r += kWgEmit) {
-        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.q_head) > r; })) break;
+        if (__builtin_expect(head_seen <= r, 0)) {
+            if (!wg_wait_timed<PROF>(L, t_wait, [&] {
+                    head_seen = wg_ld(&L.q_head);
+                    return head_seen > r;
+                }))
+                break;
+        }
         const uint4 rec = L.q[r & (kWgQ - 1u)];
-        const uint32_t kind = __builtin_amdgcn_readfirstlane(rec.x), ry = __builtin_amdgcn_readfirstlane(rec.y);
+        const uint32_t rx = __builtin_amdgcn_readfirstlane(rec.x), ry = __builtin_amdgcn_readfirstlane(rec.y);
         const uint32_t rz = __builtin_amdgcn_readfirstlane(rec.z), rw = __builtin_amdgcn_readfirstlane(rec.w);
         asm volatile("" ::: "memory");
-        // what this record adds to the output; then its place in the output, from the record before it
-        uint32_t total = 0, ll = 0, ml = 0, len = 0, incl = 0, offv = 0;
-        uint64_t lits = 0;
-        bool member = false;
-        uint32_t wi = 0;
-        if (kind == REC_WINDOW) {
-            wi = (ry + lane) & (kWgInw - 1u);
+        const uint32_t kind = rx >> 28, op = rx & 0xFFFFFFFu;
+        if (__builtin_expect(kind == REC_WINDOW, 1)) {
+            uint32_t wi = ry + lane;  // (ry: index into inw of the window's first byte)
+            if (wi >= kWgInw) wi -= kWgInw;
             uint64_t q;
             __builtin_memcpy(&q, &L.inw[wi], 8);  // token + the first 7 bytes behind it (all the literals of most sequences)
             const uint32_t tok = static_cast<uint32_t>(q) & 255u;
-            ll = tok >> 4;
-            ml = (tok & 15u) + 4u;
-            uint16_t o16;
-            __builtin_memcpy(&o16, &L.inw[wi + 1u + ll], 2);
-            offv = o16;
-            lits = q >> 8;
-            member = ((static_cast<uint64_t>(rz) | (static_cast<uint64_t>(rw) << 32)) >> lane) & 1ull;
-            len = member ? ll + ml : 0u;
-            incl = wave_scan_add(len);
-            total = __builtin_amdgcn_readlane(incl, 63);
-        } else if (kind == REC_SEQ) {
-            ll = ry >> 24;
-            ml = rw;
-            total = ll + ml;
-        }
-        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.h_seq) >= r; })) break;
-        const uint32_t op = wg_ld(&L.h_op);
-        wg_st(&L.p_safe[which], op);  // everything this emitter owes below its current record is written
-        if (kind == REC_END) {
-            if (op != oend) err = 6;
-            wg_st(&L.h_seq, r + 1u);
-            wg_st(&L.p_safe[which], kNone);
-            wg_st(&L.q_tail[which], r + kWgEmit);
-            break;
-        }
-        if (total > oend - op) {
-            err = 5;
-            break;
-        }
-        if (lane == 0u) L.h_op = op + total;
-        wg_st(&L.h_seq, r + 1u);
-        uint32_t op_idx = op % kWgNR;
-        if (kind == REC_WINDOW) {
+            const uint32_t ll = tok >> 4;
+            uint32_t ob;
+            __builtin_memcpy(&ob, &L.inw[wi + 1u + ll], 4);  // offset, first match length byte
+            const uint32_t offv = ob & 0xFFFFu;
+            const uint32_t ml = (tok & 15u) == 15u ? 19u + ((ob >> 16) & 255u) : (tok & 15u) + 4u;  // (the walker made sure that byte is not 255)
+            const uint32_t lits = static_cast<uint32_t>(q >> 8);
+            const bool member = ((static_cast<uint64_t>(rz) | (static_cast<uint64_t>(rw) << 32)) >> lane) & 1ull;
+            const uint32_t len = member ? ll + ml : 0u;
+            const uint32_t incl = wave_scan_add(len);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63);
             nseq += static_cast<uint32_t>(__builtin_popcount(rz) + __builtin_popcount(rw));
             const uint32_t rel = incl - len;           // this sequence's first output byte, relative to op
             const uint32_t mpos = op + rel + ll;       // ... and its match's
-            if (__builtin_amdgcn_ballot_w64(member & ((offv == 0u) | (offv > mpos)))) {
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(member & ((offv == 0u) | (offv > mpos))) != 0ull || total > oend - op, 0)) {
                 err = 5;
                 break;
             }
-            // in batches of <= kWgSpan output bytes (one, but for windows full of long matches)
-            uint32_t done = 0;
-            bool failed = false;
-            while (done < total) {
-                const uint32_t upto = done + kWgSpan;
-                const bool now = member & (rel >= done) & (incl <= upto);
-                const uint64_t nowm = __builtin_amdgcn_ballot_w64(now);
-                const uint32_t last = 63u - static_cast<uint32_t>(__builtin_clzll(nowm));   // (never empty: one sequence is <= 32 bytes)
-                const uint32_t end = __builtin_amdgcn_readlane(incl, last);
-                if (!room(op + done, end - done)) {
-                    failed = true;
-                    break;
-                }
-                if (now) L.mark[mpos & (kWgMR - 1u)] = offv;
-                const bool haslit = now & (ll > 0u);
-                if (__builtin_amdgcn_ballot_w64(haslit)) {
-                    if (haslit) L.mark[(op + rel) & (kWgMR - 1u)] = kMarkLiteral;
-                    uint32_t ri = op_idx + rel;
-                    if (ri >= kWgNR) ri -= kWgNR;
-                    uint64_t lb = lits;
-                    for (uint32_t j = 0; j < 7u; ++j) {
-                        const bool a = haslit & (j < ll);
+            const uint32_t op_idx = op % kWgNR;
+            uint32_t ri = op_idx + rel;
+            if (ri >= kWgNR) ri -= kWgNR;
+            const bool haslit = member & (ll > 0u);
+            // whether the short form below covers this window: all of it fits before the next publication, no literal run
+            // longer than 4 bytes, none across the end of the ring
+            const bool plain = total <= kWgSpan && !__builtin_amdgcn_ballot_w64(haslit & ((ll > 4u) | (ri + 4u > kWgNR)));
+            if (__builtin_expect(plain, 1)) {
+                if (!room(op, total)) break;
+                *(member ? &L.mark[mpos & (kWgMR - 1u)] : idle) = offv;
+                *(haslit ? &L.mark[(op + rel) & (kWgMR - 1u)] : idle) = kMarkLiteral;
+                // four bytes for a literal run of 1..4: what it writes too much lies in the sequence's own match (>= 4
+                // bytes), which the copier writes later
+                __builtin_memcpy(haslit ? static_cast<void*>(&L.ring[ri]) : static_cast<void*>(idle), &lits, 4);
+            } else {
+                // in batches of <= kWgSpan output bytes, literals byte by byte
+                uint32_t done = 0;
+                bool failed = false;
+                while (done < total) {
+                    const uint32_t upto = done + kWgSpan;
+                    const bool now = member & (rel >= done) & (incl <= upto);
+                    const uint64_t nowm = __builtin_amdgcn_ballot_w64(now);
+                    const uint32_t last = 63u - static_cast<uint32_t>(__builtin_clzll(nowm));   // (never empty: one sequence is <= 287 bytes)
+                    const uint32_t end = __builtin_amdgcn_readlane(incl, last);
+                    if (!room(op + done, end - done)) {
+                        failed = true;
+                        break;
+                    }
+                    if (now) L.mark[mpos & (kWgMR - 1u)] = offv;
+                    const bool nowlit = now & (ll > 0u);
+                    if (nowlit) L.mark[(op + rel) & (kWgMR - 1u)] = kMarkLiteral;
+                    uint32_t rj = ri;
+                    uint64_t lb = q >> 8;
+                    for (uint32_t j = 0; j < 14u; ++j) {
+                        const bool a = nowlit & (j < ll);
                         if (!__builtin_amdgcn_ballot_w64(a)) break;
-                        if (a) L.ring[ri] = static_cast<uint8_t>(lb);
+                        if (a) L.ring[rj] = j < 7u ? static_cast<uint8_t>(lb) : L.inw[wi + 1u + j];
                         lb >>= 8;
-                        ri = ri + 1u == kWgNR ? 0u : ri + 1u;
+                        rj = rj + 1u == kWgNR ? 0u : rj + 1u;
                     }
-                    if (__builtin_amdgcn_ballot_w64(haslit & (ll > 7u))) {
-                        for (uint32_t j = 7; j < 14u; ++j) {
-                            const bool a = haslit & (j < ll);
-                            if (!__builtin_amdgcn_ballot_w64(a)) break;
-                            if (a) L.ring[ri] = L.inw[wi + 1u + j];
-                            ri = ri + 1u == kWgNR ? 0u : ri + 1u;
-                        }
-                    }
+                    done = end;
+                    // (what is written so far, for the scanners: the record's position moves on)
+                    if (lane == 0u) L.q[r & (kWgQ - 1u)].x = (static_cast<uint32_t>(REC_WINDOW) << 28) | (op + done);
+                    asm volatile("" ::: "memory");
                 }
-                done = end;
-                wg_st(&L.p_safe[which], op + done);
+                if (failed) break;
             }
-            if (failed) break;
-        } else {
+        } else if (kind == REC_SEQ) {
             ++nseq;
             // literals [ry & 0xFFFFFF, + ll) (ll <= 64), then a match of ml bytes at distance rz (none: ml == 0)
-            const uint32_t off = rz;
-            if (ml && (off == 0u || off > op + ll)) {
+            const uint32_t ll = ry >> 24, ml = rw, off = rz;
+            if (ll + ml > oend - op || (ml && (off == 0u || off > op + ll))) {
                 err = 5;
                 break;
             }
             if (!room(op, ll + 1u)) break;
+            const uint32_t op_idx = op % kWgNR;
             if (lane < ll) {
                 uint32_t ri = op_idx + lane;
                 if (ri >= kWgNR) ri -= kWgNR;
-                L.ring[ri] = L.inw[((ry & 0xFFFFFFu) + lane) & (kWgInw - 1u)];
+                uint32_t li = (ry & 0xFFFFFFu) + lane;
+                if (li >= kWgInw) li -= kWgInw;
+                L.ring[ri] = L.inw[li];
             }
             if (lane == 0u) {
                 if (ll) L.mark[op & (kWgMR - 1u)] = kMarkLiteral;
                 if (ml) L.mark[(op + ll) & (kWgMR - 1u)] = off;
             }
-            wg_st(&L.p_safe[which], op + total);
+        } else {
+            wg_st(&L.q_tail[which], r + kWgEmit);
+            break;
         }
         wg_st(&L.q_tail[which], r + kWgEmit);
     }
@@ -454,18 +615,38 @@ __device__ void lz4wg_emit(WgLds& L, const uint32_t oend, const uint32_t lane, c
     }
 }
 
-// ---- waves 3 to 5: markers -> one final source per output byte; scanner `which` takes chunks which, which + 3, ...
+// ---- scanners: markers -> one final source per output byte; scanner `which` takes chunks which, which + kWgScan, ...
 template <bool PROF>
 __device__ void lz4wg_scan(WgLds& L, const uint32_t oend, const uint32_t lane, const uint32_t which,
                            unsigned long long* __restrict__ tally)
 {
     unsigned long long t_wait = 0, n_rounds = 0, n_inchunk = 0;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    // the position below which every marker and literal is in place: where the first record that is not finished starts
+    // (the emitters finish their records in order each, so it is the smallest "next record" of any of them; its position
+    // stands in its queue slot, which nobody reuses before it is finished) -- or, with every pushed record finished, where
+    // the walker is.  p_walk is read first: it can only be too small for the records found finished afterwards.
+    uint32_t front = 0;
+    auto frontier = [&]() -> uint32_t {
+        const uint32_t walk = wg_ld(&L.p_walk);
+        for (;;) {
+            const uint32_t t = wg_ld_min<kWgEmit>(L.q_tail);
+            if (t >= wg_ld(&L.q_head)) return walk;
+            const uint32_t at = wg_ld(&L.q[t & (kWgQ - 1u)].x) & 0xFFFFFFFu;
+            if (wg_ld_min<kWgEmit>(L.q_tail) == t) return at;
+        }
+    };
     for (uint32_t kc = which; kc * kWgChunk < oend; kc += kWgScan) {
         const uint32_t c = kc * kWgChunk;
         const uint32_t need = c + kWgChunk < oend ? c + kWgChunk : oend;
         const uint32_t cidx = c % kWgNR;  // ring index of the chunk's first byte
-        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return umin(wg_ld(&L.p_safe[0]), wg_ld(&L.p_safe[1])) >= need; })) break;
+        if (__builtin_expect(front < need, 0)) {
+            if (!wg_wait_timed<PROF>(L, t_wait, [&] {
+                    front = frontier();
+                    return front >= need;
+                }))
+                break;
+        }
         const uint32_t mslot = c & (kWgMR - 1u);
         const uint4 mk = *reinterpret_cast<const uint4*>(&L.mark[mslot + 4u * lane]);
         asm volatile("" ::: "memory");
@@ -485,9 +666,9 @@ __device__ void lz4wg_scan(WgLds& L, const uint32_t oend, const uint32_t lane, c
         uint32_t carry = 0;
         if (kc) {
             if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.c_ready) >= kc; })) break;
-            carry = wg_ld(&L.s_carry[kc & 3u]);
+            carry = wg_ld(&L.s_carry[kc & 7u]);
         }
-        if (lane == 0u) L.s_carry[(kc + 1u) & 3u] = last ? (last & 0x1FFFFu) : carry;
+        if (lane == 0u) L.s_carry[(kc + 1u) & 7u] = last ? (last & 0x1FFFFu) : carry;
         wg_st(&L.c_ready, kc + 1u);
         uint32_t ptr[4], ext[4];
         bool any_in = false;
@@ -544,7 +725,7 @@ __device__ void lz4wg_scan(WgLds& L, const uint32_t oend, const uint32_t lane, c
     }
 }
 
-// ---- wave 6: gather, write, flush
+// ---- the last wave: gather, write, flush
 template <bool PROF>
 __device__ void lz4wg_copy(WgLds& L, uint8_t* __restrict__ dst, const uint32_t oend, const uint32_t lane,
                            unsigned long long* __restrict__ tally)
@@ -593,6 +774,8 @@ __device__ void lz4wg_copy(WgLds& L, uint8_t* __restrict__ dst, const uint32_t o
     }
 }
 
+// (eight waves: two per SIMD, so that the two workgroups the LDS allows on a CU always fit side by side; with ten, 3 + 3
+// waves of the two workgroups landed on one SIMD, more than 92 VGPRs allow, and a CU held ONE workgroup)
 template <bool PROF>
 __global__ __launch_bounds__(kWgThreads) void lz4_decode_wg(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks,
                                                             uint8_t* __restrict__ out, uint32_t* __restrict__ status,
@@ -607,12 +790,8 @@ __global__ __launch_bounds__(kWgThreads) void lz4_decode_wg(const uint8_t* __res
     for (uint32_t i = threadIdx.x; i < kWgMR; i += kWgThreads) L.mark[i] = 0u;
     if (threadIdx.x == 0u) {
         L.q_head = 0u;
-        L.h_seq = 0u;
-        L.h_op = 0u;
-        for (uint32_t i = 0; i < kWgEmit; ++i) {
-            L.q_tail[i] = i;
-            L.p_safe[i] = 0u;
-        }
+        L.p_walk = 0u;
+        for (uint32_t i = 0; i < kWgEmit; ++i) L.q_tail[i] = i;
         for (uint32_t i = 0; i < kWgScan; ++i) {
             L.s_clr[i] = i * kWgChunk;
             L.s_done[i] = 0u;
