@@ -59,7 +59,7 @@ constexpr uint32_t kMarkLiteral = 0x10000u;        // marker: a literal run star
 constexpr uint32_t kNone = 0xFFFFFFFFu;
 constexpr uint64_t kStride3 = 0x9249249249249249ull;  // bits 0, 3, 6, ..., 63
 enum { REC_WINDOW = 0, REC_SEQ = 1, REC_END = 2 };
-static_assert(kWgThreads == 512, "two waves per SIMD");
+static_assert(kWgThreads == 512 && kWgEmit == 3 && kWgScan == 3, "two waves per SIMD; three positions and one more word per 16-byte poll");
 static_assert(kWgNR % kWgFlush == 0 && kWgNR % kWgChunk == 0 && kWgMR % kWgChunk == 0 && kWgK % kWgChunk == 0, "grids");
 static_assert(kWgSpan + kWgChunk <= kWgMR && kWgSpan + kWgChunk + kWgK <= kWgAhead + kWgChunk, "no cyclic wait");
 static_assert(kWgSeg * kWgTileSegs + kWgInPad + 1023u + kWgQ * 96u < kWgInw - 1024u, "the walker cannot overwrite input an emitter still reads");
@@ -72,11 +72,12 @@ struct __attribute__((aligned(16))) WgLds {
     uint4 q[kWgQ];                 // walker -> emitters: x = kind << 28 | output position, then WINDOW: y = input position, z / w = member lanes;
                                    // SEQ: y = position of the literals | their count (<= 64) << 24, z = offset, w = match length (0: no match)
                                    // (input positions as indices into inw)
-    uint32_t q_head, q_tail[kWgEmit];   // records pushed; per emitter the next record it will take
     uint32_t scratch[64];               // where the emitters' idle lanes write (straight-line stores instead of branches)
+    uint32_t q_tail[kWgEmit], q_head;   // per emitter the next record it will take; records pushed (16 bytes: one read)
+    uint32_t s_clr[kWgScan], d_op;      // per scanner: start of the next chunk it will clear; copier: end of the last chunk copied (16 bytes)
+    uint32_t s_done[kWgScan];           // per scanner: end of the last chunk whose final sources it has written
     uint32_t p_walk;                    // output position of the first record not pushed yet (written after q_head)
-    uint32_t s_clr[kWgScan], s_done[kWgScan];  // per scanner: start of the next chunk it will clear / end of the last chunk it has finished
-    uint32_t d_op, c_ready, s_carry[8], err;
+    uint32_t c_ready, s_carry[8], err;
 };
 
 __device__ __forceinline__ uint32_t umax(uint32_t a, uint32_t b) { return a > b ? a : b; }
@@ -126,14 +127,18 @@ __device__ __forceinline__ bool wg_wait_timed(WgLds& L, unsigned long long& t_wa
     return ok;
 }
 
-template <uint32_t N>
-__device__ __forceinline__ uint32_t wg_ld_min(const uint32_t* p)
+// four consecutive words with ONE read (a poll that read its words one by one, each with its own wait, cost ~200 cycles
+// a word)
+__device__ __forceinline__ uint4 wg_ld4(const uint32_t* p)
 {
-    uint32_t m = wg_ld(p);
-#pragma unroll
-    for (uint32_t i = 1; i < N; ++i) m = umin(m, wg_ld(p + i));
-    return m;
+    asm volatile("" ::: "memory");
+    typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+    const v4u v = *reinterpret_cast<const volatile v4u*>(p);
+    asm volatile("" ::: "memory");
+    return make_uint4(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y), __builtin_amdgcn_readfirstlane(v.z),
+                      __builtin_amdgcn_readfirstlane(v.w));
 }
+__device__ __forceinline__ uint32_t umin3(uint32_t a, uint32_t b, uint32_t c) { return umin(umin(a, b), c); }
 
 // inclusive prefix sum over the 64 lanes
 __device__ __forceinline__ uint32_t wave_scan_add(uint32_t x)
@@ -213,7 +218,8 @@ __device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint
     auto have = [&](uint32_t n) -> bool {
         if (nrec + n <= tail_seen + kWgQ) return true;
         return wg_wait_timed<PROF>(L, t_wait, [&] {
-            tail_seen = wg_ld_min<kWgEmit>(L.q_tail);
+            const uint4 t = wg_ld4(L.q_tail);
+            tail_seen = umin3(t.x, t.y, t.z);
             return nrec + n <= tail_seen + kWgQ;
         });
     };
@@ -227,7 +233,10 @@ __device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint
     };
     // every queued record has been taken (before the walker runs far ahead of input that a record still refers to)
     auto drain = [&]() -> bool {
-        return wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld_min<kWgEmit>(L.q_tail) >= nrec; });
+        return wg_wait_timed<PROF>(L, t_wait, [&] {
+            const uint4 t = wg_ld4(L.q_tail);
+            return umin3(t.x, t.y, t.z) >= nrec;
+        });
     };
     // one sequence of any shape at ip, scalar: its literals in pieces of <= 64 bytes (by reference), the last piece with
     // the match (offset and length by value).  No record makes the walker advance more than 96 input bytes.
@@ -309,7 +318,7 @@ __device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint
         for (int k = 0; k < 8; ++k) __builtin_memcpy(&w[k], &L.inw[base + 4u * k], 4);
         // ---- (1) exits: ex(i) = where a chain through position i lands in the next segment; 31 = through a token the
         // window form does not cover.  win0..2 = ex(i + 1 .. i + 18), 5 bits each; tab0..3 = ex(0 .. 19).
-        uint32_t win0 = 0, win1 = 0, win2 = 0, tab0 = 0, tab1 = 0, tab2 = 0, tab3 = 0;
+        uint32_t win0 = 0, win1 = 0, win2 = 0, tab0 = 0, tab1 = 0;
         if (PROF) t_mark = __builtin_readcyclecounter();
 #pragma unroll
         for (int i = 31; i >= 0; --i) {
@@ -325,34 +334,37 @@ __device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint
             win2 = ((win2 << 5) | (win1 >> 25)) & 0x3FFFFFFFu;
             win1 = ((win1 << 5) | (win0 >> 25)) & 0x3FFFFFFFu;
             win0 = ((win0 << 5) | ex) & 0x3FFFFFFFu;
-            if (i < 20) {
+            if (i < 12) {
                 const uint32_t put = ex << ((i % 6) * 5);
                 if (i / 6 == 0) tab0 |= put;
                 if (i / 6 == 1) tab1 |= put;
-                if (i / 6 == 2) tab2 |= put;
-                if (i / 6 == 3) tab3 |= put;
             }
         }
+        // ex(0 .. 11) as one 60-bit word (a chain enters a segment at 0..17, at 12 or more only behind nine or more literals:
+        // the tile then ends with the segment before, which costs nothing but a short tile)
+        const uint32_t tlo = tab0 | (tab1 << 30), thi = tab1 >> 2;
         // (the two unrolled passes share nothing but w[]: without this the compiler keeps 32 decoded tokens alive, 149 VGPRs)
 #pragma unroll
         for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(w[k]));
         tock(t_dp);
         // ---- (2) the chain through the tile: entry of every segment.  Straight-line (a taken branch costs this wave ~50
         // cycles, four of them per segment made this loop the most expensive part of the tile): selects instead of
-        // branches, one exit test per 8 segments; segments behind nseg compute garbage that nothing uses.
-        uint32_t ent = 0, e = 0, nvalid = nseg, e_last = 0;
+        // branches, one exit test per 8 segments; segments behind the end compute garbage that nothing uses.
+        uint32_t ent = 0, e = 0, nvalid = nseg, e_next = 0;
 #pragma unroll
         for (uint32_t sg = 0; sg < kWgTileSegs; ++sg) {
-            if ((sg & 7u) == 0u && sg >= nseg) break;
+            if ((sg & 7u) == 0u && sg >= nvalid) break;
             ent = lane == sg ? e : ent;
-            const uint64_t ta = static_cast<uint64_t>(__builtin_amdgcn_readlane(tab0, sg)) | (static_cast<uint64_t>(__builtin_amdgcn_readlane(tab1, sg)) << 30);
-            const uint64_t tb = static_cast<uint64_t>(__builtin_amdgcn_readlane(tab2, sg)) | (static_cast<uint64_t>(__builtin_amdgcn_readlane(tab3, sg)) << 30);
-            const bool lo = e < 12u;
-            const uint32_t e2 = static_cast<uint32_t>((lo ? ta : tb) >> ((lo ? e : e - 12u) * 5u)) & 31u;
-            const bool special = e2 >= 20u;  // the chain meets a token for the scalar code inside this segment
-            nvalid = umin(nvalid, special ? sg + 1u : kWgTileSegs);
-            e = special ? 0u : e2;
-            e_last = sg + 1u == nseg ? e : e_last;  // entry of the segment behind the tile
+            // (the builtin returns int: through uint32_t, or the cast to 64 bits extends bit 31 over the upper entries)
+            const uint64_t tab = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(tlo, sg))) |
+                                 (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(thi, sg))) << 32);
+            const uint32_t e2 = static_cast<uint32_t>(tab >> (e * 5u)) & 31u;
+            // the tile ends behind this segment: it was the last one, or the chain leaves it at 12 or more (or through a
+            // token for the scalar code: 31, which the members pass turns into a stop inside the segment)
+            const bool last = (sg + 1u == nvalid) | (e2 >= 12u);
+            e_next = (last & (sg < nvalid)) ? e2 : e_next;
+            nvalid = last ? umin(nvalid, sg + 1u) : nvalid;
+            e = e2 >= 12u ? 0u : e2;
         }
         tock(t_chain);
         // ---- (3) members: the positions reachable from the entry; their output bytes; straight-line
@@ -412,11 +424,11 @@ __device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint
                     m &= m - 1u;
                 }
             }
-        } else if (nvalid < nseg) {
+        } else if (e_next >= 18u) {
             err = 7;  // (cannot happen: the chain saw a token for the scalar code that the members pass did not)
             break;
         } else {
-            adv = nseg * kWgSeg + e_last;
+            adv = nvalid * kWgSeg + e_next;
         }
         if (lane >= nvalid) {
             members = 0u;
@@ -489,8 +501,9 @@ __device__ void lz4wg_emit(WgLds& L, const uint32_t oend, const uint32_t lane, c
     auto room = [&](uint32_t at, uint32_t n) -> bool {
         if (__builtin_expect(at + n <= s_seen + kWgMR && at + n <= d_seen + kWgAhead, 1)) return true;
         return wg_wait_timed<PROF>(L, t_wait, [&] {
-            s_seen = wg_ld_min<kWgScan>(L.s_clr);
-            d_seen = wg_ld(&L.d_op);
+            const uint4 t = wg_ld4(L.s_clr);
+            s_seen = umin3(t.x, t.y, t.z);
+            d_seen = t.w;
             return at + n <= s_seen + kWgMR && at + n <= d_seen + kWgAhead;
         });
     };
@@ -630,10 +643,12 @@ __device__ void lz4wg_scan(WgLds& L, const uint32_t oend, const uint32_t lane, c
     auto frontier = [&]() -> uint32_t {
         const uint32_t walk = wg_ld(&L.p_walk);
         for (;;) {
-            const uint32_t t = wg_ld_min<kWgEmit>(L.q_tail);
-            if (t >= wg_ld(&L.q_head)) return walk;
+            const uint4 a = wg_ld4(L.q_tail);
+            const uint32_t t = umin3(a.x, a.y, a.z);
+            if (t >= a.w) return walk;
             const uint32_t at = wg_ld(&L.q[t & (kWgQ - 1u)].x) & 0xFFFFFFFu;
-            if (wg_ld_min<kWgEmit>(L.q_tail) == t) return at;
+            const uint4 b = wg_ld4(L.q_tail);
+            if (umin3(b.x, b.y, b.z) == t) return at;
         }
     };
     for (uint32_t kc = which; kc * kWgChunk < oend; kc += kWgScan) {
@@ -777,7 +792,7 @@ __device__ void lz4wg_copy(WgLds& L, uint8_t* __restrict__ dst, const uint32_t o
 // (eight waves: two per SIMD, so that the two workgroups the LDS allows on a CU always fit side by side; with ten, 3 + 3
 // waves of the two workgroups landed on one SIMD, more than 92 VGPRs allow, and a CU held ONE workgroup)
 template <bool PROF>
-__global__ __launch_bounds__(kWgThreads) void lz4_decode_wg(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks,
+__global__ __launch_bounds__(kWgThreads, 4) void lz4_decode_wg(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks,
                                                             uint8_t* __restrict__ out, uint32_t* __restrict__ status,
                                                             unsigned long long* __restrict__ tally)
 {
