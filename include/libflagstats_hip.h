@@ -184,13 +184,18 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *   "fence_free_events" FLAGSTATS_hip_stream_wait_stream / the overlapped all-reduce: 1 = ordering events without the
  *                    system-scope fence (default 0)
  *   "lz4_decoder"    LZ4 block files (FLAGSTATS_hip_blockfile*, blockimage_lz4): 0 = decode on host threads into pinned
- *                    chunks (decoded flags cross PCIe), 1 = decode on the GPU (the compressed bytes cross PCIe, one wave
- *                    per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default 1 GiB
- *                    compressed: the measured break-even, profiles/r03/lz4_decoder_sweep.log), on the host below.  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
- *   "lz4_gpu_keep_bytes" device memory the GPU LZ4 decoder may keep between calls (default 16 GiB; its two buffers -- a
- *                    segment's compressed and decoded bytes -- are reused by the next file: allocating them right after
- *                    freeing them was measured to stall ~0.5 s on the driver wiping the freed memory); 0 = free after
- *                    every call.  Read-only "lz4_gpu_kept_bytes": what is held now (FLAGSTATS_hip_shutdown frees it)
+ *                    chunks (decoded flags cross PCIe), 1 = decode on the GPU (the compressed bytes cross PCIe, one
+ *                    workgroup per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default
+ *                    128 MiB compressed: the measured break-even of an LZ4-fast file, an LZ4-HC file wins from 40 MiB,
+ *                    profiles/r04/lz4_decoder_sweep.log), on the host below.  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
+ *   "lz4_gpu_keep_bytes" device memory the GPU LZ4 decoder may keep between calls: its two buffers -- a segment's
+ *                    compressed and decoded bytes -- are reused by the next file (allocating them right after freeing
+ *                    them was measured to stall ~0.5 s on the driver wiping the freed memory).  Default ~0 = automatic:
+ *                    what the last call needed, at most a quarter of the device; in every mode they are released once
+ *                    eight calls of other entry points of the engine have passed, by a failed call and by
+ *                    FLAGSTATS_hip_shutdown; 0 = free after every call.  Read-only "lz4_gpu_kept_bytes": held now
+ *   "lz4_gpu_kernel" 0 (default) = the workgroup decode kernel (eight waves per block, 64 KiB LZ4 window in LDS),
+ *                    1 = r03's one wave per block (kept as the yardstick)
  * Read-only keys of FLAGSTATS_hip_get: "grid" (K1 workgroups), "numa_node" (of the default device),
  * "host_chunks" / "host_overlapped" (last multi-chunk host-pointer call on the default engine: chunks
  * submitted / chunks handed over while the previous chunk's copy + kernel were still in flight).

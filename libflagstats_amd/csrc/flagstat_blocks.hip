@@ -291,6 +291,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
 
     // the engine's host pipeline (staging buffers, two streams, counters, pinned chunks) is one resource
     std::lock_guard<std::mutex> lk(eng.mu);
+    fsint::lz4_gpu_other_use(eng);  // (the GPU LZ4 decoder's kept buffers go after eight calls that did not use it)
     fsint::DeviceGuard guard(eng.device);
     if (!guard.ok()) return -1;
     if (!chunks.empty()) {
@@ -583,7 +584,9 @@ int run_gpu_lz4(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, 
     src.threads = threads;
     FLAGSTATS_gpu_lz4_stats g;
     const int rc = fsint::lz4_gpu_run(eng, src, out, &g);
-    if (rc) return rc;
+    if (rc == fsint::kLz4GpuNoMemory && fsint::knobs().lz4_decoder.load() == 1)
+        return fsint::fail_text("GPU LZ4 decoder: the device cannot hold the file's compressed and decoded bytes");
+    if (rc) return rc;  // (kLz4GpuNoMemory with the decoder chosen by size: the caller takes the host-thread pipeline)
     if (st) {
         *st = FLAGSTATS_blockfile_stats{};
         st->n_flags = g.n_flags;
@@ -610,8 +613,10 @@ int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FL
     static const uint8_t empty = 0;
     fsint::Engine* eng = fsint::default_engine();
     if (!eng) return -1;
-    if (codec == 0 && lz4_on_gpu(bytes))
-        return run_gpu_lz4(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, superset, out, stats);
+    if (codec == 0 && lz4_on_gpu(bytes)) {
+        const int rc = run_gpu_lz4(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, superset, out, stats);
+        if (rc != fsint::kLz4GpuNoMemory) return rc;
+    }
     Source in;
     in.img = image ? static_cast<const uint8_t*>(image) : &empty;
     in.bytes = bytes;
@@ -643,8 +648,10 @@ int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_
     if (codec == 0 && lz4_on_gpu(bytes)) {
         fsint::Engine* eng = fsint::default_engine();
         const int rc = eng ? run_gpu_lz4(*eng, nullptr, fd, bytes, threads, superset, out, stats) : -1;
-        close(fd);
-        return rc;
+        if (rc != fsint::kLz4GpuNoMemory) {
+            close(fd);
+            return rc;
+        }
     }
     const char* io = std::getenv("FLAGSTATS_HIP_BLOCK_IO");
     void* map = MAP_FAILED;

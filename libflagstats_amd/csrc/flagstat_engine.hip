@@ -134,11 +134,7 @@ void release_engine_resources(Engine& e)
         if (e.stage[i]) (void)hipFree(e.stage[i]);
         if (e.stream[i]) (void)hipStreamDestroy(e.stream[i]);
     }
-    for (int i = 0; i < 2; ++i) {
-        if (e.lz4_buf[i]) (void)hipFree(e.lz4_buf[i]);
-        e.lz4_buf[i] = nullptr;
-        e.lz4_cap[i] = 0;
-    }
+    lz4_gpu_release(e, true);
     for (auto& kv : e.user_ws)
         if (kv.second.partials) (void)hipFree(kv.second.partials);
     e.user_ws.clear();
@@ -662,6 +658,7 @@ int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
     if (engine_alive(e)) return -1;
     DeviceGuard guard(e.device);
     if (!guard.ok()) return -1;
+    lz4_gpu_other_use(e);
     const uint64_t chunk = g_knobs.chunk_flags.load() < 8 ? 8 : g_knobs.chunk_flags.load();
     const int slots = (n > chunk) ? 2 : 1;
     int rc = 0;

@@ -1,25 +1,27 @@
-// flagstat_lz4_gpu.hip -- the LZ4 block decode of row f1 ON the GPU (behind the block-file entries
-// for large files, knob "lz4_decoder").
+// flagstat_lz4_gpu.hip -- host side of the LZ4 block decode ON the GPU (row f1; the kernels are flagstat_lz4_kernels.hip,
+// behind the block-file entries for large files, knob "lz4_decoder").  Plain host code: no device code in this file, so
+// it also builds against the test-only HIP stand-in (tests/hoststub) and runs under ThreadSanitizer.
 //
 // The reference's block reader decodes every block with liblz4's LZ4_decompress_safe on the host
 // (benchmark/flagstats.cpp:311-316); the host pipeline of this repo (flagstat_blocks.hip) does the same on N host threads
 // and is PCIe-bound on the DECODED bytes (27 Gflags/s).  Here the file crosses PCIe as it is (2.1-3.4x fewer bytes) and is
-// decoded on the device.  An LZ4 block is one serial chain of ~156,000 sequences per 1,024,000-byte block, so it is ONE
-// WAVE PER BLOCK -- a wave decodes ~35 MB/s, but 4,352 of them are resident at once:
-//   * compressed bytes staged through a 1 KiB LDS window (coalesced 16-byte loads),
-//   * the last 8 KiB of output kept in an LDS ring, so a match copy is ds_read -> ds_write for every offset up to
-//     8,128; farther matches read the already flushed output back from global memory,
-//   * up to 16 bare sequences (3 input bytes each) parsed AT ONCE by 16 lanes, output positions by a DPP prefix sum,
-//   * copied in PASSES of up to four sequences that do not read each other's output: one LDS read and one write for
-//     all of them, each on a row of 16 lanes, their words gathered through a small LDS table read one pass ahead,
-//   * the ring flushed to global memory 2 KiB at a time with coalesced 16-byte stores,
-//   * every index masked or checked: a malformed block sets its status word and stops, it cannot fault.
-// 9.3 KiB of LDS per wave = 17 waves per CU.  The decoder is bound by the chain of dependent LDS round trips of a wave
-// when the chip is half empty and by instruction issue when every wave slot is taken: both reward fewer instructions
-// per sequence, which is what every step from the first version (161 ms for a 4 GiB file) to this one (30 ms) did.
-// Host side: lz4_gpu_run (pieces of the file on the copy stream, one decode launch per piece on its own stream, one
-// K1/K2 pass; file mode with a reader pool; segments for files larger than the device).  Measurements:
-// profiles/r03/gpu_lz4_4GiB.log, lz4_decoder_sweep.log; DESIGN.md section 4.
+// decoded on the device:
+//   * the file goes over in PIECES of whole blocks on the engine's copy stream (a piece = 1/16 of the file, 128..512
+//     blocks: the decode kernel holds 512 blocks at a time and a block takes 2.5-3.5 ms, so what is exposed behind the last
+//     copy is one small piece);
+//   * every piece's blocks are decoded by their own launch on one of FOUR decode streams as soon as the piece has landed,
+//     and COUNTED right behind it on the same stream (K1 adds to one counter array from any number of streams).  Four,
+//     because the runtime puts its streams on four hardware queues and launches that share a queue run one after the
+//     other, each for at least one block's 2.5-3.5 ms: sixteen pieces on sixteen streams measured 25 ms where eight on
+//     four take 13; and 128 blocks at least, so that a stream's next piece lands no sooner than its last one is decoded;
+//   * file mode reads with a pool of parallel preads into the engine's three pinned chunk buffers, one span ahead of the
+//     copies;
+//   * streams, events and the small device buffers are made once per engine; the two large buffers (compressed, decoded)
+//     stay with the engine between calls and are released when eight other calls have passed without the decoder
+//     (knob "lz4_gpu_keep_bytes"), on every failure, and by FLAGSTATS_hip_shutdown;
+//   * compressed and decoded bytes of a run are resident together, so a file larger than a third of the free device
+//     memory (or 16 GiB of flags) goes through in several segments.
+// Measurements: profiles/r04/lz4_*.log; DESIGN.md section 4.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -37,107 +39,172 @@
 #include "flagstat_engine.h"
 #include "flagstat_lz4_kernels.h"
 
-
 namespace fsint {
 
-// LZ4 block file, decoded ON the GPU.  The compressed bytes cross PCIe (2-3x fewer than the decoded flags the host pipeline
-// sends), in `pieces` of whole blocks on the engine's copy stream; every piece's blocks are decoded by their own launch of
-// lz4_decode_wave (one wave per block) on a decode stream of its own as soon as the piece has landed, so all but the last
-// piece's decode hides behind the copies; one K1/K2 pass then counts the whole decoded buffer.  Image mode copies
-// straight out of the caller's memory; file mode reads the file with `threads` parallel preads into the engine's three
-// pinned chunk buffers and copies from there.  e.mu must be held.
-// one segment: file bytes [file_lo, file_lo + bytes) hold `blocks` (offsets relative to the segment), dpos decoded bytes
+void lz4_gpu_release(Engine& e, bool all)
+{
+    for (int i = 0; i < 2; ++i) {
+        uint8_t* p = e.lz4_buf[i];
+        e.lz4_buf[i] = nullptr;
+        e.lz4_cap[i] = 0;
+        if (p) (void)hipFree(p);
+    }
+    if (!all) return;
+    for (hipStream_t& x : e.lz4_stream) {
+        if (x) (void)hipStreamDestroy(x);
+        x = nullptr;
+    }
+    for (Workspace& w : e.lz4_ws) {
+        if (w.partials) (void)hipFree(w.partials);
+        w = Workspace{};
+    }
+    auto drop = [](hipEvent_t& x) {
+        if (x) (void)hipEventDestroy(x);
+        x = nullptr;
+    };
+    for (hipEvent_t& x : e.lz4_ev) drop(x);
+    for (hipEvent_t& x : e.lz4_landed) drop(x);
+    for (hipEvent_t& x : e.lz4_joined) drop(x);
+    for (hipEvent_t& x : e.lz4_pin_free) drop(x);
+    if (e.lz4_index) (void)hipFree(e.lz4_index);
+    e.lz4_index = nullptr;
+    e.lz4_index_cap = 0;
+    e.lz4_ready = false;
+}
+
+void lz4_gpu_other_use(Engine& e)
+{
+    if (!e.lz4_buf[0] && !e.lz4_buf[1]) return;
+    if (++e.lz4_idle >= static_cast<uint32_t>(Engine::kLz4IdleCalls)) lz4_gpu_release(e, false);
+}
+
+// streams, events: once per engine
+static int lz4_gpu_prepare(Engine& e)
+{
+    if (e.lz4_ready) return 0;
+    hipError_t err = hipSuccess;
+    for (hipStream_t& x : e.lz4_stream)
+        if (err == hipSuccess && !x) err = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
+    for (hipEvent_t& x : e.lz4_ev)
+        if (err == hipSuccess && !x) err = hipEventCreate(&x);
+    for (hipEvent_t& x : e.lz4_landed)
+        if (err == hipSuccess && !x) err = hipEventCreateWithFlags(&x, hipEventDisableTiming);
+    for (hipEvent_t& x : e.lz4_joined)
+        if (err == hipSuccess && !x) err = hipEventCreateWithFlags(&x, hipEventDisableTiming);
+    for (hipEvent_t& x : e.lz4_pin_free)
+        if (err == hipSuccess && !x) err = hipEventCreateWithFlags(&x, hipEventDisableTiming | hipEventBlockingSync);
+    if (err != hipSuccess) {
+        lz4_gpu_release(e, true);
+        return fail_hip("GPU LZ4 decoder: streams / events", err);
+    }
+    e.lz4_ready = true;
+    return 0;
+}
+
+// One segment: file bytes [file_lo, file_lo + bytes) hold `blocks` (offsets relative to the segment), dpos decoded bytes.
+// e.mu must be held.  Returns kLz4GpuNoMemory when the device cannot hold the buffers (nothing has been queued then).
 static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, const std::vector<fsk::GpuBlock>& blocks,
                            uint64_t bytes, uint64_t dpos, uint64_t n_flags, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
 {
     const uint8_t* img = in.img ? in.img + file_lo : nullptr;
-    uint8_t *d_comp = nullptr, *d_out = nullptr;
-    fsk::GpuBlock* d_blocks = nullptr;
-    uint32_t* d_status = nullptr;
-    unsigned long long* d_tally = nullptr;
-    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t landed[8] = {}, joined[8] = {}, pin_free[3] = {};
-    hipStream_t dec_stream[8] = {};
-    int rc = 0;
-    auto cleanup = [&] {
-        (void)hipStreamSynchronize(e.stream[0]);
-        for (hipStream_t x : dec_stream)
-            if (x) {
-                (void)hipStreamSynchronize(x);
-                (void)hipStreamDestroy(x);
-            }
-        if (d_blocks) (void)hipFree(d_blocks);
-        if (d_status) (void)hipFree(d_status);
-        if (d_tally) (void)hipFree(d_tally);
-        for (hipEvent_t x : ev)
-            if (x) (void)hipEventDestroy(x);
-        for (hipEvent_t x : landed)
-            if (x) (void)hipEventDestroy(x);
-        for (hipEvent_t x : joined)
-            if (x) (void)hipEventDestroy(x);
-        for (hipEvent_t x : pin_free)
-            if (x) (void)hipEventDestroy(x);
+    int rc = lz4_gpu_prepare(e);
+    if (rc) return rc;
+    hipStream_t s = e.stream[0];
+    constexpr uint32_t nstreams = Engine::kLz4Streams;
+    // everything queued so far must be over before an error leaves (the buffers may be released by the caller)
+    auto settle = [&] {
+        (void)hipStreamSynchronize(s);
+        for (hipStream_t x : e.lz4_stream) (void)hipStreamSynchronize(x);
     };
 #define LZG_TRY(expr)                            \
     do {                                         \
         hipError_t e_ = (expr);                  \
         if (e_ != hipSuccess) {                  \
             rc = fail_hip(#expr, e_);            \
-            cleanup();                           \
+            settle();                            \
             return rc;                           \
         }                                        \
     } while (0)
-    hipStream_t s = e.stream[0];
-    for (hipEvent_t& x : ev) LZG_TRY(hipEventCreate(&x));
     // the two large buffers belong to the engine and are reused by the next segment / file (knob "lz4_gpu_keep_bytes")
     const uint64_t want[2] = {bytes + 64, dpos + 16};
     for (int i = 0; i < 2; ++i)
         if (e.lz4_cap[i] < want[i]) {
-            if (e.lz4_buf[i]) LZG_TRY(hipFree(e.lz4_buf[i]));
+            uint8_t* old = e.lz4_buf[i];
             e.lz4_buf[i] = nullptr;
             e.lz4_cap[i] = 0;
+            if (old) LZG_TRY(hipFree(old));
             const uint64_t cap = (want[i] + (64ull << 20) - 1) & ~((64ull << 20) - 1);
-            LZG_TRY(hipMalloc(&e.lz4_buf[i], cap));
+            const hipError_t e_ = hipMalloc(&e.lz4_buf[i], cap);
+            if (e_ != hipSuccess) {
+                (void)hipGetLastError();
+                e.lz4_buf[i] = nullptr;
+                return kLz4GpuNoMemory;
+            }
             e.lz4_cap[i] = cap;
         }
-    d_comp = e.lz4_buf[0];
-    d_out = e.lz4_buf[1];
-    LZG_TRY(hipMalloc(&d_blocks, blocks.size() * sizeof(fsk::GpuBlock)));
-    LZG_TRY(hipMalloc(&d_status, blocks.size() * sizeof(uint32_t)));
-    LZG_TRY(hipMalloc(&d_tally, fsk::kLz4TallyWords * 8));
+    uint8_t* const d_comp = e.lz4_buf[0];
+    uint8_t* const d_out = e.lz4_buf[1];
+    // blocks | status | tally in one small allocation that grows with the largest segment seen
+    const uint64_t off_status = (blocks.size() * sizeof(fsk::GpuBlock) + 255) & ~255ull;
+    const uint64_t off_tally = (off_status + blocks.size() * sizeof(uint32_t) + 255) & ~255ull;
+    const uint64_t index_bytes = off_tally + fsk::kLz4TallyWords * 8;
+    if (e.lz4_index_cap < index_bytes) {
+        void* old = e.lz4_index;
+        e.lz4_index = nullptr;
+        e.lz4_index_cap = 0;
+        if (old) LZG_TRY(hipFree(old));
+        const uint64_t cap = (index_bytes + 65535) & ~65535ull;
+        const hipError_t e_ = hipMalloc(&e.lz4_index, cap);
+        if (e_ != hipSuccess) {
+            (void)hipGetLastError();
+            e.lz4_index = nullptr;
+            return kLz4GpuNoMemory;
+        }
+        e.lz4_index_cap = cap;
+    }
+    fsk::GpuBlock* const d_blocks = static_cast<fsk::GpuBlock*>(e.lz4_index);
+    uint32_t* const d_status = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(e.lz4_index) + off_status);
+    unsigned long long* const d_tally = reinterpret_cast<unsigned long long*>(static_cast<uint8_t*>(e.lz4_index) + off_tally);
     // only the slack between blocks (16-byte slots) and behind dropped odd bytes needs zero flags: blocks of the reference's
     // writer are whole multiples of 16 bytes, so this is normally nothing at all
     bool ragged = false;
     for (const fsk::GpuBlock& b : blocks) ragged = ragged || (b.dst_len & 15u);
+    LZG_TRY(hipEventRecord(e.lz4_ev[0], s));
     if (ragged) LZG_TRY(hipMemsetAsync(d_out, 0, dpos + 16, s));
     LZG_TRY(hipMemsetAsync(d_status, 0xFF, blocks.size() * sizeof(uint32_t), s));
     LZG_TRY(hipMemsetAsync(d_tally, 0, fsk::kLz4TallyWords * 8, s));
+    LZG_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), s));
     LZG_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(fsk::GpuBlock), hipMemcpyHostToDevice, s));
-    // env FLAGSTATS_HIP_GPU_LZ4_RING = 8 (default) | 16: KiB of recent output per wave in LDS (see lz4_decode_wave)
+    // env FLAGSTATS_HIP_GPU_LZ4_RING = 8 (default) | 16: KiB of recent output per wave in LDS (r03's kernel only)
     const char* rk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_RING");
     const bool big_ring = rk && std::atoi(rk) == 16;
-    // knob "lz4_gpu_kernel": 0 = the workgroup pipeline (three waves per block, 64 KiB window in LDS), 1 = r03's wave per block
+    // knob "lz4_gpu_kernel": 0 = the workgroup pipeline (eight waves per block, 64 KiB window in LDS), 1 = r03's wave per block
     const int kernel = knobs().lz4_gpu_kernel.load() == 0 ? fsk::LZ4K_WORKGROUP : (big_ring ? fsk::LZ4K_WAVE_RING16 : fsk::LZ4K_WAVE);
     const char* pk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");  // tuning: per-phase wave cycles on stderr
     const bool prof = pk && std::atoi(pk) != 0;
-    // pieces: a decode launch lasts as long as its slowest block whatever its size (one wave decodes ~35 MB/s), and
-    // launches on one stream run one after the other -- so few, large pieces, each on a stream of its own.  Default:
-    // one piece per 1024 blocks, at most 4.  env FLAGSTATS_HIP_GPU_LZ4_CHUNKS / _STREAMS override (tuning).
+    // Pieces.  The workgroup kernel holds 512 blocks at a time and a block takes 2.5-3.5 ms whatever else runs, so the
+    // decode time left exposed behind the last copy is one piece's: 1/16 of the file each, but not under 128 blocks (PCIe
+    // delivers ~120-180 blocks a millisecond: with four streams a stream's next piece then lands when its last one is
+    // done, launches that queue up behind each other are lost time) nor over 512.  r03's kernel wants few large ones (a
+    // launch lasts 20-30 ms however small): one per 1024 blocks, at most 4.  env FLAGSTATS_HIP_GPU_LZ4_CHUNKS overrides.
     const char* ck = std::getenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS");
-    const char* sk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_STREAMS");
-    uint32_t npieces = ck ? static_cast<uint32_t>(std::atoi(ck)) : static_cast<uint32_t>((blocks.size() + 1023) / 1024);
-    if (!ck && npieces > 4) npieces = 4;
+    uint32_t npieces;
+    if (ck) {
+        npieces = static_cast<uint32_t>(std::atoi(ck));
+    } else if (kernel == fsk::LZ4K_WORKGROUP) {
+        uint64_t per = blocks.size() / 16;
+        per = per < 128 ? 128 : (per > 512 ? 512 : per);
+        npieces = static_cast<uint32_t>((blocks.size() + per - 1) / per);
+    } else {
+        npieces = static_cast<uint32_t>((blocks.size() + 1023) / 1024);
+        if (npieces > 4) npieces = 4;
+    }
     if (npieces < 1) npieces = 1;
-    if (npieces > 8) npieces = 8;
+    if (npieces > static_cast<uint32_t>(Engine::kLz4MaxPieces)) npieces = Engine::kLz4MaxPieces;
     if (npieces > blocks.size()) npieces = static_cast<uint32_t>(blocks.size());
-    uint32_t nstreams = sk ? static_cast<uint32_t>(std::atoi(sk)) : npieces;
-    if (nstreams < 1) nstreams = 1;
-    if (nstreams > npieces) nstreams = npieces;
-    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamCreateWithFlags(&dec_stream[i], hipStreamNonBlocking));
-    for (uint32_t i = 0; i < npieces; ++i) LZG_TRY(hipEventCreateWithFlags(&landed[i], hipEventDisableTiming));
-    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipEventCreateWithFlags(&joined[i], hipEventDisableTiming));
     // file mode: the engine's pinned chunk buffers, filled by parallel preads
     uint8_t* pinned[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t* const pin_free = e.lz4_pin_free;
     uint64_t span_cap = 0;
     int readers = 0;
     if (!img) {
@@ -146,19 +213,16 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         void* bufs[3];
         rc = pinned_reserve(e, span_cap, bufs);
         if (rc) {
-            cleanup();
+            settle();
             return rc;
         }
-        for (int i = 0; i < 3; ++i) {
-            pinned[i] = static_cast<uint8_t*>(bufs[i]);
-            LZG_TRY(hipEventCreateWithFlags(&pin_free[i], hipEventDisableTiming | hipEventBlockingSync));
-        }
+        for (int i = 0; i < 3; ++i) pinned[i] = static_cast<uint8_t*>(bufs[i]);
         readers = in.threads > 0 ? in.threads : static_cast<int>(std::thread::hardware_concurrency());
         if (readers > 16) readers = 16;
         if (readers < 1) readers = 1;
     }
-    LZG_TRY(hipEventRecord(ev[0], s));
-    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamWaitEvent(dec_stream[i], ev[0], 0));  // index on the device, status preset
+    LZG_TRY(hipEventRecord(e.lz4_ev[3], s));  // index on the device, status and counters preset
+    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamWaitEvent(e.lz4_stream[i], e.lz4_ev[3], 0));
     // pieces: blocks [first, last) = segment bytes [lo, hi), split by compressed bytes
     struct Piece {
         uint64_t first, last, lo, hi;
@@ -173,16 +237,20 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         first = last;
     }
     const uint32_t pieces_done = static_cast<uint32_t>(pieces.size());
-    // piece c has been queued on the copy stream: decode its blocks behind it
+    // piece c has been queued on the copy stream: decode its blocks behind it, and count them behind that
     auto launch_piece = [&](uint32_t c) -> int {
-        hipError_t e_ = hipEventRecord(landed[c], s);
-        hipStream_t ds = dec_stream[c % nstreams];
-        if (e_ == hipSuccess) e_ = hipStreamWaitEvent(ds, landed[c], 0);
+        hipError_t e_ = hipEventRecord(e.lz4_landed[c], s);
+        hipStream_t ds = e.lz4_stream[c % nstreams];
+        if (e_ == hipSuccess) e_ = hipStreamWaitEvent(ds, e.lz4_landed[c], 0);
         if (e_ != hipSuccess) return fail_hip("hipEventRecord / hipStreamWaitEvent(piece landed)", e_);
         const Piece& pc = pieces[c];
         e_ = fsk_lz4_decode(kernel, d_comp, d_blocks + pc.first, static_cast<uint32_t>(pc.last - pc.first), d_out, d_status + pc.first,
                             d_tally, prof ? 1 : 0, ds);
-        return e_ == hipSuccess ? 0 : fail_hip("LZ4 decode kernel launch", e_);
+        if (e_ != hipSuccess) return fail_hip("LZ4 decode kernel launch", e_);
+        const uint64_t d0 = blocks[pc.first].dst_off;
+        const uint64_t d1 = blocks[pc.last - 1].dst_off + ((static_cast<uint64_t>(blocks[pc.last - 1].dst_len) + 15) & ~15ull);
+        return count_device_async(e, reinterpret_cast<const uint16_t*>(d_out + d0), (d1 - d0) / 2, e.d_out[0], ds, e.lz4_ws[c % nstreams],
+                                  OP_FLAGSTAT | (in.superset ? OP_SUPERSET : 0));
     };
     if (img) {
         for (uint32_t c = 0; c < pieces.size() && !rc; ++c) {
@@ -270,23 +338,15 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         for (std::thread& t : pool) t.join();
     }
     if (rc) {
-        cleanup();
+        settle();
         return rc;
     }
-    LZG_TRY(hipEventRecord(ev[1], s));  // every piece has landed
+    LZG_TRY(hipEventRecord(e.lz4_ev[1], s));  // every piece has landed
     for (uint32_t i = 0; i < nstreams; ++i) {
-        LZG_TRY(hipEventRecord(joined[i], dec_stream[i]));
-        LZG_TRY(hipStreamWaitEvent(s, joined[i], 0));
+        LZG_TRY(hipEventRecord(e.lz4_joined[i], e.lz4_stream[i]));
+        LZG_TRY(hipStreamWaitEvent(s, e.lz4_joined[i], 0));
     }
-    LZG_TRY(hipEventRecord(ev[2], s));  // ... and is decoded
-    LZG_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), s));
-    rc = count_device_async(e, reinterpret_cast<const uint16_t*>(d_out), dpos / 2, e.d_out[0], s, e.ws[0],
-                            OP_FLAGSTAT | (in.superset ? OP_SUPERSET : 0));
-    if (rc) {
-        cleanup();
-        return rc;
-    }
-    LZG_TRY(hipEventRecord(ev[3], s));
+    LZG_TRY(hipEventRecord(e.lz4_ev[2], s));  // ... is decoded and counted
     LZG_TRY(hipMemcpyAsync(e.h_out, e.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
     unsigned long long tally[fsk::kLz4TallyWords] = {0};
     LZG_TRY(hipMemcpyAsync(tally, d_tally, sizeof tally, hipMemcpyDeviceToHost, s));
@@ -303,11 +363,10 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             }
             ++bad;
         }
-    float h2d = 0, dec = 0, cnt = 0, pipe = 0;
-    LZG_TRY(hipEventElapsedTime(&h2d, ev[0], ev[1]));
-    LZG_TRY(hipEventElapsedTime(&dec, ev[1], ev[2]));
-    LZG_TRY(hipEventElapsedTime(&cnt, ev[2], ev[3]));
-    LZG_TRY(hipEventElapsedTime(&pipe, ev[0], ev[3]));
+    float h2d = 0, dec = 0, pipe = 0;
+    LZG_TRY(hipEventElapsedTime(&h2d, e.lz4_ev[0], e.lz4_ev[1]));
+    LZG_TRY(hipEventElapsedTime(&dec, e.lz4_ev[1], e.lz4_ev[2]));
+    LZG_TRY(hipEventElapsedTime(&pipe, e.lz4_ev[0], e.lz4_ev[2]));
     if (prof) {
         std::fprintf(stderr, "lz4 gpu profile: kernel %d, %d block(s) per CU fit\n", kernel, fsk_lz4_blocks_per_cu(kernel));
         if (kernel == fsk::LZ4K_WORKGROUP) {
@@ -335,7 +394,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     stats->bad_blocks += bad;
     stats->h2d_ms += h2d;
     stats->decode_ms += dec;
-    stats->count_ms += cnt;
+    stats->count_ms += 0;  // (a piece is counted behind its decode: part of decode_ms)
     stats->sequences += tally[0];
     stats->far_matches += tally[1];
     stats->ring_kib = kernel == fsk::LZ4K_WORKGROUP ? 66 : (kernel == fsk::LZ4K_WAVE ? 8 : 16);
@@ -346,7 +405,6 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         if (in.superset) e.h_out[9] -= dpos / 2 - n_flags;  // zero flags in the slack between blocks are not reads (see run_pipeline)
         for (int k = 0; k < 32; ++k) out[k] += e.h_out[k];
     }
-    cleanup();
     if (bad) {
         char buf[192];
         std::snprintf(buf, sizeof buf, "block file: %llu block(s) failed to decode to their declared size (GPU LZ4 decoder; first: block %llu, code %u)",
@@ -426,16 +484,25 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
             seg_flags += static_cast<uint64_t>(g.dst_len) >> 1;
         }
         const int rc = lz4_gpu_segment(e, in, file_lo, seg, file_hi - file_lo, dsz, seg_flags, out, stats);
-        if (rc) return rc;
+        if (rc) {
+            // nothing of a failed run stays on the device; a file the device cannot hold may still go through the host pipeline
+            // (only if nothing has been added to out[] yet)
+            lz4_gpu_release(e, false);
+            if (rc == kLz4GpuNoMemory && b0 != 0) return fail_text("GPU LZ4 decoder: out of device memory in a later segment");
+            return rc;
+        }
         ++stats->segments;
         b0 = b1;
     }
-    if (e.lz4_cap[0] + e.lz4_cap[1] > knobs().lz4_gpu_keep_bytes.load()) {
-        for (int i = 0; i < 2; ++i) {
-            if (e.lz4_buf[i]) (void)hipFree(e.lz4_buf[i]);
-            e.lz4_buf[i] = nullptr;
-            e.lz4_cap[i] = 0;
+    // what stays with the engine for the next call: knob "lz4_gpu_keep_bytes" (~0 = automatic: at most a quarter of the device)
+    e.lz4_idle = 0;
+    {
+        uint64_t keep = knobs().lz4_gpu_keep_bytes.load();
+        if (keep == ~0ull) {
+            size_t free_b = 0, total_b = 0;
+            keep = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 4 : 0;
         }
+        if (e.lz4_cap[0] + e.lz4_cap[1] > keep) lz4_gpu_release(e, false);
     }
     stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     return 0;

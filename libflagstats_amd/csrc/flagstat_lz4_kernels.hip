@@ -56,8 +56,6 @@ constexpr uint32_t kWgSpan = 384;                  // most output bytes the emit
 constexpr uint32_t kWgFlush = 1024;
 constexpr uint32_t kWgSpinLimit = 1u << 19;        // polls before a wait gives up (a logic error must not hang the GPU)
 constexpr uint32_t kMarkLiteral = 0x10000u;        // marker: a literal run starts here (matches: their offset, 1..65535)
-constexpr uint32_t kNone = 0xFFFFFFFFu;
-constexpr uint64_t kStride3 = 0x9249249249249249ull;  // bits 0, 3, 6, ..., 63
 enum { REC_WINDOW = 0, REC_SEQ = 1, REC_END = 2 };
 static_assert(kWgThreads == 512 && kWgEmit == 3 && kWgScan == 3, "two waves per SIMD; three positions and one more word per 16-byte poll");
 static_assert(kWgNR % kWgFlush == 0 && kWgNR % kWgChunk == 0 && kWgMR % kWgChunk == 0 && kWgK % kWgChunk == 0, "grids");
@@ -204,10 +202,6 @@ __device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint
             pend_a = pend_b;
             pend_b = *reinterpret_cast<const uint4*>(src + umin(in_hi + 1024u + lane * 16u, iend));
         }
-    };
-    auto ridx = [&](uint32_t pos) -> uint32_t {  // index into inw of input position pos (ip <= pos < ip + kWgInw)
-        const uint32_t r = ip_r + (pos - ip);
-        return r >= kWgInw ? r - kWgInw : r;
     };
     auto advance = [&](uint32_t n) {
         ip += n;

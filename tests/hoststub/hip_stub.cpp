@@ -210,6 +210,13 @@ hipError_t hipHostMalloc(void** p, size_t bytes, unsigned)
     remember(*p, bytes, hipMemoryTypeHost);
     return hipSuccess;
 }
+hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes)
+{
+    if (free_bytes) *free_bytes = 8ull << 30;
+    if (total_bytes) *total_bytes = 16ull << 30;
+    return hipSuccess;
+}
+
 hipError_t hipHostFree(void* p)
 {
     if (!p) return hipSuccess;
@@ -477,8 +484,32 @@ void fsk_set_epoch_stagger(int) {}
 
 }  // extern "C"
 
-// the GPU LZ4 decoder (flagstat_lz4_gpu.hip) is device code: not part of the host build; small files never reach it (knob "lz4_decoder")
-namespace fsint {
-int lz4_gpu_run(Engine&, const Lz4GpuSource&, uint64_t*, FLAGSTATS_gpu_lz4_stats*) { return fail_text("GPU LZ4 decoder: not in the host stub build"); }
-}  // namespace fsint
+// The GPU LZ4 decoder's KERNEL is device code; its host side (flagstat_lz4_gpu.hip: pieces, reader pool, span recycling,
+// cached buffers) is part of this build.  The stand-in "kernel" decodes the launch's blocks on the stream's worker thread with
+// the PRODUCT's own host decoder (lz4_block_decode.h), so copies, decode and counting touch the same buffers in the same
+// order as on the device.
+#include "../../libflagstats_amd/csrc/flagstat_lz4_kernels.h"
+#include "../../libflagstats_amd/csrc/lz4_block_decode.h"
 
+extern "C" hipError_t fsk_lz4_decode(int kernel, const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out,
+                                     uint32_t* status, unsigned long long* tally, int, hipStream_t stream)
+{
+    if (nblocks == 0) return hipSuccess;
+    if (!comp || !blocks || !out || !status || !tally || kernel < 0 || kernel > 2) return hipErrorInvalidValue;
+    enqueue(stream, [=] {
+        for (uint32_t i = 0; i < nblocks; ++i) {
+            const fsk::GpuBlock b = blocks[i];
+            std::vector<uint8_t> tmp(b.dst_len + 64);
+            const int64_t got = fslz4::lz4_block_decode(comp + b.src_off, b.src_len, tmp.data(), b.dst_len);
+            if (got == static_cast<int64_t>(b.dst_len)) {
+                std::memcpy(out + b.dst_off, tmp.data(), b.dst_len & ~1u);  // (an odd trailing byte is dropped, like the kernel)
+                status[i] = 0;
+            } else {
+                status[i] = 5;
+            }
+            __atomic_fetch_add(&tally[0], 1ull, __ATOMIC_RELAXED);
+        }
+    });
+    return hipSuccess;
+}
+extern "C" int fsk_lz4_blocks_per_cu(int) { return 2; }

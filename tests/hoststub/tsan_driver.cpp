@@ -8,6 +8,7 @@
 #include <string>
 #include <thread>
 #include <vector>
+#include <unistd.h>
 
 #include "../../include/libflagstats_hip.h"
 extern "C" {
@@ -71,6 +72,77 @@ static void block_pipeline(const std::vector<uint16_t>& flags, const uint64_t* w
         CHECK(rc == 0 && same(out, want), "block image, %d decoder threads: rc %d (%s)", threads, rc, FLAGSTATS_hip_last_error());
         CHECK(st.n_flags == flags.size(), "block image: %llu flags seen", static_cast<unsigned long long>(st.n_flags));
     }
+}
+
+// the GPU LZ4 decoder's host side (flagstat_lz4_gpu.hip): pieces on four decode streams with a count behind each, the
+// reader pool of file mode with its pinned spans recycled by events, segments, the kept buffers and their release --
+// image and file mode, 1 / 5 / 16 readers, a truncated file, a damaged block.  The stand-in kernel is the product's
+// host decoder.
+static void gpu_decoder_host_side(const std::vector<uint16_t>& flags, const uint64_t* want, const std::string& dir)
+{
+    const std::vector<unsigned char> img = make_image(flags, {51200, 512000, 7, 300001, 123456});
+    CHECK(FLAGSTATS_hip_set("lz4_decoder", 1) == 0, "lz4_decoder 1");
+    FLAGSTATS_hip_set("chunk_flags", 8);  // (spans of the floor size, 4 MiB: several per file)
+    for (const char* pieces : {"", "1", "7"}) {
+        if (*pieces)
+            setenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS", pieces, 1);
+        else
+            unsetenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS");
+        uint64_t out[32] = {0};
+        FLAGSTATS_blockfile_stats st;
+        int rc = FLAGSTATS_hip_blockimage_lz4(img.data(), img.size(), 0, out, &st);
+        CHECK(rc == 0 && same(out, want) && st.gpu_decode == 1, "GPU decoder, image, pieces '%s': rc %d (%s)", pieces, rc, FLAGSTATS_hip_last_error());
+        const std::string path = "/tmp/flagstats_tsan_" + std::to_string(getpid()) + ".lz4";
+        FILE* f = std::fopen(path.c_str(), "wb");
+        CHECK(f && std::fwrite(img.data(), 1, img.size(), f) == img.size(), "write %s", path.c_str());
+        if (f) std::fclose(f);
+        for (int readers : {1, 5, 16}) {
+            uint64_t o2[32] = {0};
+            rc = FLAGSTATS_hip_blockfile_lz4(path.c_str(), readers, o2, &st);
+            CHECK(rc == 0 && same(o2, want) && st.gpu_decode == 1, "GPU decoder, file, %d readers: rc %d (%s)", readers, rc, FLAGSTATS_hip_last_error());
+        }
+        // a file cut inside a payload, and one with a damaged block: loud, and nothing stays on the device
+        f = std::fopen(path.c_str(), "wb");
+        if (f) {
+            std::fwrite(img.data(), 1, img.size() - 1000, f);
+            std::fclose(f);
+        }
+        uint64_t o3[32] = {0};
+        CHECK(FLAGSTATS_hip_blockfile_lz4(path.c_str(), 5, o3, nullptr) != 0, "a truncated file must fail");
+        std::vector<unsigned char> bad = img;
+        bad[9] = 0x00;  // the first block's literal run now ends after 15 bytes: what follows is no valid sequence
+        uint64_t o4[32] = {0};
+        CHECK(FLAGSTATS_hip_blockimage_lz4(bad.data(), bad.size(), 0, o4, nullptr) != 0, "a damaged block must fail");
+        CHECK(FLAGSTATS_hip_get("lz4_gpu_kept_bytes") == 0, "a failed call keeps nothing on the device");
+        std::remove(path.c_str());
+    }
+    unsetenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS");
+    // segments (files larger than the device may hold at once) and the idle rule of the kept buffers
+    setenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES", "2000000", 1);
+    {
+        uint64_t out[32] = {0};
+        FLAGSTATS_gpu_lz4_stats gs;
+        const int rc = FLAGSTATS_hip_blockimage_lz4_gpu(img.data(), img.size(), out, &gs);
+        CHECK(rc == 0 && same(out, want) && gs.segments >= 3, "segments: rc %d, %llu segments", rc, static_cast<unsigned long long>(gs.segments));
+    }
+    unsetenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES");
+    CHECK(FLAGSTATS_hip_get("lz4_gpu_kept_bytes") > 0, "the buffers stay for the next call");
+    for (int i = 0; i < 8; ++i) {
+        uint32_t got[32] = {0};
+        FLAGSTATS_u16(flags.data(), 1000, got);
+    }
+    CHECK(FLAGSTATS_hip_get("lz4_gpu_kept_bytes") == 0, "... and go after eight other calls");
+    if (!dir.empty()) {
+        for (const char* name : {"exact2_fast_a1.lz4", "hc_HC_c9.lz4", "ragged_fast_a2.lz4", "tiny_fast_a2.lz4"}) {
+            uint64_t a[32] = {0}, b[32] = {0};
+            CHECK(FLAGSTATS_hip_blockfile((dir + "/" + name).c_str(), 5, a, nullptr) == 0, "%s on the GPU decoder's host side", name);
+            FLAGSTATS_hip_set("lz4_decoder", 0);
+            CHECK(FLAGSTATS_hip_blockfile((dir + "/" + name).c_str(), 5, b, nullptr) == 0 && same(a, b), "%s: host pipeline gives the same", name);
+            FLAGSTATS_hip_set("lz4_decoder", 1);
+        }
+    }
+    FLAGSTATS_hip_set("chunk_flags", 32ull << 20);
+    FLAGSTATS_hip_set("lz4_decoder", 2);
 }
 
 static void golden_files(const std::string& dir)
@@ -181,6 +253,7 @@ int main(int argc, char** argv)
     for (int round = 0; round < 2; ++round) {
         block_pipeline(flags, want);
         if (argc > 1) golden_files(argv[1]);
+        gpu_decoder_host_side(flags, want, argc > 1 ? argv[1] : "");
         sessions(flags, want);
         callers(flags);
         multi(flags, want);

@@ -188,7 +188,7 @@ def test_gpu_side_lz4_decode_rejects_damaged_blocks(hip):
 @pytest.fixture
 def gpu_decoder(hip):
     """knob lz4_decoder = 1: every LZ4 block file goes through the GPU decoder whatever its size (default 2: from 1 GiB)"""
-    assert hip.FLAGSTATS_hip_get(b"lz4_decoder") == 2 and hip.FLAGSTATS_hip_get(b"lz4_gpu_min_bytes") == 1 << 30
+    assert hip.FLAGSTATS_hip_get(b"lz4_decoder") == 2 and hip.FLAGSTATS_hip_get(b"lz4_gpu_min_bytes") == 128 << 20
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
     yield hip
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 2) == 0
@@ -255,7 +255,7 @@ def test_gpu_decoder_is_chosen_by_size_and_fails_loudly(gpu_decoder, tmp_path):
     assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", len(img)) == 0
     got, st = blockfile.flagstat_lz4_image(img, 2)
     assert np.array_equal(got, want) and st["gpu_decode"] == 1
-    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 1 << 30) == 0
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 128 << 20) == 0
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 3) != 0
     # damaged input: truncated header / payload, a header that claims more than the block holds, a corrupted payload
@@ -400,12 +400,14 @@ def test_gpu_decoder_goes_through_large_files_in_segments(gpu_decoder, tmp_path,
 
 
 def test_gpu_decoder_keeps_its_device_buffers_between_calls(gpu_decoder):
-    """The decoder's two large device buffers are reused by the next call (knob lz4_gpu_keep_bytes, default 16 GiB) and
-    given back when they exceed the limit; stale bytes of an earlier, larger file must not leak into a later one."""
+    """The decoder's two large device buffers are reused by the next call (knob lz4_gpu_keep_bytes; default automatic: what
+    the last call needed, at most a quarter of the device) and given back when they exceed the limit, after eight calls of
+    other entry points, and by a failed call; stale bytes of an earlier, larger file must not leak into a later one."""
     import oracle
-    from libflagstats_amd import blockfile
+    from libflagstats_amd import blockfile, pyflagstats
     hip = gpu_decoder
-    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_keep_bytes") == 16 << 30
+    auto = (1 << 64) - 1
+    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_keep_bytes") == auto
     big = oracle.generate(oracle.GEN_UNIFORM, 41, 0xFFFF, 0, 512000 * 6)
     got, _ = blockfile.flagstat_lz4_image(bt.block_file_image(big), 2)
     assert np.array_equal(got, expect(big, bt.BLOCK_BYTES)[0])
@@ -416,7 +418,23 @@ def test_gpu_decoder_keeps_its_device_buffers_between_calls(gpu_decoder):
     got, st = blockfile.flagstat_lz4_image(bt.block_file_image(small, block_bytes=9999), 2)
     assert st["gpu_decode"] == 1 and np.array_equal(got, expect(small, 9999)[0])
     assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == kept
+    # the idle rule: eight calls that do not use the decoder, and the buffers are gone
+    a = oracle.generate(oracle.GEN_UNIFORM, 43, 0xFFFF, 0, 5000)
+    for i in range(7):
+        pyflagstats.counters_u32(a)
+        assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == kept, i
+    pyflagstats.counters_u32(a)
+    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
+    # a damaged file leaves nothing behind either
+    img = bytearray(bt.block_file_image(small, block_bytes=9999))
+    img[len(img) // 2] ^= 0x5A
+    img[len(img) // 2 + 1] ^= 0xA5
+    try:
+        blockfile.flagstat_lz4_image(bytes(img), 2)
+    except Exception:
+        assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
+    # an explicit limit: 0 = free after every call
     assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", 0) == 0
     got, _ = blockfile.flagstat_lz4_image(bt.block_file_image(small, block_bytes=9999), 2)
     assert np.array_equal(got, expect(small, 9999)[0]) and hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
-    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", 16 << 30) == 0
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", auto) == 0
