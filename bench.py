@@ -182,39 +182,101 @@ def quantiles(ms):
 
 def spawn_ranks(nproc):
     """Be our own launcher: `nproc` fresh child processes of this script, one rank each.  The parent never imports
-    torch or the library (nothing here has initialised the GPU), relays rank 0's stdout -- the JSON line -- and the
-    other ranks' output to stderr, and returns the worst exit code.  A rank that dies takes the others with it."""
+    torch or the library (nothing here has initialised the GPU).  It relays rank 0's stdout -- the JSON line -- as it
+    comes (a reader thread), keeps every rank's stderr in a file of its own, and polls ALL children: the first rank that
+    exits non-zero, or a deadline that starts at spawn (env FLAGSTATS_BENCH_SPAWN_TIMEOUT, default 900 s), ends the run --
+    the children started here are killed (nothing is re-executed), the failing rank's stderr tail is printed, the exit
+    code is non-zero.  A rank that dies in communicator set-up therefore cannot leave the others, and this parent, inside
+    a collective until somebody else's timeout."""
     import socket
     import subprocess
+    import tempfile
+    import threading
 
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
-    procs = []
+    deadline = time.time() + float(os.environ.get("FLAGSTATS_BENCH_SPAWN_TIMEOUT", "900"))
+    procs, errs = [], []
     for r in range(nproc):
         env = dict(os.environ)
         env.update(RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(nproc), LOCAL_WORLD_SIZE=str(nproc),
                    MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        ef = tempfile.TemporaryFile(mode="w+b")
+        errs.append(ef)
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env,
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr))
-    out0 = procs[0].stdout
-    rc = 0
-    try:
-        for line in out0:                       # rank 0's stdout, as it comes
+                                      stdout=subprocess.PIPE if r == 0 else ef, stderr=ef))
+
+    def relay():
+        for line in procs[0].stdout:                # rank 0's stdout, as it comes
             sys.stdout.write(line.decode(errors="replace"))
             sys.stdout.flush()
-        deadline = time.time() + 600
-        for pr in procs:
-            pr.wait(timeout=max(1.0, deadline - time.time()))
-            rc = rc or pr.returncode
-    except (KeyboardInterrupt, subprocess.TimeoutExpired):
-        rc = rc or 1
+
+    th = threading.Thread(target=relay, daemon=True)
+    th.start()
+
+    def tail(r, lines=40):
+        errs[r].flush()
+        errs[r].seek(0)
+        text = errs[r].read().decode(errors="replace").splitlines()
+        return "\n".join(text[-lines:])
+
+    rc, why, culprit = 0, None, None
+    try:
+        while True:
+            codes = [pr.poll() for pr in procs]
+            bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
+            if bad:
+                culprit, rc = bad[0], codes[bad[0]]
+                why = "rank %d exited with code %d" % (culprit, rc)
+                break
+            if all(c == 0 for c in codes):
+                break
+            if time.time() > deadline:
+                culprit = next(r for r, c in enumerate(codes) if c is None)
+                rc, why = 124, "deadline passed with rank(s) %s still running" % [r for r, c in enumerate(codes) if c is None]
+                break
+            time.sleep(0.2)
+    except KeyboardInterrupt:
+        rc, why = 130, "interrupted"
     finally:
         for pr in procs:
             if pr.poll() is None:
-                pr.kill()                       # exactly the processes started here
-    return rc
+                pr.kill()                           # exactly the processes started here
+        for pr in procs:
+            try:
+                pr.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                pass
+        th.join(timeout=5)
+    for r in range(nproc):                          # every rank's stderr, in rank order (rank > 0: its stdout too)
+        text = tail(r, lines=10 ** 9)
+        if text:
+            sys.stderr.write(text + "\n")
+    if why:
+        sys.stderr.write("bench.py: multi-rank run FAILED: %s; the other ranks were stopped.\n" % why)
+        if culprit is not None:
+            sys.stderr.write("---- last lines of rank %d ----\n%s\n----\n" % (culprit, tail(culprit)))
+        sys.stderr.flush()
+        return rc if rc else 1
+    return 0
+
+
+def injected_fault(stage, rank):
+    """TEST ONLY (tests/test_bench_spawn.py, tests/test_gpu_bench_contract.py): env FLAGSTATS_BENCH_FAULT = "<rank>:<stage>[:hang]"
+    makes that rank exit with code 3 (or hang) when it reaches the stage: start | init | comm | warmup."""
+    spec = os.environ.get("FLAGSTATS_BENCH_FAULT", "")
+    if not spec:
+        return
+    parts = spec.split(":")
+    if len(parts) >= 2 and parts[0] == str(rank) and parts[1] == stage:
+        if len(parts) > 2 and parts[2] == "hang":
+            print("bench.py: injected fault: rank %d hangs at stage %s" % (rank, stage), file=sys.stderr, flush=True)
+            while True:
+                time.sleep(3600)
+        print("bench.py: injected fault: rank %d dies at stage %s" % (rank, stage), file=sys.stderr, flush=True)
+        os._exit(3)
 
 
 def main():
@@ -260,6 +322,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     args.gpus = world
+    injected_fault("start", rank)
 
     import numpy as np
     import torch
@@ -298,6 +361,7 @@ def main():
     ar_impl = None
     rccl_nranks = None
     if multi:
+        injected_fault("init", rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29531")
         if args.backend == "nccl":
@@ -305,6 +369,7 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
         ar_impl = "torch.distributed (%s)" % args.backend
+        injected_fault("comm", rank)
         if args.allreduce == "c-abi" and not args.same_device:
             # the library's own RCCL communicator: rank 0 makes the 128-byte id, the rendezvous ships it
             try:
@@ -518,6 +583,23 @@ def main():
     for _ in range(args.warmup):
         step()
     drain()
+    injected_fault("warmup", rank)
+    # N > 1, untimed: what the collective alone costs here (stream events around 10 all-reduces of a scratch uint64[32] on
+    # the launch stream; the slowest rank's figure) -- so that a first 8-GPU number can be read: step = K1 + K2 + this
+    allreduce_us = None
+    if multi:
+        scratch = torch.zeros(32, dtype=torch.int64, device=dev)
+        allreduce(scratch, main_stream)
+        torch.cuda.synchronize()
+        a0, a1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a0.record()
+        for _ in range(10):
+            allreduce(scratch, main_stream)
+        a1.record()
+        a1.synchronize()
+        t = torch.tensor([a0.elapsed_time(a1) * 100.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        allreduce_us = round(float(t[0]), 2)
     if not multi:
         counters.zero_()      # stream-ordered behind the warm-up steps: ONE sync gap before the timed region, not two
     # the per-step events exist (torch creates the HIP event at the first record) BEFORE the barrier: the GPU idles
@@ -539,7 +621,13 @@ def main():
     ev_ms = evs[0].elapsed_time(evs[args.steps])
     step_ms = [evs[i].elapsed_time(evs[i + 1]) for i in range(args.steps)]
 
+    per_rank_ms = None
     if multi:
+        # every rank's own event-timed mean step, gathered: a slow first 8-GPU number can then be laid at a rank's door
+        mine = torch.zeros(world, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        mine[rank] = ev_ms / args.steps
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank_ms = [round(float(x), 5) for x in mine.cpu()]
         tmax = torch.tensor([wall, ev_ms], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall, ev_ms = float(tmax[0]), float(tmax[1])
@@ -614,6 +702,9 @@ def main():
                        "allreduce": (("overlapped" if state["overlap"] else "in-line") + calib_note) if multi else None,
                        "allreduce_impl": ar_impl,
                        "rccl_nranks": rccl_nranks,
+                       "per_rank_ms": per_rank_ms,
+                       "slowest_rank": (max(range(world), key=lambda r: per_rank_ms[r]) if per_rank_ms else None),
+                       "allreduce_us": allreduce_us,
                        "kernel_variant": int(lib.FLAGSTATS_hip_get(b"variant")),
                        "grid_blocks": int(lib.FLAGSTATS_hip_get(b"grid")),
                        "kernel_source_id": kernel_source_id()},

@@ -78,3 +78,22 @@ def test_two_ranks_self_spawned_on_one_gpu(hip):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["global_flags"] == 2 * 2 ** 27
     assert d["config"]["parallelism"] == "shard2" and d["config"]["allreduce"].split()[0] == "in-line"
     assert d["parity"].startswith("bit-exact") and "all 2 shards" in d["parity"]
+    # what lets a reader attribute a slow multi-GPU number: every rank's own step time, the slowest rank, the collective alone
+    c = d["config"]
+    assert len(c["per_rank_ms"]) == 2 and all(t > 0 for t in c["per_rank_ms"]) and c["slowest_rank"] in (0, 1)
+    assert c["per_rank_ms"][c["slowest_rank"]] == max(c["per_rank_ms"]) and c["allreduce_us"] > 0
+
+
+def test_a_rank_that_dies_in_set_up_fails_the_run_quickly(hip):
+    """A rank killed (injected fault) after the rendezvous but before the communicator: rank 0 is left inside a
+    collective; the launching parent must notice the dead rank, stop rank 0 and return non-zero within 30 s."""
+    import time
+    env = dict(os.environ, FLAGSTATS_BENCH_FAULT="1:comm")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--same-device", "--backend", "gloo",
+                        "--allreduce", "torch", "--flags-per-gpu", str(2 ** 24), "--steps", "3", "--warmup", "1", "--cpu-seconds", "0"],
+                       capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    took = time.time() - t0
+    assert r.returncode != 0 and took < 30 + 60, (r.returncode, took, r.stderr[-2000:])   # (+ the first import torch of a fresh box)
+    assert "rank 1 exited with code 3" in r.stderr and "multi-rank run FAILED" in r.stderr
+    assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
