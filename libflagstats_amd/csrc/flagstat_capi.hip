@@ -283,7 +283,7 @@ int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
     if (!out) return fail_text("NULL out");
     Engine* e = fsint::default_engine();
     if (!e) return -1;
-    return fsint::count_host(*e, array, n, out);
+    return fsint::count_host_shared(*e, array, n, out);
 }
 
 int FLAGSTATS_u16_x64_superset(const uint16_t* array, uint64_t n, uint64_t* out)
@@ -291,7 +291,7 @@ int FLAGSTATS_u16_x64_superset(const uint16_t* array, uint64_t n, uint64_t* out)
     if (!out) return fail_text("NULL out");
     Engine* e = fsint::default_engine();
     if (!e) return -1;
-    return fsint::count_host(*e, array, n, out, fsint::OP_FLAGSTAT | fsint::OP_SUPERSET);
+    return fsint::count_host_shared(*e, array, n, out, fsint::OP_FLAGSTAT | fsint::OP_SUPERSET);
 }
 
 static int flagstat_hip_u32(const uint16_t* array, uint32_t len, uint32_t* flags)
@@ -609,7 +609,7 @@ int FLAGSTATS_hip_pospopcnt_u16_x64(const uint16_t* array, uint64_t n, uint64_t*
     if (!out) return fail_text("NULL out");
     Engine* e = fsint::default_engine();
     if (!e) return -1;
-    return fsint::count_host(*e, array, n, out, fsint::OP_POSPOPCNT);
+    return fsint::count_host_shared(*e, array, n, out, fsint::OP_POSPOPCNT);
 }
 
 int STORM_pospopcnt_u16(const uint16_t* data, size_t len, uint32_t* out)

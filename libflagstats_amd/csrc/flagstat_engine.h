@@ -104,6 +104,9 @@ struct Engine {
     hipEvent_t order_ev[kOrderEvents] = {};
     unsigned order_next = 0;                       // guarded by user_mu
     bool order_ev_fence_free = false;              // flavour of the events currently in order_ev[] (guarded by user_mu)
+    static constexpr int kSideEngines = 3;         // default engines only: where concurrent caller threads go (count_host_shared)
+    std::atomic<Engine*> side[kSideEngines] = {};
+    std::mutex side_mu;                            // creation / release of the side engines
     std::mutex user_mu;                            // guards user_ws and the ordering events
     std::list<std::pair<void*, Workspace>> user_ws;  // caller-owned streams, most recently used first (bounded)
 };
@@ -161,6 +164,9 @@ int count_device_async(Engine& e, const uint16_t* d_array, uint64_t n, uint64_t*
 int count_on_user_stream(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream, int op);
 // host array -> counters through the engine's two-stream pipeline; takes e.mu
 int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op = OP_FLAGSTAT);
+// the same for the DEFAULT engine's reference-shaped entry points: concurrent caller threads do not queue behind each
+// other, they spread over the engine and up to Engine::kSideEngines side engines of its device
+int count_host_shared(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op = OP_FLAGSTAT);
 
 int stage_reserve(Engine& e, int slot, uint64_t flags);   // e.mu held
 int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3]);  // e.mu held

@@ -357,6 +357,14 @@ void retire_engine(Engine* e)
 {
     bool was = false;
     if (!e->dead.compare_exchange_strong(was, true)) return;
+    {
+        // its side engines (count_host_shared) go with it; a caller inside one finishes first (retire takes the engine's lock)
+        std::lock_guard<std::mutex> mk(e->side_mu);
+        for (auto& slot : e->side) {
+            Engine* side = slot.exchange(nullptr);
+            if (side) engine_destroy(side);
+        }
+    }
     std::lock_guard<std::mutex> lk(e->mu);
     DeviceGuard guard(e->device);
     release_engine_resources(*e);
@@ -397,12 +405,12 @@ void shutdown_all()
         privates.swap(g_private);
         g_default_device = -1;
     }
-    for (Engine* e : defaults) {
+    for (Engine* e : privates) retire_engine(e);  // their creators' handles (ctx, multi, a default engine's side engines) drop the reference
+    for (Engine* e : defaults) {                  // (after the private ones: a default engine lets go of its side engines here)
         if (!e) continue;
         retire_engine(e);
         engine_release(e);  // the registry's reference; sessions still holding one keep the (dead) object
     }
-    for (Engine* e : privates) retire_engine(e);  // their creators' handles (ctx, multi) drop the reference
 }
 
 int device_of_pointer(const void* p, const char* what, int* device, bool* plain_device_memory)
@@ -649,12 +657,50 @@ int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3])
 }
 
 // host array -> counters: double-buffered H2D + K1/K2 per chunk on the engine's two streams
+// The reference's entry points are reentrant and lock-free (libflagstats.h:2980-2997): caller threads that meet on the
+// DEFAULT engine must not queue behind each other.  A call takes the default engine if it is free; if another thread is
+// inside it, one of up to kSideEngines side engines of the same device (private streams, staging and result buffers, made
+// on first need, released with the default engine); only when all are busy does it wait for the default engine.
+static int count_host_locked(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op);
+
+int count_host_shared(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
+{
+    if (n == 0) return 0;
+    if (!h) return fail_text("NULL array with n > 0");
+    {
+        std::unique_lock<std::mutex> lk(e.mu, std::try_to_lock);
+        if (lk.owns_lock()) return count_host_locked(e, h, n, out, op);
+    }
+    for (int i = 0; i < Engine::kSideEngines; ++i) {
+        Engine* side = e.side[i].load(std::memory_order_acquire);
+        if (!side) {
+            std::lock_guard<std::mutex> mk(e.side_mu);
+            side = e.side[i].load(std::memory_order_relaxed);
+            if (!side) {
+                if (e.dead.load()) break;
+                side = engine_create(e.device);
+                if (!side) break;  // (out of memory for another set of buffers: wait for the default engine instead)
+                e.side[i].store(side, std::memory_order_release);
+            }
+        }
+        std::unique_lock<std::mutex> lk(side->mu, std::try_to_lock);
+        if (lk.owns_lock()) return count_host_locked(*side, h, n, out, op);
+    }
+    std::lock_guard<std::mutex> lk(e.mu);
+    return count_host_locked(e, h, n, out, op);
+}
+
 int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
 {
-    const int nout = ((op & OP_BASE_MASK) == OP_POSPOPCNT) ? 16 : 32;
     if (n == 0) return 0;
     if (!h) return fail_text("NULL array with n > 0");
     std::lock_guard<std::mutex> lk(e.mu);
+    return count_host_locked(e, h, n, out, op);
+}
+
+static int count_host_locked(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
+{
+    const int nout = ((op & OP_BASE_MASK) == OP_POSPOPCNT) ? 16 : 32;
     if (engine_alive(e)) return -1;
     DeviceGuard guard(e.device);
     if (!guard.ok()) return -1;

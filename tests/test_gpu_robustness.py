@@ -118,3 +118,58 @@ def test_handles_opened_before_a_shutdown_stay_safe(hip):
     assert np.array_equal(out, want)
     _lib.check(hip.FLAGSTATS_hip_init(0), "init")
     hip.FLAGSTATS_hip_set(b"on_error", 0)
+
+
+def test_default_engine_callers_overlap(hip):
+    """The reference API is reentrant (libflagstats.h:2980-2997): caller threads that meet on the default engine spread over
+    its side engines instead of queueing behind one lock.  Four threads, results exact.  Per-block sized calls (2^18 flags =
+    512 KiB, what a per-block caller of the reference makes) are latency-bound alone and must get through more than
+    1.5 x together; 64 MiB calls already move ~55 GB/s from ONE thread, all the PCIe link has, so there the four together
+    only must not be slower than one."""
+    import threading
+    import time
+
+    import oracle
+
+    def measure(n, reps):
+        arrays = [np.random.RandomState(100 + t).randint(0, 65536, n).astype(np.uint16) for t in range(4)]
+        wants = [oracle.flagstat_hist(a) for a in arrays]
+
+        def call(a):
+            out = np.zeros(32, dtype=np.uint64)
+            assert hip.FLAGSTATS_u16_x64(a.ctypes.data, a.size, out.ctypes.data) == 0
+            return out
+
+        for a, w in zip(arrays, wants):           # warm: engines, staging, pinned buffers
+            assert np.array_equal(call(a), w)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            call(arrays[0])
+        one = reps * n / (time.perf_counter() - t0)
+        results = [None] * 4
+        barrier = threading.Barrier(5)
+
+        def worker(t):
+            for _ in range(3):                    # untimed: every thread meets its side engine once
+                call(arrays[t])
+            barrier.wait()
+            for _ in range(reps):
+                results[t] = call(arrays[t])
+
+        threads = [threading.Thread(target=worker, args=(t,)) for t in range(4)]
+        for th in threads:
+            th.start()
+        barrier.wait()
+        t0 = time.perf_counter()
+        for th in threads:
+            th.join()
+        four = 4 * reps * n / (time.perf_counter() - t0)
+        for t in range(4):
+            assert np.array_equal(results[t], wants[t]), (n, t)
+        print("%d flags per call: one caller thread %.2f Gflags/s, four together %.2f Gflags/s (%.2fx)" % (n, one / 1e9, four / 1e9, four / one))
+        return one, four
+
+    one, four = measure(1 << 18, 300)
+    assert four > 1.5 * one, (one, four)
+    one, four = measure(32 * 1024 * 1024, 6)
+    assert four > 0.9 * one, (one, four)
