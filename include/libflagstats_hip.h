@@ -186,7 +186,7 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *   "lz4_decoder"    LZ4 block files (FLAGSTATS_hip_blockfile*, blockimage_lz4): 0 = decode on host threads into pinned
  *                    chunks (decoded flags cross PCIe), 1 = decode on the GPU (the compressed bytes cross PCIe, one
  *                    workgroup per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default
- *                    128 MiB compressed: the measured break-even of an LZ4-fast file, an LZ4-HC file wins from 40 MiB,
+ *                    64 MiB compressed: the measured break-even of an LZ4-fast file, an LZ4-HC file wins from 40 MiB,
  *                    profiles/r04/lz4_decoder_sweep.log), on the host below.  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
  *   "lz4_gpu_keep_bytes" device memory the GPU LZ4 decoder may keep between calls: its two buffers -- a segment's
  *                    compressed and decoded bytes -- are reused by the next file (allocating them right after freeing

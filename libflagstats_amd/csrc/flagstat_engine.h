@@ -48,7 +48,7 @@ struct Knobs {
     std::atomic<int> on_error{1};                 // legacy uint32 entry points: 1 = abort after the message, 0 = return non-zero
     std::atomic<int> lz4_decoder{2};              // LZ4 block files: 0 = decode on host threads, 1 = on the GPU, 2 = by size
     std::atomic<int> lz4_gpu_kernel{0};           // GPU LZ4 decode kernel: 0 = workgroup pipeline (r04), 1 = one wave per block (r03)
-    std::atomic<uint64_t> lz4_gpu_min_bytes{128ull << 20};  // lz4_decoder 2: GPU decode for files of at least this many bytes
+    std::atomic<uint64_t> lz4_gpu_min_bytes{64ull << 20};  // lz4_decoder 2: GPU decode for files of at least this many bytes
     std::atomic<uint64_t> lz4_gpu_keep_bytes{~0ull};  // device bytes the GPU LZ4 decoder may keep between calls; ~0 = automatic: what the
                                                   // last call needed, at most a quarter of the device, until 8 other calls have passed
     std::atomic<int> fence_free_events{0};        // stream_wait_stream: 1 = ordering events without the system-scope fence (opt-in)
@@ -90,9 +90,8 @@ struct Engine {
     void* pinned[3] = {nullptr, nullptr, nullptr}; // block-file chunk buffers, kept across calls
     uint8_t* lz4_buf[2] = {nullptr, nullptr};      // GPU LZ4 decoder: compressed / decoded bytes of a segment, kept across calls
     uint64_t lz4_cap[2] = {0, 0};                  // (knob "lz4_gpu_keep_bytes"; released after kLz4IdleCalls other calls)
-    static constexpr int kLz4Streams = 4, kLz4MaxPieces = 64, kLz4IdleCalls = 8;
+    static constexpr int kLz4Streams = 2, kLz4MaxPieces = 64, kLz4IdleCalls = 8;
     hipStream_t lz4_stream[kLz4Streams] = {};      // ... its decode streams, events and small device buffers, made on first use
-    Workspace lz4_ws[kLz4Streams];                 // K1 workspaces of the decode streams (a piece is counted behind its decode)
     hipEvent_t lz4_ev[4] = {};                     // start, copies queued, decoded + counted (timed); index on the device
     hipEvent_t lz4_landed[kLz4MaxPieces] = {}, lz4_joined[kLz4Streams] = {}, lz4_pin_free[3] = {};
     void* lz4_index = nullptr;                     // blocks + status + tally of a segment

@@ -6,14 +6,15 @@
 // (benchmark/flagstats.cpp:311-316); the host pipeline of this repo (flagstat_blocks.hip) does the same on N host threads
 // and is PCIe-bound on the DECODED bytes (27 Gflags/s).  Here the file crosses PCIe as it is (2.1-3.4x fewer bytes) and is
 // decoded on the device:
-//   * the file goes over in PIECES of whole blocks on the engine's copy stream (a piece = 1/16 of the file, 128..512
-//     blocks: the decode kernel holds 512 blocks at a time and a block takes 2.5-3.5 ms, so what is exposed behind the last
-//     copy is one small piece);
-//   * every piece's blocks are decoded by their own launch on one of FOUR decode streams as soon as the piece has landed,
-//     and COUNTED right behind it on the same stream (K1 adds to one counter array from any number of streams).  Four,
-//     because the runtime puts its streams on four hardware queues and launches that share a queue run one after the
-//     other, each for at least one block's 2.5-3.5 ms: sixteen pieces on sixteen streams measured 25 ms where eight on
-//     four take 13; and 128 blocks at least, so that a stream's next piece lands no sooner than its last one is decoded;
+//   * the file goes over in PIECES of whole blocks on the engine's copy stream (a piece = 1/16 of the file, 256..512
+//     blocks); every piece's blocks are decoded by their own launch as soon as the piece has landed, on one of TWO decode
+//     streams.  Two, and 256 blocks at least: the runtime multiplexes a process's streams onto four hardware queues, of
+//     which the decode streams get two (a rocprofv3 timeline of sixteen 128-block pieces on four streams shows launches on
+//     two queues only, two in flight at any time, half of the 512 blocks the chip holds: 31 ms for 2^30 flags, where
+//     256-block pieces take 2x ms, profiles/r04/lz4_timeline_*.txt); a launch lasts at least one block's 2.5-3.5 ms, so
+//     what is exposed behind the last copy is one piece's decode;
+//   * ONE K1 pass over the decoded buffer at the end (0.15 ms per GiB; counting each piece behind its decode changed
+//     nothing measurable at large sizes and costs K1 launches whose 168-VGPR waves wait for decode workgroups to leave);
 //   * file mode reads with a pool of parallel preads into the engine's three pinned chunk buffers, one span ahead of the
 //     copies;
 //   * streams, events and the small device buffers are made once per engine; the two large buffers (compressed, decoded)
@@ -53,10 +54,6 @@ void lz4_gpu_release(Engine& e, bool all)
     for (hipStream_t& x : e.lz4_stream) {
         if (x) (void)hipStreamDestroy(x);
         x = nullptr;
-    }
-    for (Workspace& w : e.lz4_ws) {
-        if (w.partials) (void)hipFree(w.partials);
-        w = Workspace{};
     }
     auto drop = [](hipEvent_t& x) {
         if (x) (void)hipEventDestroy(x);
@@ -182,18 +179,18 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     const int kernel = knobs().lz4_gpu_kernel.load() == 0 ? fsk::LZ4K_WORKGROUP : (big_ring ? fsk::LZ4K_WAVE_RING16 : fsk::LZ4K_WAVE);
     const char* pk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");  // tuning: per-phase wave cycles on stderr
     const bool prof = pk && std::atoi(pk) != 0;
-    // Pieces.  The workgroup kernel holds 512 blocks at a time and a block takes 2.5-3.5 ms whatever else runs, so the
-    // decode time left exposed behind the last copy is one piece's: 1/16 of the file each, but not under 128 blocks (PCIe
-    // delivers ~120-180 blocks a millisecond: with four streams a stream's next piece then lands when its last one is
-    // done, launches that queue up behind each other are lost time) nor over 512.  r03's kernel wants few large ones (a
-    // launch lasts 20-30 ms however small): one per 1024 blocks, at most 4.  env FLAGSTATS_HIP_GPU_LZ4_CHUNKS overrides.
+    // Pieces.  The workgroup kernel holds 512 blocks at a time, a block takes 2.5-3.5 ms whatever else runs, and TWO
+    // decode launches run at a time (two hardware queues): pieces of 1/16 of the file, but not under 256 blocks (two
+    // launches then fill the chip) nor over 512.  The decode time left exposed behind the last copy is one piece's.
+    // r03's kernel wants few large ones (a launch lasts 20-30 ms however small): one per 1024 blocks, at most 4.
+    // env FLAGSTATS_HIP_GPU_LZ4_CHUNKS overrides.
     const char* ck = std::getenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS");
     uint32_t npieces;
     if (ck) {
         npieces = static_cast<uint32_t>(std::atoi(ck));
     } else if (kernel == fsk::LZ4K_WORKGROUP) {
         uint64_t per = blocks.size() / 16;
-        per = per < 128 ? 128 : (per > 512 ? 512 : per);
+        per = per < 256 ? 256 : (per > 512 ? 512 : per);
         npieces = static_cast<uint32_t>((blocks.size() + per - 1) / per);
     } else {
         npieces = static_cast<uint32_t>((blocks.size() + 1023) / 1024);
@@ -237,7 +234,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         first = last;
     }
     const uint32_t pieces_done = static_cast<uint32_t>(pieces.size());
-    // piece c has been queued on the copy stream: decode its blocks behind it, and count them behind that
+    // piece c has been queued on the copy stream: decode its blocks behind it
     auto launch_piece = [&](uint32_t c) -> int {
         hipError_t e_ = hipEventRecord(e.lz4_landed[c], s);
         hipStream_t ds = e.lz4_stream[c % nstreams];
@@ -246,11 +243,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         const Piece& pc = pieces[c];
         e_ = fsk_lz4_decode(kernel, d_comp, d_blocks + pc.first, static_cast<uint32_t>(pc.last - pc.first), d_out, d_status + pc.first,
                             d_tally, prof ? 1 : 0, ds);
-        if (e_ != hipSuccess) return fail_hip("LZ4 decode kernel launch", e_);
-        const uint64_t d0 = blocks[pc.first].dst_off;
-        const uint64_t d1 = blocks[pc.last - 1].dst_off + ((static_cast<uint64_t>(blocks[pc.last - 1].dst_len) + 15) & ~15ull);
-        return count_device_async(e, reinterpret_cast<const uint16_t*>(d_out + d0), (d1 - d0) / 2, e.d_out[0], ds, e.lz4_ws[c % nstreams],
-                                  OP_FLAGSTAT | (in.superset ? OP_SUPERSET : 0));
+        return e_ == hipSuccess ? 0 : fail_hip("LZ4 decode kernel launch", e_);
     };
     if (img) {
         for (uint32_t c = 0; c < pieces.size() && !rc; ++c) {
@@ -345,6 +338,13 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     for (uint32_t i = 0; i < nstreams; ++i) {
         LZG_TRY(hipEventRecord(e.lz4_joined[i], e.lz4_stream[i]));
         LZG_TRY(hipStreamWaitEvent(s, e.lz4_joined[i], 0));
+    }
+    // One K1 pass over the whole decoded buffer (0.15 ms per GiB).
+    rc = count_device_async(e, reinterpret_cast<const uint16_t*>(d_out), dpos / 2, e.d_out[0], s, e.ws[0],
+                            OP_FLAGSTAT | (in.superset ? OP_SUPERSET : 0));
+    if (rc) {
+        settle();
+        return rc;
     }
     LZG_TRY(hipEventRecord(e.lz4_ev[2], s));  // ... is decoded and counted
     LZG_TRY(hipMemcpyAsync(e.h_out, e.d_out[0], 32 * sizeof(uint64_t), hipMemcpyDeviceToHost, s));
@@ -442,6 +442,9 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         dpos += (static_cast<uint64_t>(us) + 15) & ~15ull;
         pos += 8 + static_cast<uint64_t>(cs);
     }
+    const char* pk_ = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");
+    const bool prof_host = pk_ && std::atoi(pk_) != 0;
+    const auto t_index = std::chrono::steady_clock::now();
     FLAGSTATS_gpu_lz4_stats local;
     if (!stats) stats = &local;
     {
@@ -464,6 +467,7 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         const char* sb = std::getenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES");
         if (sb && *sb) seg_cap = std::strtoull(sb, nullptr, 0);
     }
+    const auto t_meminfo = std::chrono::steady_clock::now();
     std::vector<fsk::GpuBlock> seg;
     for (size_t b0 = 0; b0 < blocks.size();) {
         size_t b1 = b0;
@@ -494,6 +498,7 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         ++stats->segments;
         b0 = b1;
     }
+    const auto t_segments = std::chrono::steady_clock::now();
     // what stays with the engine for the next call: knob "lz4_gpu_keep_bytes" (~0 = automatic: at most a quarter of the device)
     e.lz4_idle = 0;
     {
@@ -505,6 +510,11 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         if (e.lz4_cap[0] + e.lz4_cap[1] > keep) lz4_gpu_release(e, false);
     }
     stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    if (prof_host) {
+        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+        std::fprintf(stderr, "lz4 gpu profile, host side: index %.2f ms, device memory query %.2f ms, segments %.2f ms (of which the GPU pipeline %.2f ms), keep rule %.2f ms\n",
+                     ms(t_start, t_index), ms(t_index, t_meminfo), ms(t_meminfo, t_segments), stats->pipeline_ms, ms(t_segments, std::chrono::steady_clock::now()));
+    }
     return 0;
 }
 

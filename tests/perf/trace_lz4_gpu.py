@@ -17,7 +17,8 @@ n = int(sys.argv[1]) if len(sys.argv) > 1 else 2 ** 31
 lib = _lib.lib()
 _lib.check(lib.FLAGSTATS_hip_init(0), "init")
 _lib.check(lib.FLAGSTATS_hip_set(b"lz4_decoder", 1), "set")
-img = build_image(n, "fast", 2)
+mode, level = (sys.argv[2] if len(sys.argv) > 2 else "fast:2").split(":")
+img = build_image(n, mode, int(level))
 buf = np.frombuffer(img, dtype=np.uint8)
 for rep in range(5):
     out = np.zeros(32, dtype=np.uint64)

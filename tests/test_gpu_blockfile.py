@@ -188,7 +188,7 @@ def test_gpu_side_lz4_decode_rejects_damaged_blocks(hip):
 @pytest.fixture
 def gpu_decoder(hip):
     """knob lz4_decoder = 1: every LZ4 block file goes through the GPU decoder whatever its size (default 2: from 1 GiB)"""
-    assert hip.FLAGSTATS_hip_get(b"lz4_decoder") == 2 and hip.FLAGSTATS_hip_get(b"lz4_gpu_min_bytes") == 128 << 20
+    assert hip.FLAGSTATS_hip_get(b"lz4_decoder") == 2 and hip.FLAGSTATS_hip_get(b"lz4_gpu_min_bytes") == 64 << 20
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
     yield hip
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 2) == 0
@@ -255,7 +255,7 @@ def test_gpu_decoder_is_chosen_by_size_and_fails_loudly(gpu_decoder, tmp_path):
     assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", len(img)) == 0
     got, st = blockfile.flagstat_lz4_image(img, 2)
     assert np.array_equal(got, want) and st["gpu_decode"] == 1
-    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 128 << 20) == 0
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 64 << 20) == 0
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 3) != 0
     # damaged input: truncated header / payload, a header that claims more than the block holds, a corrupted payload
