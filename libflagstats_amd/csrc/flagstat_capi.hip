@@ -526,6 +526,7 @@ int FLAGSTATS_hip_time_device_u16_rotating(const uint16_t* d_array, uint64_t n, 
     if (!ep) return -1;
     Engine& e = *ep;
     std::lock_guard<std::mutex> lk(e.mu);
+    if (fsint::engine_alive(e)) return -1;
     DeviceGuard guard(e.device);
     if (!guard.ok()) return -1;
     hipStream_t s = e.stream[0];

@@ -506,7 +506,28 @@ int ensure_ws(Workspace& w, uint32_t grid, hipStream_t s)
     // first launch.  Stream-ordered on the LAUNCHING stream: no device-wide wait, other streams keep running.
     // (r02 used hipMemset + two hipDeviceSynchronize here: the NULL-stream memset is not ordered against the
     // engines' non-blocking streams, and the waits stalled every other stream on a caller's first call.)
-    HIP_TRY(hipMemsetAsync(w.partials, 0, fsk_partials_bytes(grid), s));
+    // While `s` is being captured into a graph a memset on it would become a NODE of that graph: the block would be zero
+    // only once the graph has run, and a plain launch on the stream before its first replay (or after an abandoned
+    // capture) would meet the fresh allocation's bytes in the epilogue's tickets and copies.  Zero it now instead, on a
+    // stream of its own, and wait (a first call under capture, once per stream).
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &cap) != hipSuccess) {
+        (void)hipGetLastError();
+        cap = hipStreamCaptureStatusNone;
+    }
+    if (cap == hipStreamCaptureStatusActive) {
+        hipStreamCaptureMode relaxed = hipStreamCaptureModeRelaxed;
+        const bool sw = hipThreadExchangeStreamCaptureMode(&relaxed) == hipSuccess;
+        hipStream_t side = nullptr;
+        hipError_t e1 = hipStreamCreateWithFlags(&side, hipStreamNonBlocking);
+        if (e1 == hipSuccess) e1 = hipMemsetAsync(w.partials, 0, fsk_partials_bytes(grid), side);
+        if (e1 == hipSuccess) e1 = hipStreamSynchronize(side);
+        if (side) (void)hipStreamDestroy(side);
+        if (sw) (void)hipThreadExchangeStreamCaptureMode(&relaxed);
+        if (e1 != hipSuccess) return fail_hip("workspace zeroing beside a stream capture", e1);
+    } else {
+        HIP_TRY(hipMemsetAsync(w.partials, 0, fsk_partials_bytes(grid), s));
+    }
     w.grid_cap = grid;
     return 0;
 }

@@ -81,6 +81,8 @@ hipError_t hipStreamSynchronize(hipStream_t s);
 hipError_t hipStreamGetDevice(hipStream_t s, hipDevice_t* d);
 hipError_t hipStreamWaitEvent(hipStream_t s, hipEvent_t e, unsigned flags);
 hipError_t hipThreadExchangeStreamCaptureMode(hipStreamCaptureMode* mode);
+enum hipStreamCaptureStatus { hipStreamCaptureStatusNone = 0, hipStreamCaptureStatusActive = 1, hipStreamCaptureStatusInvalidated = 2 };
+static inline hipError_t hipStreamIsCapturing(hipStream_t, hipStreamCaptureStatus* st) { *st = hipStreamCaptureStatusNone; return hipSuccess; }
 
 hipError_t hipEventCreate(hipEvent_t* e);
 hipError_t hipEventCreateWithFlags(hipEvent_t* e, unsigned flags);

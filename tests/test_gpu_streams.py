@@ -92,7 +92,7 @@ def test_first_call_on_a_fresh_stream_does_not_wait_for_other_streams(hip):
 @pytest.mark.parametrize("store", [False, True])
 def test_first_use_under_stream_capture(hip, store):
     """K1 (and, in the store form, K2) captured into a HIP graph on a stream the library has never seen: the workspace
-    set-up is capture-legal (allocation in relaxed mode, zeroing as a memset node); replays give the right counters."""
+    set-up is capture-legal (allocation and zeroing in relaxed mode, beside the capture); replays give the right counters."""
     import torch
 
     import oracle
@@ -107,6 +107,13 @@ def test_first_use_under_stream_capture(hip, store):
     with torch.cuda.graph(g, stream=s, capture_error_mode="global"):
         device.count_torch(t, out, store=store)
     torch.cuda.synchronize()
+    # a PLAIN launch on that stream before the graph has ever run: the stream's workspace (made during the capture) must
+    # already be zero -- it is zeroed beside the capture, not by a node of the graph
+    plain = torch.zeros(32, dtype=torch.int64, device="cuda:0")
+    with torch.cuda.stream(s):
+        device.count_torch(t, plain)
+    torch.cuda.synchronize()
+    assert np.array_equal(plain.cpu().numpy().view(np.uint64), oracle.flagstat_generated(oracle.GEN_NA12878, 77, 1, 0, n))
     out.zero_()
     for _ in range(3):
         g.replay()
