@@ -740,7 +740,7 @@ static int count_host_locked(Engine& e, const uint16_t* h, uint64_t n, uint64_t*
         // number next to them; the host polls that word instead of synchronising the stream (a synchronous stream
         // round trip is ~20 us of the r02 path's 23).  Input: up to `small_flags` flags are copied by the CPU into a
         // pinned buffer that K1 reads in place over PCIe (no copy call, no DMA set-up: a copy call alone is 10-12 us);
-        // above that (measured: between 1 Mi and 2 Mi flags, profiles/r03/small_calls_threshold.log) the runtime's
+        // above that (measured: between 1 Mi and 2 Mi flags, profiles/r03/small_calls.log, small_calls_pinned_input.log) the runtime's
         // asynchronous H2D copy into device staging is faster than the CPU's memcpy.
         const bool in_place = n <= g_knobs.small_flags.load() && n * sizeof(uint16_t) <= kSmallInBytes;
         const bool through_bar = in_place && e.small_bar_in && n > kSmallPinnedFlags;

@@ -1168,10 +1168,10 @@ extern "C" hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t g
     case 71: e = launch_count_t<8, true, false, false, 9>(a, stream); break;
 #ifdef FLAGSTAT_TUNING_VARIANTS
     // bit 7: 25 + guided self-scheduling.  Balances the XCDs to within 2 us of each other and is NOT faster (HBM, not the
-    // split between XCDs, sets the time: profiles/r03/dyn_sweep*.log, timeline_153.log) -- evidence, tuning build only
+    // split between XCDs, sets the time: profiles/r03/dyn_sweep_*.log, timeline_153_dynamic.log) -- evidence, tuning build only
     case 153: e = launch_count_t<8, true, false, true, 4>(a, stream); break;
     // 25 with TWO waves per SIMD: 512-thread workgroups, every wave rolls over half a step (4 loads in flight), same
-    // 32 KiB in flight per CU -- the VERDICT r02 experiment on K1's VALU headroom (profiles/r03/two_waves_per_simd.log)
+    // 32 KiB in flight per CU -- the VERDICT r02 experiment on K1's VALU headroom (profiles/r03/two_waves_per_simd_and_lds_ring.log)
     case 29: e = launch_count_t<8, true, false, true, 5>(a, stream); break;
     // measurement only: 25's load schedule with (almost) no arithmetic (57), and 25 with each wave owning a contiguous
     // 8 KiB of the step instead of the 1 KiB interleave (17) -- where the last 1.5 % to the read probe is

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Soak of the GPU LZ4 decode pipeline (copy stream + four decode streams + events, file and image mode): the same image
+"""Soak of the GPU LZ4 decode pipeline (copy stream + two decode streams + events, file and image mode): the same image
 through the product entry again and again, alternating with the host-thread decoder, counters checked every time."""
 import argparse
 import ctypes
@@ -48,8 +48,12 @@ def main():
             assert st.gpu_decode == dec
             assert np.array_equal(out, want), "round %d (%s, %s): counters differ from the oracle" % (r, "GPU" if dec else "host", "file" if r % 2 else "image")
     _lib.check(lib.FLAGSTATS_hip_set(b"lz4_decoder", 2), "set")
-    print("soak: %d rounds on %d flags (%s), image and file mode alternating, all exact | GPU decode %.1f-%.1f ms, host threads %.1f-%.1f ms"
-          % (args.rounds, args.flags, args.mode, min(walls[1]) * 1e3, max(walls[1]) * 1e3, min(walls[0]) * 1e3, max(walls[0]) * 1e3))
+    g = walls[1]
+    print("soak: %d rounds on %d flags (%s), image and file mode alternating, all exact" % (args.rounds, args.flags, args.mode))
+    print("  GPU decode, every round in order (ms; even = image, odd = file): " + " ".join("%.1f" % (w * 1e3) for w in g))
+    print("  GPU decode: FIRST call %.1f ms (it allocates the two large device buffers, the pinned spans, streams and events: r03's "
+          "'61.4-157.9 ms' was this call against the others), afterwards %.1f-%.1f ms; host threads %.1f-%.1f ms"
+          % (g[0] * 1e3, min(g[1:]) * 1e3, max(g[1:]) * 1e3, min(walls[0]) * 1e3, max(walls[0]) * 1e3))
 
 
 if __name__ == "__main__":
