@@ -31,8 +31,18 @@ def expect(flags, block_bytes):
 @pytest.mark.parametrize("case", ["na_ragged", "exact_multiple", "uniform_incompressible", "hc9", "tiny_odd_blocks",
                                   "three_chunks"])
 def test_lz4_block_files(hip, tmp_path, case):
+    """the HOST-thread pipeline (knob lz4_decoder = 0; by the default size rule files from 64 MiB go to the GPU decoder,
+    whose tests follow further down)"""
     import oracle
     from libflagstats_amd import blockfile
+    assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 0) == 0
+    try:
+        _lz4_block_files(hip, tmp_path, case, oracle, blockfile)
+    finally:
+        assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 2) == 0
+
+
+def _lz4_block_files(hip, tmp_path, case, oracle, blockfile):
     kw = dict(block_bytes=bt.BLOCK_BYTES, mode="fast", level=2)
     if case == "na_ragged":
         flags = oracle.generate(oracle.GEN_NA12878, 1, 1, 0, 512000 * 3 + 12345)
@@ -128,10 +138,20 @@ def gpu_decode(hip, img):
     return rc, out, st
 
 
+@pytest.fixture(params=[0, 1], ids=["workgroup_kernel", "r03_wave_kernel"])
+def lz4_kernel(hip, request):
+    """both decode kernels the library carries: the workgroup pipeline (default) and r03's one wave per block (the yardstick)"""
+    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kernel") == 0
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_kernel", request.param) == 0
+    yield request.param
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_kernel", 0) == 0
+
+
 @pytest.mark.parametrize("case", ["na_ragged", "exact_multiple", "uniform_incompressible", "hc9", "tiny_odd_blocks", "many_blocks"])
-def test_gpu_side_lz4_decode_matches_oracle(hip, case):
-    """flagstat_lz4_gpu.hip (one wave per block, LDS ring): same counters as the host pipeline's contract on liblz4-written
-    block images -- long literal runs (incompressible), far matches (HC), odd block sizes, the writer's empty block."""
+def test_gpu_side_lz4_decode_matches_oracle(hip, lz4_kernel, case):
+    """flagstat_lz4_kernels.hip (a workgroup of eight waves per block, the 64 KiB window in LDS; and r03's wave per block):
+    same counters as the host pipeline's contract on liblz4-written block images -- long literal runs (incompressible),
+    far matches (HC), odd block sizes, the writer's empty block."""
     import oracle
     kw = dict(block_bytes=bt.BLOCK_BYTES, mode="fast", level=2)
     if case == "na_ragged":
@@ -154,6 +174,7 @@ def test_gpu_side_lz4_decode_matches_oracle(hip, case):
     assert rc == 0, hip.FLAGSTATS_hip_last_error()
     assert np.array_equal(got, want), case
     assert st.n_flags == n and st.bad_blocks == 0 and st.compressed_bytes == len(img)
+    assert st.ring_kib == (66 if lz4_kernel == 0 else 8) and (st.far_matches == 0 or lz4_kernel == 1)
 
 
 def test_gpu_side_lz4_decode_on_reference_written_files(hip):
@@ -438,3 +459,50 @@ def test_gpu_decoder_keeps_its_device_buffers_between_calls(gpu_decoder):
     got, _ = blockfile.flagstat_lz4_image(bt.block_file_image(small, block_bytes=9999), 2)
     assert np.array_equal(got, expect(small, 9999)[0]) and hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
     assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", auto) == 0
+
+
+def _stress_flags(kind, n, seed):
+    """uint16 streams that make liblz4 emit what an NA12878-like stream hardly ever does: matches of hundreds and thousands
+    of bytes (length bytes, 255-runs of them), offsets 1..3 (a match that overlaps its own output), literal runs of 15 and
+    more, long incompressible stretches between compressible ones."""
+    rs = np.random.RandomState(seed)
+    if kind == "zeros":
+        a = np.zeros(n, dtype=np.uint16)
+    elif kind == "period":
+        p = rs.randint(0, 4096, size=int(rs.choice([1, 2, 3, 5, 7, 64]))).astype(np.uint16)
+        a = np.resize(p, n)
+        a[rs.randint(0, n, size=max(1, n // 5000))] ^= 1          # a literal every few thousand flags
+    elif kind == "runs":
+        parts, left = [], n
+        while left > 0:
+            m = int(min(left, rs.choice([1, 3, 17, 40, 300, 5000, 70000])))
+            parts.append(np.full(m, rs.randint(0, 4096), dtype=np.uint16) if rs.rand() < 0.7
+                         else rs.randint(0, 65536, size=m).astype(np.uint16))
+            left -= m
+        a = np.concatenate(parts)
+    elif kind == "repeats":
+        base = rs.randint(0, 4096, size=3000).astype(np.uint16)
+        parts, left = [], n
+        while left > 0:
+            o, m = int(rs.randint(0, 2900)), int(min(left, rs.randint(2, 100)))
+            parts.append(base[o:o + m])
+            left -= len(parts[-1])
+        a = np.concatenate(parts)[:n]
+    else:
+        raise ValueError(kind)
+    return np.ascontiguousarray(a[:n])
+
+
+@pytest.mark.parametrize("kind", ["zeros", "period", "runs", "repeats"])
+@pytest.mark.parametrize("mode,level", [("fast", 1), ("fast", 9), ("hc", 4), ("hc", 12)])
+def test_gpu_decoder_on_streams_with_long_matches_and_literal_runs(gpu_decoder, lz4_kernel, kind, mode, level):
+    """liblz4-written blocks of highly compressible and mixed data (see _stress_flags), block sizes from 4 KiB to the
+    format's 1,024,000 bytes: the GPU decoder must give the host oracle's counters (the reference-written golden
+    `ragged_fast_a2.lz4`, ratio 39, once found a deadlock that NA12878-like streams never reached)."""
+    from libflagstats_amd import blockfile
+    for i, (n, block_bytes) in enumerate([(700_001, bt.BLOCK_BYTES), (300_000, 65536), (120_003, 4096), (1_600_000, bt.BLOCK_BYTES)]):
+        flags = _stress_flags(kind, n, 1000 * level + i)
+        img = bt.block_file_image(flags, block_bytes=block_bytes, mode=mode, level=level)
+        want = expect(flags, block_bytes)[0]
+        got, st = blockfile.flagstat_lz4_image(img, 2)
+        assert st["gpu_decode"] == 1 and np.array_equal(got, want), (kind, mode, level, n, block_bytes)
