@@ -4,31 +4,38 @@
 //
 // Two kernels:
 //
-// lz4_decode_wg (r04, default) -- ONE WORKGROUP OF THREE WAVES PER BLOCK, the whole 64 KiB LZ4 window in LDS.
+// lz4_decode_wg (r04, default) -- ONE WORKGROUP OF EIGHT WAVES PER BLOCK, the whole 64 KiB LZ4 window in LDS.
 //   An LZ4 block is a serial chain twice over: the position of token k + 1 depends on token k, and a match may read what
 //   the match before it wrote.  r03's kernel walked both chains with one wave, one to four sequences per LDS round trip
-//   (216 cycles per sequence, 16-30 ms per block).  Here the two chains are taken apart and each is walked in units the
-//   hardware is wide enough for:
-//     wave 0, PARSE: 64 lanes decode the token at 64 CONSECUTIVE input bytes at once (every byte position speculatively:
-//       literal length, match length, where the next token would be); which of them are real tokens is a walk over that
-//       "next" table in scalar registers -- runs of bare 3-byte sequences by one ctz over a ballot, anything else one
-//       v_readlane per sequence.  The real sequences get their output positions from a DPP prefix sum and leave, per
-//       sequence, ONE 16-bit marker (the offset) at the match's first output byte; literal bytes go straight into the
-//       output ring with a bit set in a literal bitmap.  No copies, no dependence on decoded data.
-//     wave 1, SCAN: per 256-byte chunk of OUTPUT (4 bytes a lane) a DPP "last marker" scan turns the markers into one
+//   (216 cycles per sequence, 19-32 ms per block).  Here the two chains are taken apart, each is walked in units the
+//   hardware is wide enough for, and the stages run as a pipeline of waves:
+//     wave 0, WALK: which input bytes are tokens.  One lane per 32-byte segment of a 2 KiB tile: backward over its
+//       segment every lane computes where a chain entering at position e = 0..11 leaves it (a sliding window of 5-bit
+//       "exits" in three registers: no memory, no dependence on where the chain is); the real chain through the tile is
+//       then 64 scalar table look-ups, straight-line; forward again every lane marks the positions reachable from its
+//       segment's entry -- the tokens -- and adds up their output bytes; a prefix sum over the lanes gives every 64-byte
+//       window its output position.  One record per window goes to the emitters.
+//     waves 1-3, EMIT: lane = byte position of a window; a DPP prefix sum places every sequence; ONE 32-bit marker (the
+//       offset) goes to the match's first output byte, a literal run gets a "literal" marker and its bytes go straight
+//       into the output ring.  No copies, no dependence on decoded data.
+//     waves 4-6, SCAN: per 256-byte chunk of OUTPUT (4 bytes a lane) a DPP "last marker" scan turns the markers into one
 //       source pointer per byte; pointers that land inside the chunk itself are chased to their roots by pointer
 //       doubling on packed byte indices (ds_bpermute, data-independent: a byte -> byte pointer composes without the
 //       bytes), so that every byte ends up with the ring index of a byte that is FINAL before the chunk starts.
-//     wave 2, COPY: per chunk one 16-byte read of four final sources, four byte gathers from the ring, one aligned
-//       4-byte write: 256 output bytes per LDS round trip, whatever the sequences were; every 4 KiB the ring goes to
+//     wave 7, COPY: per chunk one 16-byte read of four final sources, four byte gathers from the ring, one aligned
+//       4-byte write: 256 output bytes per LDS round trip, whatever the sequences were; every KiB the ring goes to
 //       global memory with 16-byte stores.
-//   The ring holds 64 KiB + 4 KiB: LZ4 offsets reach at most 65,535 bytes back, so NO match ever reads global memory
+//   The ring holds 64 KiB + 2 KiB: LZ4 offsets reach at most 65,535 bytes back, so NO match ever reads global memory
 //   (r03: 9 % / 25 % of the sequences of an LZ4-fast / HC-9 flag stream went behind its 8 KiB ring, a global round trip
-//   each) and the 4 KiB are what the parser may write ahead of the copier.  The waves hand over through four words in
-//   LDS (positions reached, first error) polled with s_sleep; every LDS operation of a wave executes in order, so "data,
-//   then position" needs no fence.  80 KB of LDS per block: two blocks per CU, 512 in flight -- a block takes ~1-2 ms
-//   instead of 16-30, so 512 at a time decode faster than 4,352 did.  Every index is masked, clamped or checked; a
-//   malformed block sets its status word and the three waves leave through the same barrier; every wait is bounded.
+//   each) and the 2 KiB are what the emitters may write ahead of the copier.  The waves hand over through a few words in
+//   LDS (positions reached, a 16-entry record queue) polled with s_sleep back-off; every LDS operation of a wave executes
+//   in order, so "data, then position" needs no fence.  80 KB of LDS per block: two blocks per CU, 512 in flight -- a
+//   block takes 2-3.5 ms instead of 19-32.  What shaped the code: a taken branch costs a wave ~50 cycles and a scalar
+//   instruction ~12 (sixteen waves share a CU's scalar unit) where a straight-line VALU instruction costs 5.5, so the hot
+//   paths are straight-line (selects, idle lanes storing to a scratch word) and lane-parallel wherever a serial scalar
+//   walk could be turned into one.  Every index is masked, clamped or checked; a malformed block sets its status word and
+//   the eight waves leave through the same barrier; every wait is bounded.
+//   tests/test_lz4_walker_model.py restates the walker's algorithm in Python against liblz4's token chains.
 //
 // lz4_decode_wave (r03) -- one wave per block, 8 KiB ring; kept as the yardstick (knob "lz4_gpu_kernel" = 1).
 #include <hip/hip_runtime.h>
