@@ -149,6 +149,9 @@ int index_blocks(const uint8_t* img, int fd, uint64_t bytes, uint64_t chunk_cap,
     return 0;
 }
 
+}  // namespace
+
+namespace fsint {
 // CPUs of a host NUMA node ("/sys/devices/system/node/nodeN/cpulist", e.g. "0-63,128-191")
 bool node_cpuset(int node, cpu_set_t* set)
 {
@@ -189,6 +192,11 @@ bool node_cpuset(int node, cpu_set_t* set)
     }
     return true;
 }
+
+}  // namespace fsint
+
+namespace {
+using fsint::node_cpuset;
 
 // CPUs this process may use per the cgroup v2 CPU controller ("<quota> <period>" or "max <period>"); 0 = no limit known
 double cgroup_cpu_quota()

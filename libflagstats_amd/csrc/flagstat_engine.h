@@ -14,6 +14,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <sched.h>
+
 #include <atomic>
 #include <list>
 #include <mutex>
@@ -171,6 +173,8 @@ int stage_reserve(Engine& e, int slot, uint64_t flags);   // e.mu held
 int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3]);  // e.mu held
 void* host_alloc_on_node(size_t bytes, int numa_node);   // pinned, pages placed on `numa_node` when >= 0
 uint64_t chunk_bytes();
+// CPUs of host NUMA node `node` inside the calling process's own affinity mask (flagstat_blocks.hip); false: unknown / none
+bool node_cpuset(int node, cpu_set_t* set);
 
 // LZ4 block file decoded on the GPU (flagstat_lz4_gpu.hip).  img != nullptr: whole file image in memory; else fd: file mode.
 struct Lz4GpuSource {

@@ -34,6 +34,8 @@
 #include <mutex>
 #include <chrono>
 #include <thread>
+#include <pthread.h>
+#include <sched.h>
 #include <unistd.h>
 
 #include "../../include/libflagstats_hip.h"
@@ -269,7 +271,11 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         size_t released = 0;                       // spans [0, released) may be read
         std::vector<int> done(spans.size(), 0);    // reader threads finished per span
         bool stop = false, failed = false;
+        // (the pinned spans live on the GPU's host NUMA node: the readers run there too, like the host pipeline's decoders)
+        cpu_set_t node_cpus;
+        const bool pin_threads = knobs().numa.load() && node_cpuset(e.numa_node, &node_cpus);
         auto reader = [&](int t) {
+            if (pin_threads) (void)pthread_setaffinity_np(pthread_self(), sizeof node_cpus, &node_cpus);
             for (size_t i = 0; i < spans.size(); ++i) {
                 {
                     std::unique_lock<std::mutex> ul(m);

@@ -41,10 +41,12 @@ def main():
     ap.add_argument("--file-flags", default="2**31")
     ap.add_argument("--reps", type=int, default=3)
     ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--numa", type=int, default=1, help="knob numa: bind decoder / reader threads to the GPU's host NUMA node")
     args = ap.parse_args()
     import oracle
     lib = _lib.lib()
     _lib.check(lib.FLAGSTATS_hip_init(0), "init")
+    _lib.check(lib.FLAGSTATS_hip_set(b"numa", args.numa), "set")
     for mode_level in args.modes.split(","):
         mode, level = mode_level.split(":")
         for size in args.sizes.split(","):
