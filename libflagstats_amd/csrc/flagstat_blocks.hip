@@ -570,14 +570,17 @@ int pick_decoder(int codec, block_decode_fn* fn)
     return 0;
 }
 
-// LZ4 block files: knob "lz4_decoder" -- 0 host threads, 1 GPU, 2 (default) GPU from "lz4_gpu_min_bytes" compressed bytes up
-bool lz4_on_gpu(uint64_t bytes)
+// Block files: knob "lz4_decoder" / "zstd_decoder" -- 0 host threads, 1 GPU, 2 (default) GPU from "lz4_gpu_min_bytes" /
+// "zstd_gpu_min_bytes" compressed bytes up
+bool decode_on_gpu(int codec, uint64_t bytes)
 {
-    const int mode = fsint::knobs().lz4_decoder.load();
-    return mode == 1 || (mode == 2 && bytes >= fsint::knobs().lz4_gpu_min_bytes.load());
+    const int mode = codec == 0 ? fsint::knobs().lz4_decoder.load() : fsint::knobs().zstd_decoder.load();
+    const uint64_t from = codec == 0 ? fsint::knobs().lz4_gpu_min_bytes.load() : fsint::knobs().zstd_gpu_min_bytes.load();
+    return mode == 1 || (mode == 2 && bytes >= from);
 }
 
-int run_gpu_lz4(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, int threads, bool superset, uint64_t* out,
+// > 0: the GPU decoder did not take the file and nothing was counted -- the caller decodes it on host threads
+int run_gpu_lz4(fsint::Engine& eng, int codec, const uint8_t* img, int fd, uint64_t bytes, int threads, bool superset, uint64_t* out,
                 FLAGSTATS_blockfile_stats* st)
 {
     std::lock_guard<std::mutex> lk(eng.mu);
@@ -590,11 +593,14 @@ int run_gpu_lz4(fsint::Engine& eng, const uint8_t* img, int fd, uint64_t bytes, 
     src.bytes = bytes;
     src.superset = superset;
     src.threads = threads;
+    src.codec = codec;
     FLAGSTATS_gpu_lz4_stats g;
     const int rc = fsint::lz4_gpu_run(eng, src, out, &g);
-    if (rc == fsint::kLz4GpuNoMemory && fsint::knobs().lz4_decoder.load() == 1)
-        return fsint::fail_text("GPU LZ4 decoder: the device cannot hold the file's compressed and decoded bytes");
-    if (rc) return rc;  // (kLz4GpuNoMemory with the decoder chosen by size: the caller takes the host-thread pipeline)
+    const bool forced = (codec == 0 ? fsint::knobs().lz4_decoder.load() : fsint::knobs().zstd_decoder.load()) == 1;
+    if (rc == fsint::kLz4GpuNoMemory && forced)
+        return fsint::fail_text("GPU block decoder: the device cannot hold the file's compressed and decoded bytes");
+    if (rc == fsint::kGpuDecodeRejected && forced) return -1;  // (the message names the frame and the code)
+    if (rc) return rc;  // (> 0 with the decoder chosen by size: the caller takes the host-thread pipeline)
     if (st) {
         *st = FLAGSTATS_blockfile_stats{};
         st->n_flags = g.n_flags;
@@ -617,14 +623,16 @@ int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FL
     if (!out) return fsint::fail_text("NULL out");
     if (!image && bytes) return fsint::fail_text("NULL image");
     block_decode_fn fn = nullptr;
-    if (int rc = pick_decoder(codec, &fn)) return rc;
+    const int prc = pick_decoder(codec, &fn);  // (libzstd missing: only fatal if the host has to decode)
+    if (prc && !decode_on_gpu(codec, bytes)) return prc;
     static const uint8_t empty = 0;
     fsint::Engine* eng = fsint::default_engine();
     if (!eng) return -1;
-    if (codec == 0 && lz4_on_gpu(bytes)) {
-        const int rc = run_gpu_lz4(*eng, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, superset, out, stats);
-        if (rc != fsint::kLz4GpuNoMemory) return rc;
+    if (decode_on_gpu(codec, bytes)) {
+        const int rc = run_gpu_lz4(*eng, codec, image ? static_cast<const uint8_t*>(image) : &empty, -1, bytes, threads, superset, out, stats);
+        if (rc != fsint::kLz4GpuNoMemory && rc != fsint::kGpuDecodeRejected) return rc;
     }
+    if (prc) return prc;
     Source in;
     in.img = image ? static_cast<const uint8_t*>(image) : &empty;
     in.bytes = bytes;
@@ -638,7 +646,7 @@ int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_
     if (!out) return fsint::fail_text("NULL out");
     if (!path) return fsint::fail_text("NULL path");
     block_decode_fn fn = nullptr;
-    if (int rc = pick_decoder(codec, &fn)) return rc;
+    const int prc = pick_decoder(codec, &fn);  // (libzstd missing: only fatal if the host has to decode)
     const int fd = open(path, O_RDONLY);
     if (fd < 0) return fsint::fail_text("cannot open file");
     struct stat sb;
@@ -653,13 +661,21 @@ int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_
     // on the page cache of the r02 boxes -- populating and tearing down 490 k PTEs costs what the copy
     // costs (19-22 vs 24-26 Gflags/s, profiles/r02/blockfile_lz4_4GiB.log) -- so it is opt-in.
     const uint64_t bytes = static_cast<uint64_t>(sb.st_size);
-    if (codec == 0 && lz4_on_gpu(bytes)) {
+    if (prc && !decode_on_gpu(codec, bytes)) {
+        close(fd);
+        return prc;
+    }
+    if (decode_on_gpu(codec, bytes)) {
         fsint::Engine* eng = fsint::default_engine();
-        const int rc = eng ? run_gpu_lz4(*eng, nullptr, fd, bytes, threads, superset, out, stats) : -1;
-        if (rc != fsint::kLz4GpuNoMemory) {
+        const int rc = eng ? run_gpu_lz4(*eng, codec, nullptr, fd, bytes, threads, superset, out, stats) : -1;
+        if (rc != fsint::kLz4GpuNoMemory && rc != fsint::kGpuDecodeRejected) {
             close(fd);
             return rc;
         }
+    }
+    if (prc) {
+        close(fd);
+        return prc;
     }
     const char* io = std::getenv("FLAGSTATS_HIP_BLOCK_IO");
     void* map = MAP_FAILED;

@@ -201,6 +201,11 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
     } else if (!std::strcmp(key, "lz4_decoder")) {
         if (value > 2) return fail_text("lz4_decoder must be 0 (host threads), 1 (GPU) or 2 (by file size)");
         k.lz4_decoder = static_cast<int>(value);
+    } else if (!std::strcmp(key, "zstd_decoder")) {
+        if (value > 2) return fail_text("zstd_decoder must be 0 (libzstd on host threads), 1 (GPU) or 2 (by file size)");
+        k.zstd_decoder = static_cast<int>(value);
+    } else if (!std::strcmp(key, "zstd_gpu_min_bytes")) {
+        k.zstd_gpu_min_bytes = value;
     } else if (!std::strcmp(key, "lz4_gpu_kernel")) {
         if (value > 1) return fail_text("lz4_gpu_kernel must be 0 (workgroup pipeline) or 1 (one wave per block)");
         k.lz4_gpu_kernel = static_cast<int>(value);
@@ -247,6 +252,8 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "on_error")) return static_cast<uint64_t>(k.on_error.load());
     if (!std::strcmp(key, "numa")) return static_cast<uint64_t>(k.numa.load());
     if (!std::strcmp(key, "lz4_decoder")) return static_cast<uint64_t>(k.lz4_decoder.load());
+    if (!std::strcmp(key, "zstd_decoder")) return static_cast<uint64_t>(k.zstd_decoder.load());
+    if (!std::strcmp(key, "zstd_gpu_min_bytes")) return k.zstd_gpu_min_bytes.load();
     if (!std::strcmp(key, "lz4_gpu_kernel")) return static_cast<uint64_t>(k.lz4_gpu_kernel.load());
     if (!std::strcmp(key, "lz4_gpu_min_bytes")) return k.lz4_gpu_min_bytes.load();
     if (!std::strcmp(key, "lz4_gpu_keep_bytes")) return k.lz4_gpu_keep_bytes.load();

@@ -53,6 +53,8 @@ struct Knobs {
     std::atomic<uint64_t> lz4_gpu_min_bytes{64ull << 20};  // lz4_decoder 2: GPU decode for files of at least this many bytes
     std::atomic<uint64_t> lz4_gpu_keep_bytes{~0ull};  // device bytes the GPU LZ4 decoder may keep between calls; ~0 = automatic: what the
                                                   // last call needed, at most a quarter of the device, until 8 other calls have passed
+    std::atomic<int> zstd_decoder{2};             // Zstandard block files: 0 = libzstd on host threads, 1 = decode on the GPU, 2 = by size
+    std::atomic<uint64_t> zstd_gpu_min_bytes{4ull << 20};  // zstd_decoder 2: GPU decode for files of at least this many bytes
     std::atomic<int> fence_free_events{0};        // stream_wait_stream: 1 = ordering events without the system-scope fence (opt-in)
     std::atomic<int> numa{1};                     // block pipeline: 1 = pinned chunks + decoders on the GPU's NUMA node
 };
@@ -96,6 +98,8 @@ struct Engine {
     hipStream_t lz4_stream[kLz4Streams] = {};      // ... its decode streams, events and small device buffers, made on first use
     hipEvent_t lz4_ev[4] = {};                     // start, copies queued, decoded + counted (timed); index on the device
     hipEvent_t lz4_landed[kLz4MaxPieces] = {}, lz4_joined[kLz4Streams] = {}, lz4_pin_free[3] = {};
+    uint8_t* zstd_scratch[kLz4Streams] = {};       // GPU Zstandard decoder: records / literals / checkpoints of a piece, per decode stream
+    uint64_t zstd_scratch_cap[kLz4Streams] = {};   // (kept and released with the two large buffers)
     void* lz4_index = nullptr;                     // blocks + status + tally of a segment
     uint64_t lz4_index_cap = 0;
     bool lz4_ready = false;
@@ -183,10 +187,14 @@ struct Lz4GpuSource {
     uint64_t bytes = 0;
     bool superset = false;
     int threads = 0;        // file mode: parallel preads (<= 0: up to 16)
+    int codec = 0;          // payloads: 0 = LZ4 blocks, 1 = Zstandard frames
 };
 int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, struct ::FLAGSTATS_gpu_lz4_stats* stats);  // e.mu held, device current
 // > 0 from lz4_gpu_run: the device could not hold the decoder's buffers (nothing was counted; the caller may take the host pipeline)
 constexpr int kLz4GpuNoMemory = 77;
+// > 0 from lz4_gpu_run, Zstandard only: the GPU decoder did not take a frame (damaged, or valid Zstandard outside what it
+// handles); nothing was counted, the message is set; the caller may decode the file with libzstd on the host
+constexpr int kGpuDecodeRejected = 78;
 void lz4_gpu_release(Engine& e, bool all);         // e.mu held: the two large buffers (all: streams, events, index too)
 void lz4_gpu_other_use(Engine& e);                 // e.mu held: another entry point ran (the idle rule of the kept buffers)
 

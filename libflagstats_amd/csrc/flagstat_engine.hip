@@ -96,6 +96,9 @@ void read_env_knobs()
         g_knobs.lz4_decoder = static_cast<int>(env_u64("FLAGSTATS_HIP_LZ4_DECODER", static_cast<uint64_t>(g_knobs.lz4_decoder)));
         g_knobs.lz4_gpu_kernel = static_cast<int>(env_u64("FLAGSTATS_HIP_LZ4_GPU_KERNEL", static_cast<uint64_t>(g_knobs.lz4_gpu_kernel)));
         g_knobs.lz4_gpu_min_bytes = env_u64("FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES", g_knobs.lz4_gpu_min_bytes);
+        g_knobs.zstd_decoder = static_cast<int>(env_u64("FLAGSTATS_HIP_ZSTD_DECODER", static_cast<uint64_t>(g_knobs.zstd_decoder)));
+        if (g_knobs.zstd_decoder > 2) g_knobs.zstd_decoder = 2;
+        g_knobs.zstd_gpu_min_bytes = env_u64("FLAGSTATS_HIP_ZSTD_GPU_MIN_BYTES", g_knobs.zstd_gpu_min_bytes);
         g_knobs.lz4_gpu_keep_bytes = env_u64("FLAGSTATS_HIP_LZ4_GPU_KEEP_BYTES", g_knobs.lz4_gpu_keep_bytes);
         const char* oe = std::getenv("FLAGSTATS_HIP_ON_ERROR");
         if (oe && *oe) g_knobs.on_error = (!std::strcmp(oe, "return") || !std::strcmp(oe, "0")) ? 0 : 1;

@@ -41,6 +41,7 @@
 #include "../../include/libflagstats_hip.h"
 #include "flagstat_engine.h"
 #include "flagstat_lz4_kernels.h"
+#include "flagstat_zstd_kernels.h"
 
 namespace fsint {
 
@@ -50,6 +51,12 @@ void lz4_gpu_release(Engine& e, bool all)
         uint8_t* p = e.lz4_buf[i];
         e.lz4_buf[i] = nullptr;
         e.lz4_cap[i] = 0;
+        if (p) (void)hipFree(p);
+    }
+    for (int i = 0; i < Engine::kLz4Streams; ++i) {
+        uint8_t* p = e.zstd_scratch[i];
+        e.zstd_scratch[i] = nullptr;
+        e.zstd_scratch_cap[i] = 0;
         if (p) (void)hipFree(p);
     }
     if (!all) return;
@@ -73,7 +80,7 @@ void lz4_gpu_release(Engine& e, bool all)
 
 void lz4_gpu_other_use(Engine& e)
 {
-    if (!e.lz4_buf[0] && !e.lz4_buf[1]) return;
+    if (!e.lz4_buf[0] && !e.lz4_buf[1] && !e.zstd_scratch[0]) return;
     if (++e.lz4_idle >= static_cast<uint32_t>(Engine::kLz4IdleCalls)) lz4_gpu_release(e, false);
 }
 
@@ -178,7 +185,8 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     const char* rk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_RING");
     const bool big_ring = rk && std::atoi(rk) == 16;
     // knob "lz4_gpu_kernel": 0 = the workgroup pipeline (eight waves per block, 64 KiB window in LDS), 1 = r03's wave per block
-    const int kernel = knobs().lz4_gpu_kernel.load() == 0 ? fsk::LZ4K_WORKGROUP : (big_ring ? fsk::LZ4K_WAVE_RING16 : fsk::LZ4K_WAVE);
+    const bool zstd = in.codec == 1;
+    const int kernel = zstd || knobs().lz4_gpu_kernel.load() == 0 ? fsk::LZ4K_WORKGROUP : (big_ring ? fsk::LZ4K_WAVE_RING16 : fsk::LZ4K_WAVE);
     const char* pk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");  // tuning: per-phase wave cycles on stderr
     const bool prof = pk && std::atoi(pk) != 0;
     // Pieces.  The workgroup kernel holds 512 blocks at a time, a block takes 2.5-3.5 ms whatever else runs, and TWO
@@ -190,6 +198,10 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     uint32_t npieces;
     if (ck) {
         npieces = static_cast<uint32_t>(std::atoi(ck));
+    } else if (zstd) {
+        // Zstandard: 256 frames a piece (two launches fill the chip; the records, literals and checkpoints between the two
+        // kernels take 4 MB of scratch per frame and decode stream)
+        npieces = static_cast<uint32_t>((blocks.size() + 255) / 256);
     } else if (kernel == fsk::LZ4K_WORKGROUP) {
         uint64_t per = blocks.size() / 16;
         per = per < 256 ? 256 : (per > 512 ? 512 : per);
@@ -236,6 +248,36 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         first = last;
     }
     const uint32_t pieces_done = static_cast<uint32_t>(pieces.size());
+    // Zstandard: scratch between the entropy and the execution kernel, one per decode stream, sized for the largest piece
+    uint32_t z_max_dst = 0;
+    if (zstd) {
+        uint64_t most = 0;
+        for (const Piece& pc : pieces) most = pc.last - pc.first > most ? pc.last - pc.first : most;
+        for (const fsk::GpuBlock& b : blocks) z_max_dst = b.dst_len > z_max_dst ? b.dst_len : z_max_dst;
+        if (z_max_dst > fsk::kZstdMaxFrameBytes) {
+            settle();
+            if (knobs().zstd_decoder.load() == 1) fail_text("GPU Zstandard decoder: a block decodes to more than it takes (64 MiB)");
+            return kGpuDecodeRejected;
+        }
+        const uint64_t need = fsk_zstd_scratch_bytes(z_max_dst, static_cast<uint32_t>(most));
+        const uint32_t used = pieces.size() < nstreams ? static_cast<uint32_t>(pieces.size()) : nstreams;
+        for (uint32_t i = 0; i < used; ++i)
+            if (e.zstd_scratch_cap[i] < need) {
+                uint8_t* old = e.zstd_scratch[i];
+                e.zstd_scratch[i] = nullptr;
+                e.zstd_scratch_cap[i] = 0;
+                if (old) LZG_TRY(hipFree(old));
+                const uint64_t cap = (need + (16ull << 20) - 1) & ~((16ull << 20) - 1);
+                const hipError_t e_ = hipMalloc(&e.zstd_scratch[i], cap);
+                if (e_ != hipSuccess) {
+                    (void)hipGetLastError();
+                    e.zstd_scratch[i] = nullptr;
+                    settle();
+                    return kLz4GpuNoMemory;
+                }
+                e.zstd_scratch_cap[i] = cap;
+            }
+    }
     // piece c has been queued on the copy stream: decode its blocks behind it
     auto launch_piece = [&](uint32_t c) -> int {
         hipError_t e_ = hipEventRecord(e.lz4_landed[c], s);
@@ -243,9 +285,13 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         if (e_ == hipSuccess) e_ = hipStreamWaitEvent(ds, e.lz4_landed[c], 0);
         if (e_ != hipSuccess) return fail_hip("hipEventRecord / hipStreamWaitEvent(piece landed)", e_);
         const Piece& pc = pieces[c];
-        e_ = fsk_lz4_decode(kernel, d_comp, d_blocks + pc.first, static_cast<uint32_t>(pc.last - pc.first), d_out, d_status + pc.first,
-                            d_tally, prof ? 1 : 0, ds);
-        return e_ == hipSuccess ? 0 : fail_hip("LZ4 decode kernel launch", e_);
+        if (zstd)
+            e_ = fsk_zstd_decode(d_comp, d_blocks + pc.first, static_cast<uint32_t>(pc.last - pc.first), d_out, d_status + pc.first, d_tally,
+                                 e.zstd_scratch[c % nstreams], e.zstd_scratch_cap[c % nstreams], z_max_dst, prof ? 1 : 0, ds);
+        else
+            e_ = fsk_lz4_decode(kernel, d_comp, d_blocks + pc.first, static_cast<uint32_t>(pc.last - pc.first), d_out, d_status + pc.first,
+                                d_tally, prof ? 1 : 0, ds);
+        return e_ == hipSuccess ? 0 : fail_hip(zstd ? "Zstandard decode kernel launch" : "LZ4 decode kernel launch", e_);
     };
     if (img) {
         for (uint32_t c = 0; c < pieces.size() && !rc; ++c) {
@@ -373,7 +419,17 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     LZG_TRY(hipEventElapsedTime(&h2d, e.lz4_ev[0], e.lz4_ev[1]));
     LZG_TRY(hipEventElapsedTime(&dec, e.lz4_ev[1], e.lz4_ev[2]));
     LZG_TRY(hipEventElapsedTime(&pipe, e.lz4_ev[0], e.lz4_ev[2]));
-    if (prof) {
+    if (prof && zstd) {
+        const double nb = static_cast<double>(blocks.size());
+        const int ne = 3, ns = 3;
+        std::fprintf(stderr, "zstd gpu profile: %d frame(s) per CU fit (execution kernel); cycles per frame: entropy wave %.3g (literals %.3g, tables %.3g, sequences %.3g) | "
+                             "emit %.3g x %d (waiting %.1f %%), scan %.3g x %d (waiting %.1f %%), copy %.3g (waiting %.1f %%) | per frame: %.0f records, %.0f far matches, "
+                             "%.0f batches in %.0f groups, %.0f chunks, %.1f %% with pointers inside (%.2f doubling rounds each)\n",
+                     fsk_zstd_frames_per_cu(), tally[17] / nb, tally[18] / nb, tally[19] / nb, tally[20] / nb, tally[15] / nb / ne, ne,
+                     100.0 * tally[16] / (tally[15] + 1e-9), tally[8] / nb / ns, ns, 100.0 * tally[9] / (tally[8] + 1e-9), tally[12] / nb,
+                     100.0 * tally[13] / (tally[12] + 1e-9), tally[0] / nb, tally[1] / nb, tally[5] / nb, tally[6] / nb, tally[14] / nb,
+                     100.0 * tally[11] / (tally[14] + 1e-9), tally[11] ? static_cast<double>(tally[10]) / tally[11] : 0.0);
+    } else if (prof) {
         std::fprintf(stderr, "lz4 gpu profile: kernel %d, %d block(s) per CU fit\n", kernel, fsk_lz4_blocks_per_cu(kernel));
         if (kernel == fsk::LZ4K_WORKGROUP) {
             const double nb = static_cast<double>(blocks.size());
@@ -403,7 +459,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     stats->count_ms += 0;  // (a piece is counted behind its decode: part of decode_ms)
     stats->sequences += tally[0];
     stats->far_matches += tally[1];
-    stats->ring_kib = kernel == fsk::LZ4K_WORKGROUP ? 66 : (kernel == fsk::LZ4K_WAVE ? 8 : 16);
+    stats->ring_kib = zstd ? 68 : (kernel == fsk::LZ4K_WORKGROUP ? 66 : (kernel == fsk::LZ4K_WAVE ? 8 : 16));
     stats->chunks += pieces_done;
     stats->pipeline_ms += pipe;
     stats->readers = static_cast<uint64_t>(readers);
@@ -412,10 +468,13 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         for (int k = 0; k < 32; ++k) out[k] += e.h_out[k];
     }
     if (bad) {
+        // (Zstandard with the decoder chosen by size: the caller decodes the file with libzstd, whose verdict counts)
+        if (zstd && knobs().zstd_decoder.load() != 1) return kGpuDecodeRejected;
         char buf[192];
-        std::snprintf(buf, sizeof buf, "block file: %llu block(s) failed to decode to their declared size (GPU LZ4 decoder; first: block %llu, code %u)",
-                      static_cast<unsigned long long>(bad), static_cast<unsigned long long>(first_bad), first_code);
-        return fail_text(buf);
+        std::snprintf(buf, sizeof buf, "block file: %llu block(s) failed to decode to their declared size (GPU %s decoder; first: block %llu, code %u)",
+                      static_cast<unsigned long long>(bad), zstd ? "Zstandard" : "LZ4", static_cast<unsigned long long>(first_bad), first_code);
+        const int rc_ = fail_text(buf);
+        return zstd ? kGpuDecodeRejected : rc_;
     }
     return 0;
 #undef LZG_TRY
@@ -498,7 +557,8 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
             // nothing of a failed run stays on the device; a file the device cannot hold may still go through the host pipeline
             // (only if nothing has been added to out[] yet)
             lz4_gpu_release(e, false);
-            if (rc == kLz4GpuNoMemory && b0 != 0) return fail_text("GPU LZ4 decoder: out of device memory in a later segment");
+            if (rc == kLz4GpuNoMemory && b0 != 0) return fail_text("GPU block decoder: out of device memory in a later segment");
+            if (rc == kGpuDecodeRejected && b0 != 0) return -1;  // (earlier segments are in out[] already: the message stands)
             return rc;
         }
         ++stats->segments;
@@ -513,7 +573,9 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
             size_t free_b = 0, total_b = 0;
             keep = hipMemGetInfo(&free_b, &total_b) == hipSuccess ? total_b / 4 : 0;
         }
-        if (e.lz4_cap[0] + e.lz4_cap[1] > keep) lz4_gpu_release(e, false);
+        uint64_t held = e.lz4_cap[0] + e.lz4_cap[1];
+        for (uint64_t c : e.zstd_scratch_cap) held += c;
+        if (held > keep) lz4_gpu_release(e, false);
     }
     stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
     if (prof_host) {

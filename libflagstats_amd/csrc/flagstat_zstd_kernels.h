@@ -1,0 +1,60 @@
+// flagstat_zstd_kernels.h -- device side of the GPU Zstandard frame decoder (flagstat_zstd_kernels.hip), as the host
+// orchestration (flagstat_lz4_gpu.hip) sees it: plain C++, no device code, so the orchestration also builds against the
+// test-only HIP stand-in (tests/hoststub) and runs under ThreadSanitizer.
+#ifndef FLAGSTAT_ZSTD_KERNELS_H_
+#define FLAGSTAT_ZSTD_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+
+#include <stdint.h>
+
+#include "flagstat_lz4_kernels.h"  // fsk::GpuBlock: one payload = one frame here
+
+namespace fsk {
+
+constexpr uint32_t kZstdMaxBlocks = 256;        // Zstandard blocks per frame the GPU decoder takes (more: status kZstdTooManyBlocks)
+constexpr uint32_t kZstdMaxFrameBytes = 1u << 26;  // decoded bytes per frame it takes
+constexpr int kZstdTallyWords = 32;             // unsigned long long words of the tally the kernels add to
+
+// Status codes of a frame.  1..63: the frame is damaged; from 64: valid Zstandard this decoder does not take (skippable or
+// concatenated frames, dictionaries, content checksums, more than kZstdMaxBlocks blocks, frames above kZstdMaxFrameBytes) --
+// the host decodes such a file with libzstd.
+enum {
+    kZstdOk = 0,
+    kZstdBadHeader = 1,        // frame header damaged / content size differs from the declared block size
+    kZstdBadBlock = 2,         // block header: reserved type, size past the payload
+    kZstdBadLiterals = 3,      // literals section: sizes past the block, stream table, Huffman stream not consumed exactly
+    kZstdBadHuffman = 4,       // Huffman tree description
+    kZstdBadSequences = 5,     // sequences section header / FSE table description
+    kZstdBadBitstream = 6,     // sequence bit stream not consumed exactly
+    kZstdBadOffset = 7,        // a match reaches before the frame, a repeat offset of zero
+    kZstdBadSize = 8,          // decoded size differs from the declared one, a block decodes to more than 128 KiB
+    kZstdNoTable = 9,          // repeat mode / treeless literals without an earlier table
+    kZstdStuck = 10,           // a wait inside the workgroup ran out (a logic error, not the data)
+    kZstdUnsupported = 64,     // not a plain Zstandard frame (skippable frame, bad magic)
+    kZstdDictionary = 65,
+    kZstdChecksum = 66,
+    kZstdTooManyBlocks = 67,
+    kZstdTrailingData = 68,    // bytes behind the frame (a second frame)
+    kZstdTooLarge = 69,
+};
+
+}  // namespace fsk
+
+extern "C" {
+// Bytes of device scratch a launch over `nframes` frames of at most `max_dst_len` decoded bytes each needs (sequence
+// records, literals and batch checkpoints between the two kernels).
+uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes);
+// Decode `nblocks` Zstandard frames on `stream`: frame i reads comp[blocks[i].src_off ..+src_len) and writes
+// out[blocks[i].dst_off ..+dst_len); status[i] = 0 or one of the codes above (the frame's output then holds garbage).
+// Two kernels: entropy decode (Huffman literals, FSE sequences -> records in `scratch`), then sequence execution.
+// tally[0] += sequence records, tally[1] += matches read back from global memory; prof != 0: cycle counters in tally[2..].
+// `comp` must be readable for 64 bytes past the last payload; `scratch` holds fsk_zstd_scratch_bytes(max_dst_len, nblocks).
+hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
+                           unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int prof,
+                           hipStream_t stream);
+// workgroups of the execution kernel one CU holds at once (occupancy query; 0 on failure)
+int fsk_zstd_frames_per_cu(void);
+}
+
+#endif  // FLAGSTAT_ZSTD_KERNELS_H_

@@ -1,0 +1,1309 @@
+// flagstat_zstd_kernels.hip -- Zstandard frame decode ON the GPU (row f1: the reference decodes every .zst block payload
+// with libzstd's ZSTD_decompress on the host, benchmark/flagstats.cpp:636-682).  Device code only; the host orchestration
+// is flagstat_lz4_gpu.hip (shared with the LZ4 decoder).  Written from RFC 8878; tests/zstd_model.py restates the format
+// and tests/zstd_gpu_model.py the two stages below, both pinned against libzstd on the CPU.
+//
+// A frame of the reference's writer is 1,024,000 decoded bytes in eight blocks of 128 KiB; a block is a Huffman-coded
+// literals section and an FSE-coded sequences section (literal length, match length, offset), one serial bit stream
+// each, read BACKWARDS.  Two kernels per piece of a file:
+//
+// zstd_entropy -- ONE WAVE PER FRAME, a lane per block (eight blocks side by side, more in further passes):
+//   every lane parses its block's section headers; tables a block repeats from an earlier one are rebuilt by the lane
+//   that needs them from the earlier block's description (no sharing, no ordering between lanes); Huffman streams are
+//   decoded by 32 lanes (four streams a block), four symbols per window; the sequence bit stream of every block is staged
+//   into a 1 KiB ring in LDS by the whole wave (256 bytes a refill) so that one step of the serial chain
+//   "three states -> three table entries -> bits -> three states" is ONE LDS round trip: three 4-byte entries (symbol,
+//   state bits, extra bits, base packed) and a 16-byte window, read together.  What leaves the kernel is flat:
+//   8-byte RECORDS (offset | literal length | match length, runs above 16,383 split), the literal bytes, and one
+//   CHECKPOINT per 64 records (output position, literal position, records valid).  Repeat offsets need the history the
+//   previous block ends with: a lane starts with an unknown history, writes the few repeat codes it cannot resolve as they
+//   are, and one lane replays those prefixes block after block at the end.
+//
+// zstd_execute -- ONE WORKGROUP OF SEVEN WAVES PER FRAME, the pipeline of the LZ4 kernel (flagstat_wgpipe.h) behind a
+//   new front end: three EMIT waves take batches of 64 records (a DPP prefix sum places them; markers and literal bytes
+//   go into the 64 KiB + 4 KiB output ring; a match from farther back than the ring -- 6-30 % of the sequences of a flag
+//   stream -- is read from the output already flushed to global memory and becomes literal bytes), three SCAN waves turn
+//   markers into one final source per byte, one COPY wave gathers, writes and flushes.
+//
+// Every index is masked, clamped or checked; a damaged frame sets its status word and cannot fault; every wait is bounded.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "flagstat_wgpipe.h"
+#include "flagstat_zstd_kernels.h"
+
+namespace fsk {
+
+// ------------------------------------------------------------------------------------------------ scratch layout
+struct ZLayout {
+    uint64_t hdr_at, ck_at, rec_at, lit_at, total;
+    uint32_t rec_stride, ck_stride, lit_stride, nframes;
+};
+static inline ZLayout zstd_layout(uint32_t max_dst_len, uint32_t nframes)
+{
+    ZLayout y;
+    y.nframes = nframes;
+    y.rec_stride = ((max_dst_len / 3u + 64u) & ~63u) + 96u * kZstdMaxBlocks;
+    y.ck_stride = y.rec_stride / 64u;
+    y.lit_stride = (max_dst_len + 64u + 15u) & ~15u;
+    auto up = [](uint64_t v) { return (v + 255u) & ~255ull; };
+    y.hdr_at = 0;
+    y.ck_at = up(static_cast<uint64_t>(nframes) * 16u);
+    y.rec_at = y.ck_at + up(static_cast<uint64_t>(nframes) * y.ck_stride * 16u);
+    y.lit_at = y.rec_at + up(static_cast<uint64_t>(nframes) * y.rec_stride * 8u);
+    y.total = y.lit_at + up(static_cast<uint64_t>(nframes) * y.lit_stride) + 256u;
+    return y;
+}
+struct ZFrameHdr {
+    uint32_t nslots, nrec, out_len, nblk;
+};
+
+constexpr uint32_t kRecLL = 16383u, kRecML = 16383u;   // longest runs of one record
+constexpr uint32_t kRecRep = 1u << 31;                  // word 0: a repeat code not resolved yet (low byte: the code; 0x10: "what the record before resolved to")
+constexpr uint32_t kRecFlag = 1u << 30;                 // word 0: with kRecRep, the sequence had no literals; without, the record does not enter the offset history
+constexpr uint32_t kBlockMax = 1u << 17;
+
+// ------------------------------------------------------------------------------------------------ zstd_entropy
+constexpr uint32_t kZeLanes = 8;          // blocks of a frame decoded side by side
+constexpr uint32_t kZeRing = 1024, kZeChunk = 256;
+
+__device__ const uint32_t kLLBase[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
+__device__ const uint8_t kLLBits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ const uint32_t kMLBase[53] = {3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34,
+                                         35, 37, 39, 41, 43, 47, 51, 59, 67, 83, 99, 131, 259, 515, 1027, 2051, 4099, 8195, 16387, 32771, 65539};
+__device__ const uint8_t kMLBits[53] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                        1, 1, 1, 1, 2, 2, 3, 3, 4, 4, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
+__device__ const int8_t kLLDefault[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 1, 1, 1, 2, 2, 2, 2, 2, 2, 2, 2, 2, 3, 2, 1, 1, 1, 1, 1, -1, -1, -1, -1};
+__device__ const int8_t kMLDefault[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
+__device__ const int8_t kOFDefault[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
+
+struct ZeTables {  // one lane's tables: Huffman while the literals are decoded, FSE afterwards
+    union {
+        uint16_t huf[2048];  // symbol | bits << 8, indexed by the next max-bits bits of the stream
+        struct {
+            uint32_t ll[512], of[256], ml[512];  // symbol | state bits << 6 | extra bits << 10 | base << 16
+        } fse;
+    };
+};
+struct ZeShare {  // what a lane tells the others about its block
+    uint32_t def_huf;        // position of the Huffman tree description it brings, or ~0
+    uint32_t def_tab[3];     // per table: ~0 leaves it as it is, ~1 repeats, else mode << 28 | position
+    uint32_t type, size, at; // block type, size field, payload position
+    uint32_t lit_type, nlit, lit_at, lit_data, lit_end, streams, max_bits, stream_at;
+    uint32_t rec_at, rec_cap, nrec, out_len, n_sym, hist_known, hist[3];
+};
+struct __attribute__((aligned(16))) ZeLds {
+    ZeTables tab[kZeLanes];
+    uint8_t ring[kZeLanes][kZeRing + 16];
+    uint8_t weights[kZeLanes][256];
+    int16_t counts[kZeLanes][64];
+    uint32_t rank[kZeLanes][16];
+    uint32_t ll_base[36], ml_base[53];  // (in LDS: a global load in the sequence loop would wait for the record stores before it)
+    ZeShare sh[kZeLanes];
+};
+constexpr uint32_t kNone = ~0u, kRepeat = ~1u;
+
+__device__ __forceinline__ uint32_t ld_u8(const uint8_t* p) { return *p; }
+__device__ __forceinline__ uint32_t ld_le16(const uint8_t* p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8); }
+__device__ __forceinline__ uint32_t ld_le24(const uint8_t* p) { return ld_le16(p) | (static_cast<uint32_t>(p[2]) << 16); }
+__device__ __forceinline__ uint32_t ld_le32(const uint8_t* p)
+{
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+__device__ __forceinline__ uint64_t ld_le64(const uint8_t* p)
+{
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+__device__ __forceinline__ uint32_t highbit(uint32_t v) { return 31u - static_cast<uint32_t>(__builtin_clz(v)); }
+// the top n bits (n <= 63) of a top-aligned window, which moves on
+__device__ __forceinline__ uint32_t take(uint64_t& w, uint32_t n)
+{
+    const uint64_t v = (w >> 1) >> (63u - n);
+    w <<= n;
+    return static_cast<uint32_t>(v);
+}
+
+// Forward little-endian bit reader over the frame (FSE table descriptions): position in bits, every read checked
+// against `limit` (bytes) by the caller afterwards.
+struct FwdBits {
+    const uint8_t* base;
+    uint32_t bit;
+    __device__ __forceinline__ uint32_t peek(uint32_t n) const
+    {
+        const uint64_t v = ld_le64(base + (bit >> 3));
+        return static_cast<uint32_t>(v >> (bit & 7u)) & ((1u << n) - 1u);
+    }
+};
+
+// FSE table description at byte `at` of the frame -> accuracy log, counts[0..max_symbol] (LDS, -1: "less than one"),
+// position behind it.  Returns false on a damaged description.  (RFC 8878 4.1.1)
+__device__ bool fse_read_counts(const uint8_t* frame, uint32_t at, uint32_t limit, uint32_t max_symbol, uint32_t max_log, int16_t* counts,
+                                uint32_t& log_out, uint32_t& after)
+{
+    if (at >= limit) return false;
+    FwdBits br{frame, at * 8u};
+    const uint32_t log = br.peek(4) + 5u;
+    br.bit += 4u;
+    if (log > max_log) return false;
+    int32_t remaining = (1 << log) + 1;
+    int32_t threshold = 1 << log;
+    uint32_t nbits = log + 1u;
+    uint32_t sym = 0;
+    _Pragma("unroll 1") for (uint32_t s = 0; s <= max_symbol; ++s) counts[s] = 0;
+    while (remaining > 1 && sym <= max_symbol) {
+        if ((br.bit >> 3) >= limit) return false;
+        const int32_t mx = (2 * threshold - 1) - remaining;
+        const int32_t low = static_cast<int32_t>(br.peek(nbits - 1u));
+        int32_t v;
+        if (low < mx) {
+            v = low;
+            br.bit += nbits - 1u;
+        } else {
+            v = static_cast<int32_t>(br.peek(nbits));
+            if (v >= threshold) v -= mx;
+            br.bit += nbits;
+        }
+        v -= 1;
+        remaining -= v < 0 ? -v : v;
+        if (remaining < 1) return false;
+        counts[sym++] = static_cast<int16_t>(v);
+        if (v == 0) {
+            _Pragma("unroll 1") for (;;) {
+                if ((br.bit >> 3) >= limit) return false;
+                const uint32_t rep = br.peek(2);
+                br.bit += 2u;
+                sym += rep;
+                if (rep != 3u) break;
+            }
+        }
+        while (remaining < threshold) {
+            nbits -= 1u;
+            threshold >>= 1;
+        }
+    }
+    if (remaining != 1 || sym > max_symbol + 1u) return false;
+    after = (br.bit + 7u) >> 3;
+    if (after > limit) return false;
+    log_out = log;
+    return true;
+}
+
+// counts -> decode table of packed entries (RFC 8878 4.1.1; xbits(symbol) = extra bits the code reads).  One lane, serial.
+template <class XB>
+__device__ bool fse_build(uint32_t* table, int16_t* counts, uint32_t nsym, uint32_t log, XB xbits)
+{
+    const uint32_t size = 1u << log, mask = size - 1u;
+    uint32_t high = size - 1u;
+    _Pragma("unroll 1") for (uint32_t s = 0; s < nsym; ++s)
+        if (counts[s] == -1) table[high--] = s;
+    const uint32_t step = (size >> 1) + (size >> 3) + 3u;
+    uint32_t pos = 0;
+    _Pragma("unroll 1") for (uint32_t s = 0; s < nsym; ++s) {
+        const int32_t c = counts[s];
+        _Pragma("unroll 1") for (int32_t i = 0; i < c; ++i) {
+            table[pos] = s;
+            pos = (pos + step) & mask;
+            while (pos > high) pos = (pos + step) & mask;
+        }
+    }
+    _Pragma("unroll 1") for (uint32_t s = 0; s < nsym; ++s)
+        if (counts[s] == -1) counts[s] = 1;  // (from here on: the next state number of the symbol)
+    if (pos != 0u) return false;
+    _Pragma("unroll 1") for (uint32_t u = 0; u < size; ++u) {
+        const uint32_t s = table[u];
+        const uint32_t x = static_cast<uint32_t>(counts[s]);
+        counts[s] = static_cast<int16_t>(x + 1u);
+        const uint32_t nb = log - highbit(x);
+        table[u] = s | (nb << 6) | (xbits(s) << 10) | (((x << nb) - size) << 16);
+    }
+    return true;
+}
+
+// One of the three sequence tables of a block from its source (mode << 28 | position).  Returns the accuracy log, or ~0.
+template <class XB>
+__device__ uint32_t seq_table(const uint8_t* frame, uint32_t limit, uint32_t src, uint32_t* table, int16_t* counts, const int8_t* dflt, uint32_t dflt_n,
+                              uint32_t dflt_log, uint32_t max_symbol, uint32_t max_log, XB xbits)
+{
+    const uint32_t mode = src >> 28, at = src & 0xFFFFFFFu;
+    if (mode == 0u) {
+        _Pragma("unroll 1") for (uint32_t s = 0; s < dflt_n; ++s) counts[s] = dflt[s];
+        return fse_build(table, counts, dflt_n, dflt_log, xbits) ? dflt_log : ~0u;
+    }
+    if (mode == 1u) {
+        if (at >= limit) return ~0u;
+        const uint32_t sym = frame[at];
+        if (sym > max_symbol) return ~0u;
+        table[0] = sym | (xbits(sym) << 10);
+        return 0u;
+    }
+    uint32_t log, after;
+    if (!fse_read_counts(frame, at, limit, max_symbol, max_log, counts, log, after)) return ~0u;
+    return fse_build(table, counts, max_symbol + 1u, log, xbits) ? log : ~0u;
+}
+
+// Huffman tree description at `at` (RFC 8878 4.2.1) -> table in LDS; returns max bits (0 on failure), position behind it.
+__device__ uint32_t huf_build(const uint8_t* frame, uint32_t at, uint32_t limit, ZeTables& T, uint8_t* weights, int16_t* counts, uint32_t* rank,
+                              uint32_t& after)
+{
+    if (at >= limit) return 0u;
+    const uint32_t hb = frame[at];
+    uint32_t n = 0;
+    if (hb >= 128u) {
+        n = hb - 127u;
+        const uint32_t nbytes = (n + 1u) >> 1;
+        if (at + 1u + nbytes > limit) return 0u;
+        _Pragma("unroll 1") for (uint32_t i = 0; i < n; ++i) {
+            const uint32_t b = frame[at + 1u + (i >> 1)];
+            weights[i] = static_cast<uint8_t>((i & 1u) ? (b & 15u) : (b >> 4));
+        }
+        after = at + 1u + nbytes;
+    } else {
+        // FSE-compressed weights: two interleaved states over a backward stream
+        if (hb < 2u || at + 1u + hb > limit) return 0u;
+        const uint32_t end = at + 1u + hb;
+        uint32_t log, tafter;
+        if (!fse_read_counts(frame, at + 1u, end, 12u, 6u, counts, log, tafter)) return 0u;
+        uint32_t* table = T.fse.ll;  // (the Huffman table is built after the weights are out)
+        if (!fse_build(table, counts, 13u, log, [](uint32_t) { return 0u; })) return 0u;
+        if (tafter >= end || frame[end - 1u] == 0u) return 0u;
+        int32_t left = static_cast<int32_t>((end - tafter) * 8u) - static_cast<int32_t>(8u - highbit(frame[end - 1u]));  // bits below the end mark
+        // (short stream: read bit by bit group through a 64-bit window reloaded per read)
+        auto read = [&](uint32_t nb) -> uint32_t {
+            left -= static_cast<int32_t>(nb);
+            if (nb == 0u) return 0u;
+            if (left >= 0) {
+                const uint32_t bit = tafter * 8u + static_cast<uint32_t>(left);
+                const uint64_t v = ld_le64(frame + (bit >> 3));
+                return static_cast<uint32_t>(v >> (bit & 7u)) & ((1u << nb) - 1u);
+            }
+            const int32_t have = left + static_cast<int32_t>(nb);
+            if (have <= 0) return 0u;
+            const uint64_t v = ld_le64(frame + tafter);
+            return (static_cast<uint32_t>(v) & ((1u << have) - 1u)) << (nb - static_cast<uint32_t>(have));
+        };
+        uint32_t s1 = read(log), s2 = read(log);
+        _Pragma("unroll 1") for (;;) {
+            if (n >= 254u) return 0u;
+            uint32_t e = table[s1];
+            weights[n++] = static_cast<uint8_t>(e & 63u);
+            s1 = (e >> 16) + read((e >> 6) & 15u);
+            if (left < 0) {
+                weights[n++] = static_cast<uint8_t>(table[s2] & 63u);
+                break;
+            }
+            e = table[s2];
+            weights[n++] = static_cast<uint8_t>(e & 63u);
+            s2 = (e >> 16) + read((e >> 6) & 15u);
+            if (left < 0) {
+                weights[n++] = static_cast<uint8_t>(table[s1] & 63u);
+                break;
+            }
+        }
+        after = end;
+    }
+    if (n > 255u) return 0u;
+    // the last weight completes the sum of 2^(w - 1) to a power of two
+    uint32_t total = 0;
+    _Pragma("unroll 1") for (uint32_t w = 0; w < 16u; ++w) rank[w] = 0u;
+    _Pragma("unroll 1") for (uint32_t i = 0; i < n; ++i) {
+        const uint32_t w = weights[i];
+        if (w > 11u) return 0u;
+        if (w) total += 1u << (w - 1u);
+        rank[w] += 1u;
+    }
+    if (total == 0u) return 0u;
+    const uint32_t max_bits = highbit(total) + 1u;
+    if (max_bits > 11u) return 0u;
+    const uint32_t rest = (1u << max_bits) - total;
+    if (rest & (rest - 1u)) return 0u;
+    const uint32_t lastw = highbit(rest) + 1u;
+    weights[n++] = static_cast<uint8_t>(lastw);
+    rank[lastw] += 1u;
+    // codes of weight w take 2^(w - 1) slots each, lowest weights first, symbols in order within a weight
+    uint32_t next = 0;
+    _Pragma("unroll 1") for (uint32_t w = 1; w <= max_bits; ++w) {
+        const uint32_t cur = next;
+        next += rank[w] << (w - 1u);
+        rank[w] = cur;
+    }
+    _Pragma("unroll 1") for (uint32_t s = 0; s < n; ++s) {
+        const uint32_t w = weights[s];
+        if (!w) continue;
+        const uint32_t len = 1u << (w - 1u);
+        const uint16_t e = static_cast<uint16_t>(s | ((max_bits + 1u - w) << 8));
+        const uint32_t first = rank[w];
+        _Pragma("unroll 1") for (uint32_t u = 0; u < len; ++u) T.huf[(first + u) & 2047u] = e;
+        rank[w] = first + len;
+    }
+    return max_bits;
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks, uint8_t* __restrict__ scratch,
+                                                   const ZLayout lay, uint32_t* __restrict__ status, unsigned long long* __restrict__ tally)
+{
+    __shared__ ZeLds L;
+    const uint32_t fi = blockIdx.x;
+    const GpuBlock gb = blocks[fi];
+    const uint32_t lane = threadIdx.x;
+    const uint8_t* const frame = comp + gb.src_off;
+    const uint32_t n = gb.src_len, dst_len = gb.dst_len;
+    ZFrameHdr* const hdr = reinterpret_cast<ZFrameHdr*>(scratch + lay.hdr_at) + fi;
+    uint4* const ck = reinterpret_cast<uint4*>(scratch + lay.ck_at) + static_cast<uint64_t>(fi) * lay.ck_stride;
+    uint64_t* const recs = reinterpret_cast<uint64_t*>(scratch + lay.rec_at) + static_cast<uint64_t>(fi) * lay.rec_stride;
+    uint8_t* const lits = scratch + lay.lit_at + static_cast<uint64_t>(fi) * lay.lit_stride;
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long t_lit = 0, t_tab = 0, t_seq = 0;
+    uint32_t err = 0;
+    auto fail = [&](uint32_t code) {
+        if (!err) err = code;
+    };
+    if (lane < 36u) L.ll_base[lane] = kLLBase[lane];
+    if (lane < 53u) L.ml_base[lane] = kMLBase[lane];
+    // ---- frame header (uniform)
+    uint32_t p = 0;
+    if (dst_len > kZstdMaxFrameBytes || n >= (1u << 27))
+        fail(kZstdTooLarge);
+    else if (n < 6u)
+        fail(kZstdBadHeader);
+    else if (ld_le32(frame) != 0xFD2FB528u)
+        fail(kZstdUnsupported);
+    else {
+        const uint32_t fhd = frame[4];
+        const uint32_t fcs_flag = fhd >> 6, single = (fhd >> 5) & 1u;
+        p = 5u + (single ? 0u : 1u);
+        if (fhd & 8u)
+            fail(kZstdBadHeader);
+        else if (fhd & 4u)
+            fail(kZstdChecksum);
+        else if (fhd & 3u)
+            fail(kZstdDictionary);
+        else {
+            const uint32_t fcs_bytes = fcs_flag == 0u ? single : (1u << fcs_flag);
+            if (p + fcs_bytes > n)
+                fail(kZstdBadHeader);
+            else if (fcs_bytes) {
+                uint64_t content = 0;
+                for (uint32_t i = 0; i < fcs_bytes; ++i) content |= static_cast<uint64_t>(frame[p + i]) << (8u * i);
+                if (fcs_bytes == 2u) content += 256u;
+                if (content != dst_len) fail(kZstdBadHeader);
+                p += fcs_bytes;
+            }
+        }
+    }
+    uint32_t hist0 = 1u, hist1 = 4u, hist2 = 8u;   // offset history at the start of the pass (uniform)
+    uint32_t carry_huf = kNone, carry_tab[3] = {kNone, kNone, kNone};
+    uint32_t rec_top = 0, lit_top = 0, out_top = 0, nblk = 0, nrec_all = 0;
+    bool last = false;
+    while (!last && !err) {
+        // ---- block headers of this pass (uniform walk: a header gives the position of the next one)
+        uint32_t nb = 0;
+        uint32_t my_type = 0, my_size = 0, my_at = 0;
+        while (nb < kZeLanes && !last) {
+            if (p + 3u > n) {
+                fail(kZstdBadBlock);
+                break;
+            }
+            const uint32_t bh = ld_le24(frame + p);
+            last = bh & 1u;
+            const uint32_t type = (bh >> 1) & 3u, size = bh >> 3;
+            const uint32_t at = p + 3u;
+            const uint32_t span = type == 1u ? 1u : size;
+            if (type == 3u || size > kBlockMax || at + span > n) {
+                fail(kZstdBadBlock);
+                break;
+            }
+            if (lane == nb) {
+                my_type = type;
+                my_size = size;
+                my_at = at;
+            }
+            p = at + span;
+            ++nb;
+            if (++nblk > kZstdMaxBlocks) {
+                fail(kZstdTooManyBlocks);
+                break;
+            }
+        }
+        if (err) break;
+        const bool mine = lane < nb;
+        // ---- section headers, every lane its block
+        uint32_t lt = 0, nlit = 0, lit_data = 0, lit_end = 0, streams = 0, nseq = 0, bits_at = 0, bend = 0;
+        uint32_t def_huf = kNone, def_tab[3] = {kNone, kNone, kNone};
+        uint32_t lerr = 0;
+        if (mine && my_type == 2u) {
+            bend = my_at + my_size;
+            if (my_size < 2u)
+                lerr = kZstdBadBlock;
+            else {
+                const uint32_t b0 = frame[my_at];
+                lt = b0 & 3u;
+                const uint32_t fmt = (b0 >> 2) & 3u;
+                if (lt < 2u) {
+                    uint32_t hl;
+                    if (fmt == 1u) {
+                        nlit = ld_le16(frame + my_at) >> 4;
+                        hl = 2u;
+                    } else if (fmt == 3u) {
+                        nlit = ld_le24(frame + my_at) >> 4;
+                        hl = 3u;
+                    } else {
+                        nlit = b0 >> 3;
+                        hl = 1u;
+                    }
+                    lit_data = my_at + hl;
+                    lit_end = lit_data + (lt == 0u ? nlit : 1u);
+                } else {
+                    uint32_t csize, hl;
+                    const uint64_t h = ld_le64(frame + my_at);
+                    if (fmt < 2u) {
+                        nlit = static_cast<uint32_t>(h >> 4) & 1023u;
+                        csize = static_cast<uint32_t>(h >> 14) & 1023u;
+                        hl = 3u;
+                    } else if (fmt == 2u) {
+                        nlit = static_cast<uint32_t>(h >> 4) & 16383u;
+                        csize = static_cast<uint32_t>(h >> 18) & 16383u;
+                        hl = 4u;
+                    } else {
+                        nlit = static_cast<uint32_t>(h >> 4) & 262143u;
+                        csize = static_cast<uint32_t>(h >> 22) & 262143u;
+                        hl = 5u;
+                    }
+                    streams = fmt == 0u ? 1u : 4u;
+                    lit_data = my_at + hl;
+                    lit_end = lit_data + csize;
+                    if (lt == 2u) def_huf = lit_data;
+                }
+                if (lit_end > bend || nlit > kBlockMax)
+                    lerr = kZstdBadLiterals;
+                else if (lit_end >= bend)
+                    lerr = kZstdBadSequences;
+                else {
+                    uint32_t q = lit_end;
+                    const uint32_t s0 = frame[q];
+                    if (s0 == 0u) {
+                        if (q + 1u != bend) lerr = kZstdBadSequences;
+                    } else {
+                        if (s0 < 128u) {
+                            nseq = s0;
+                            q += 1u;
+                        } else if (s0 < 255u) {
+                            if (q + 2u > bend) lerr = kZstdBadSequences;
+                            nseq = ((s0 - 128u) << 8) + frame[q + 1u];
+                            q += 2u;
+                        } else {
+                            if (q + 3u > bend) lerr = kZstdBadSequences;
+                            nseq = ld_le16(frame + q + 1u) + 0x7F00u;
+                            q += 3u;
+                        }
+                        if (!lerr && (q >= bend || nseq > kBlockMax / 3u)) lerr = kZstdBadSequences;
+                        if (!lerr) {
+                            const uint32_t modes = frame[q];
+                            q += 1u;
+                            if (modes & 3u) lerr = kZstdBadSequences;
+                            const uint32_t max_sym[3] = {35u, 31u, 52u}, max_log[3] = {9u, 8u, 9u};
+                            for (uint32_t t = 0; t < 3u && !lerr; ++t) {
+                                const uint32_t mode = (modes >> (6u - 2u * t)) & 3u;
+                                if (mode == 3u) {
+                                    def_tab[t] = kRepeat;
+                                    continue;
+                                }
+                                def_tab[t] = (mode << 28) | q;
+                                if (mode == 1u) {
+                                    if (q >= bend) lerr = kZstdBadSequences;
+                                    q += 1u;
+                                } else if (mode == 2u) {
+                                    uint32_t lg, after;
+                                    if (!fse_read_counts(frame, q, bend, max_sym[t], max_log[t], L.counts[lane], lg, after))
+                                        lerr = kZstdBadSequences;
+                                    else
+                                        q = after;
+                                }
+                            }
+                            bits_at = q;
+                        }
+                    }
+                }
+            }
+        } else if (mine) {
+            nlit = my_type == 0u ? my_size : (my_size ? 1u : 0u);
+        }
+        if (__builtin_amdgcn_ballot_w64(lerr != 0u)) {
+            const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(__builtin_amdgcn_ballot_w64(lerr != 0u)));
+            fail(__builtin_amdgcn_readlane(lerr, first));
+            break;
+        }
+        // ---- scratch placement: records (a multiple of 64 per block), literals
+        const uint32_t rec_cap = mine ? (my_type == 2u ? (nseq + 40u + 63u) & ~63u : 64u) : 0u;
+        const uint32_t rec_incl = wave_scan_add(rec_cap), lit_incl = wave_scan_add(mine ? nlit : 0u);
+        const uint32_t rec_at = rec_top + rec_incl - rec_cap, lit_at = lit_top + lit_incl - (mine ? nlit : 0u);
+        rec_top += __builtin_amdgcn_readlane(rec_incl, 63);
+        lit_top += __builtin_amdgcn_readlane(lit_incl, 63);
+        if (rec_top > lay.rec_stride || lit_top > lay.lit_stride - 16u) {
+            fail(kZstdBadSize);
+            break;
+        }
+        // ---- what the others need to know
+        if (mine) {
+            ZeShare& s = L.sh[lane];
+            s.def_huf = def_huf;
+            s.def_tab[0] = def_tab[0];
+            s.def_tab[1] = def_tab[1];
+            s.def_tab[2] = def_tab[2];
+            s.type = my_type;
+            s.size = my_size;
+            s.at = my_at;
+            s.lit_type = lt;
+            s.nlit = nlit;
+            s.lit_at = lit_at;
+            s.lit_data = lit_data;
+            s.lit_end = lit_end;
+            s.streams = streams;
+            s.rec_at = rec_at;
+            s.rec_cap = rec_cap;
+        }
+        __syncthreads();  // (one wave: orders the LDS writes above before the reads below)
+        // sources of the tables this block repeats: the nearest earlier definition
+        uint32_t huf_src = def_huf, tab_src[3] = {def_tab[0], def_tab[1], def_tab[2]};
+        if (mine && my_type == 2u) {
+            if (lt == 3u) {
+                huf_src = carry_huf;
+                for (uint32_t j = 0; j < lane; ++j)
+                    if (L.sh[j].def_huf != kNone) huf_src = L.sh[j].def_huf;
+                if (huf_src == kNone) lerr = kZstdNoTable;
+            }
+            for (uint32_t t = 0; t < 3u; ++t)
+                if (def_tab[t] == kRepeat) {
+                    uint32_t src = carry_tab[t];
+                    for (uint32_t j = 0; j < lane; ++j)
+                        if (L.sh[j].def_tab[t] < kRepeat) src = L.sh[j].def_tab[t];
+                    if (src == kNone) lerr = kZstdNoTable;
+                    tab_src[t] = src;
+                }
+        }
+        for (uint32_t j = 0; j < nb; ++j) {
+            if (L.sh[j].def_huf != kNone) carry_huf = L.sh[j].def_huf;
+            for (uint32_t t = 0; t < 3u; ++t)
+                if (L.sh[j].def_tab[t] < kRepeat) carry_tab[t] = L.sh[j].def_tab[t];
+        }
+        // ---- literals: Huffman tables (a lane per block), then the streams (four lanes per block)
+        const unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0ull;
+        if (mine && my_type == 2u && lt >= 2u && !lerr) {
+            uint32_t after = 0;
+            const uint32_t mb = huf_build(frame, huf_src, lt == 2u ? lit_end : n, L.tab[lane], L.weights[lane], L.counts[lane], L.rank[lane], after);
+            if (!mb) lerr = kZstdBadHuffman;
+            L.sh[lane].max_bits = mb;
+            L.sh[lane].stream_at = lt == 2u ? after : lit_data;
+        }
+        __syncthreads();
+        {
+            const uint32_t bk = lane >> 2, st = lane & 3u;
+            bool act = false;
+            uint32_t s_begin = 0, s_end = 0, count = 0, mb = 0, o_at = 0;
+            uint32_t herr = 0;
+            if (bk < nb && L.sh[bk].type == 2u && L.sh[bk].lit_type >= 2u && L.sh[bk].max_bits) {
+                const ZeShare& s = L.sh[bk];
+                mb = s.max_bits;
+                if (s.streams == 1u) {
+                    act = st == 0u;
+                    s_begin = s.stream_at;
+                    s_end = s.lit_end;
+                    count = s.nlit;
+                    o_at = s.lit_at;
+                } else if (s.stream_at + 6u > s.lit_end) {
+                    herr = kZstdBadLiterals;
+                } else {
+                    const uint32_t j1 = ld_le16(frame + s.stream_at), j2 = ld_le16(frame + s.stream_at + 2u), j3 = ld_le16(frame + s.stream_at + 4u);
+                    const uint32_t b0 = s.stream_at + 6u, b1 = b0 + j1, b2 = b1 + j2, b3 = b2 + j3;
+                    const uint32_t per = (s.nlit + 3u) >> 2;
+                    if (b3 >= s.lit_end || per * 3u > s.nlit)
+                        herr = kZstdBadLiterals;
+                    else {
+                        act = true;
+                        s_begin = st == 0u ? b0 : (st == 1u ? b1 : (st == 2u ? b2 : b3));
+                        s_end = st == 0u ? b1 : (st == 1u ? b2 : (st == 2u ? b3 : s.lit_end));
+                        count = st < 3u ? per : s.nlit - 3u * per;
+                        o_at = s.lit_at + st * per;
+                    }
+                }
+                if (act && (s_end <= s_begin || frame[s_end - 1u] == 0u)) {
+                    herr = kZstdBadLiterals;
+                    act = false;
+                }
+            }
+            // backward stream: `pos` bits are unread; the window is the 8 bytes that end with the byte pos falls into
+            int32_t pos = act ? static_cast<int32_t>(8u * (s_end - 1u) + highbit(frame[s_end - 1u])) : 0;
+            const int32_t start_bit = static_cast<int32_t>(8u * s_begin);
+            const uint16_t* const table = L.tab[bk & (kZeLanes - 1u)].huf;
+            uint8_t* o = lits + o_at;
+            uint32_t left = act ? count : 0u;
+            while (__builtin_amdgcn_ballot_w64(left > 0u)) {
+                if (left > 0u) {
+                    const int32_t byte = pos >> 3;
+                    const int32_t lo = byte - 7;                   // (>= 0: a stream starts behind at least 9 bytes of headers)
+                    uint64_t v = ld_le64(frame + (lo < 0 ? 0 : lo));
+                    const int32_t cut = start_bit - 8 * lo;        // bits of the window below the stream read as zero
+                    if (cut > 0) v = cut >= 64 ? 0ull : (v >> cut) << cut;
+                    uint64_t w = v << (8u - (static_cast<uint32_t>(pos) & 7u));
+                    const uint32_t take_n = left < 4u ? left : 4u;
+                    uint32_t word = 0;
+                    for (uint32_t k = 0; k < take_n; ++k) {
+                        const uint32_t e = table[static_cast<uint32_t>(w >> (64u - mb)) & 2047u];
+                        word |= (e & 255u) << (8u * k);
+                        w <<= (e >> 8);
+                        pos -= static_cast<int32_t>(e >> 8);
+                    }
+                    if (take_n == 4u) {
+                        __builtin_memcpy(o, &word, 4);
+                    } else {
+                        for (uint32_t k = 0; k < take_n; ++k) o[k] = static_cast<uint8_t>(word >> (8u * k));
+                    }
+                    o += take_n;
+                    left -= take_n;
+                    if (pos < start_bit - 64) left = 0u;   // (far past the start: the stream is damaged, checked below)
+                }
+            }
+            if (act && pos != start_bit) herr = kZstdBadLiterals;
+            if (herr && !lerr) lerr = herr;
+        }
+        // raw / RLE literals, raw / RLE blocks: the bytes as they are (the whole wave, block after block)
+        for (uint32_t j = 0; j < nb; ++j) {
+            const ZeShare& s = L.sh[j];
+            uint32_t from = 0, cnt = 0;
+            bool fill = false;
+            if (s.type == 0u) {
+                from = s.at;
+                cnt = s.size;
+            } else if (s.type == 1u) {
+                from = s.at;
+                cnt = s.nlit;
+            } else if (s.lit_type == 0u) {
+                from = s.lit_data;
+                cnt = s.nlit;
+            } else if (s.lit_type == 1u) {
+                from = s.lit_data;
+                cnt = s.nlit;
+                fill = true;
+            }
+            for (uint32_t i = lane; i < cnt; i += 64u) lits[s.lit_at + i] = frame[fill ? from : from + i];
+        }
+        if (PROF) t_lit += __builtin_readcyclecounter() - t0;
+        __syncthreads();
+        // ---- sequences: tables, then the serial chain of every block in its lane
+        const unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0ull;
+        uint32_t logl = 0, logo = 0, logm = 0;
+        bool seq_act = mine && my_type == 2u && nseq > 0u && !lerr;
+        if (seq_act) {
+            ZeTables& T = L.tab[lane];
+            logl = seq_table(frame, n, tab_src[0], T.fse.ll, L.counts[lane], kLLDefault, 36u, 6u, 35u, 9u, [](uint32_t s) { return s < 36u ? static_cast<uint32_t>(kLLBits[s]) : 0u; });
+            logo = seq_table(frame, n, tab_src[1], T.fse.of, L.counts[lane], kOFDefault, 29u, 5u, 31u, 8u, [](uint32_t s) { return s; });
+            logm = seq_table(frame, n, tab_src[2], T.fse.ml, L.counts[lane], kMLDefault, 53u, 6u, 52u, 9u, [](uint32_t s) { return s < 53u ? static_cast<uint32_t>(kMLBits[s]) : 0u; });
+            if (logl == ~0u || logo == ~0u || logm == ~0u) {
+                lerr = kZstdBadSequences;
+                seq_act = false;
+            } else if (bend <= bits_at || frame[bend - 1u] == 0u) {
+                lerr = kZstdBadBitstream;
+                seq_act = false;
+            }
+        }
+        if (PROF) t_tab += __builtin_readcyclecounter() - t1;
+        const unsigned long long t2 = PROF ? __builtin_readcyclecounter() : 0ull;
+        // the bit stream ring of a lane holds frame bytes [rlo, rlo + kZeRing) at index (byte & (kZeRing - 1)), its first 16
+        // bytes once more behind its end; refills go downwards, 256 bytes at a time, by the whole wave
+        int32_t pos = seq_act ? static_cast<int32_t>(8u * (bend - 1u) + highbit(frame[bend - 1u])) : 0;
+        const int32_t start_bit = static_cast<int32_t>(8u * bits_at);
+        int32_t rlo = seq_act ? ((pos >> 3) & ~static_cast<int32_t>(kZeChunk - 1u)) + static_cast<int32_t>(kZeChunk) : 0;
+        auto refill = [&](bool want) {
+            // lanes that want a chunk and have room for it: the bytes it overwrites lie above the window
+            const bool can = want && ((pos >> 3) - (rlo - static_cast<int32_t>(kZeChunk)) <= static_cast<int32_t>(kZeRing) - 1);
+            uint64_t m = __builtin_amdgcn_ballot_w64(can) & 0xFFull;
+            while (m) {
+                const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(m));
+                m &= m - 1ull;
+                const int32_t nlo = __builtin_amdgcn_readlane(rlo, j) - static_cast<int32_t>(kZeChunk);
+                // (never below the buffer, never beyond the 64 readable bytes behind the payload: what lies there is never used)
+                int32_t rel = nlo + 4 * static_cast<int32_t>(lane);
+                if (rel > static_cast<int32_t>(n) + 56) rel = static_cast<int32_t>(n) + 56;
+                const int64_t src = static_cast<int64_t>(gb.src_off) + rel;
+                const uint32_t v = ld_le32(comp + (src < 0 ? 0 : src));
+                const uint32_t ri = (static_cast<uint32_t>(nlo) & (kZeRing - 1u)) + 4u * lane;
+                *reinterpret_cast<uint32_t*>(&L.ring[j][ri]) = v;
+                if (ri < 16u) *reinterpret_cast<uint32_t*>(&L.ring[j][kZeRing + ri]) = v;
+            }
+            if (can) rlo -= static_cast<int32_t>(kZeChunk);
+        };
+        for (int k = 0; k < 4; ++k) refill(seq_act);
+        __syncthreads();
+        auto window = [&](uint64_t& hi, uint64_t& lo) {
+            const uint32_t ri = static_cast<uint32_t>((pos >> 3) - 15) & (kZeRing - 1u);
+            __builtin_memcpy(&lo, &L.ring[lane & (kZeLanes - 1u)][ri], 8);
+            __builtin_memcpy(&hi, &L.ring[lane & (kZeLanes - 1u)][ri + 8u], 8);
+        };
+        // bits [t - 64, t) of hi:lo for t >= 65, else bits [0, t) at the top
+        auto top64 = [](uint64_t hi, uint64_t lo, uint32_t t) -> uint64_t { return t >= 65u ? (hi << (128u - t)) | (lo >> (t - 64u)) : lo << (64u - t); };
+        uint32_t sl = 0, so = 0, sm = 0;
+        if (seq_act) {
+            uint64_t hi, lo;
+            window(hi, lo);
+            uint64_t w = top64(hi, lo, (static_cast<uint32_t>(pos) & 7u) + 120u);
+            sl = take(w, logl);
+            so = take(w, logo);
+            sm = take(w, logm);
+            pos -= static_cast<int32_t>(logl + logo + logm);
+            if (pos < start_bit) {
+                lerr = kZstdBadBitstream;
+                seq_act = false;
+            }
+        }
+        uint32_t r0 = 0, r1 = 0, r2 = 0, known = 0;          // this block's view of the offset history; bit i of known: slot i holds a value
+        uint32_t nrec = 0, out = 0, lit_pos = 0, n_sym = 0;
+        bool all_known = false;
+        uint64_t* const myrec = recs + rec_at;
+        auto put = [&](uint32_t w0, uint32_t ll, uint32_t ml) {
+            if ((nrec & 63u) == 0u && nrec < rec_cap) ck[(rec_at + nrec) >> 6] = make_uint4(out, lit_pos, 0u, 0u);
+            if (nrec < rec_cap) myrec[nrec] = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(ll | (ml << 14)) << 32);
+            ++nrec;
+            out += ll + ml;
+            lit_pos += ll;
+        };
+        auto literal_run = [&](uint32_t count) {
+            while (count) {
+                const uint32_t piece = count < kRecLL ? count : kRecLL;
+                put(kRecFlag, piece, 0u);
+                count -= piece;
+            }
+        };
+        const ZeTables& T = L.tab[lane & (kZeLanes - 1u)];
+        uint32_t i = 0;
+        while (__builtin_amdgcn_ballot_w64(seq_act && i < nseq)) {
+            const bool step = seq_act && i < nseq;
+            // (a lane whose window is about to run out of staged bytes asks for a chunk; the whole wave copies)
+            if (__builtin_amdgcn_ballot_w64(step && (pos >> 3) - rlo < 48)) refill(step && (pos >> 3) - rlo < 512);
+            if (step) {
+                const uint32_t el = T.fse.ll[sl & 511u], eo = T.fse.of[so & 255u], em = T.fse.ml[sm & 511u];
+                uint64_t hi, lo;
+                window(hi, lo);
+                const uint32_t oc = (eo >> 10) & 31u, mlb = (em >> 10) & 31u, llb = (el >> 10) & 31u;
+                const bool lastseq = i + 1u == nseq;
+                const uint32_t nbl = lastseq ? 0u : (el >> 6) & 15u, nbm = lastseq ? 0u : (em >> 6) & 15u, nbo = lastseq ? 0u : (eo >> 6) & 15u;
+                const uint32_t ext = oc + mlb + llb;
+                const uint32_t t = (static_cast<uint32_t>(pos) & 7u) + 120u;
+                uint64_t w1 = top64(hi, lo, t);
+                const uint32_t obits = take(w1, oc), mbits = take(w1, mlb), lbits = take(w1, llb);
+                uint64_t w2 = top64(hi, lo, t - ext);
+                const uint32_t bl = take(w2, nbl), bm = take(w2, nbm), bo = take(w2, nbo);
+                pos -= static_cast<int32_t>(ext + nbl + nbm + nbo);
+                sl = (el >> 16) + bl;
+                sm = (em >> 16) + bm;
+                so = (eo >> 16) + bo;
+                const uint32_t lsym = el & 63u, msym = em & 63u;
+                const uint32_t ofv = (1u << oc) + obits;
+                uint32_t mlv = L.ml_base[msym < 53u ? msym : 52u] + mbits;
+                uint32_t llv = L.ll_base[lsym < 36u ? lsym : 35u] + lbits;
+                if (oc > 26u)
+                    lerr = kZstdBadOffset;
+                else if (pos < start_bit)
+                    lerr = kZstdBadBitstream;
+                else if (lit_pos + llv > nlit)
+                    lerr = kZstdBadLiterals;
+                else if (out + llv + mlv > kBlockMax)
+                    lerr = kZstdBadSize;
+                if (lerr) {
+                    seq_act = false;
+                } else {
+                    // repeat offsets (RFC 8878 3.1.1.5); the history may still hold slots this block does not know
+                    uint32_t w0;
+                    if (ofv > 3u) {
+                        r2 = r1;
+                        r1 = r0;
+                        r0 = ofv - 3u;
+                        known = ((known << 1) | 1u) & 7u;
+                        w0 = r0;
+                    } else {
+                        const uint32_t idx = ofv - 1u + (llv == 0u ? 1u : 0u);
+                        uint32_t off;
+                        if (idx == 0u) {
+                            off = r0;
+                        } else if (idx == 1u) {
+                            off = r1;
+                            r1 = r0;
+                            r0 = off;
+                            known = (known & 4u) | ((known & 1u) << 1) | ((known >> 1) & 1u);
+                        } else if (idx == 2u) {
+                            off = r2;
+                            r2 = r1;
+                            r1 = r0;
+                            r0 = off;
+                            known = ((known << 1) & 6u) | ((known >> 2) & 1u);
+                        } else {
+                            off = r0 - 1u;
+                            r2 = r1;
+                            r1 = r0;
+                            r0 = off;
+                            known = ((known << 1) & 6u) | (known & 1u);
+                        }
+                        if (all_known) {
+                            if (off == 0u) {
+                                lerr = kZstdBadOffset;
+                                seq_act = false;
+                            }
+                            w0 = off & 0x3FFFFFFFu;
+                        } else {
+                            w0 = kRecRep | (llv == 0u ? kRecFlag : 0u) | ofv;
+                        }
+                    }
+                    while (llv > kRecLL) {
+                        put(kRecFlag, kRecLL, 0u);
+                        llv -= kRecLL;
+                    }
+                    uint32_t piece = mlv < kRecML ? mlv : kRecML;
+                    put(w0, llv, piece);
+                    mlv -= piece;
+                    while (mlv) {
+                        piece = mlv < kRecML ? mlv : kRecML;
+                        put((w0 & kRecRep) ? (kRecRep | kRecFlag | 0x10u) : (w0 | kRecFlag), 0u, piece);
+                        mlv -= piece;
+                    }
+                    if (!all_known && known == 7u) {
+                        all_known = true;
+                        n_sym = nrec;
+                    }
+                    ++i;
+                }
+            }
+        }
+        if (mine && my_type == 2u && nseq > 0u && !lerr && pos != start_bit) lerr = kZstdBadBitstream;
+        if (mine && !lerr) {
+            if (my_type == 0u) {
+                literal_run(my_size);
+            } else if (my_type == 1u) {
+                if (my_size) {
+                    uint32_t left = my_size - 1u;
+                    uint32_t piece = left < kRecML ? left : kRecML;
+                    put((piece ? 1u : 0u) | kRecFlag, 1u, piece);
+                    left -= piece;
+                    while (left) {
+                        piece = left < kRecML ? left : kRecML;
+                        put(1u | kRecFlag, 0u, piece);
+                        left -= piece;
+                    }
+                }
+            } else {
+                literal_run(nlit - lit_pos);
+                if (!all_known) n_sym = nrec;
+                if (out > kBlockMax) lerr = kZstdBadSize;
+            }
+            if (nrec > rec_cap) lerr = kZstdBadSize;
+        }
+        if (PROF) t_seq += __builtin_readcyclecounter() - t2;
+        if (__builtin_amdgcn_ballot_w64(lerr != 0u)) {
+            const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(__builtin_amdgcn_ballot_w64(lerr != 0u)));
+            fail(__builtin_amdgcn_readlane(lerr, first));
+            break;
+        }
+        // ---- the records of this wave must be visible to the lane that replays them
+        __threadfence();
+        if (mine) {
+            ZeShare& s = L.sh[lane];
+            s.nrec = nrec;
+            s.out_len = out;
+            s.n_sym = n_sym;
+            s.hist_known = all_known ? 1u : 0u;
+            s.hist[0] = r0;
+            s.hist[1] = r1;
+            s.hist[2] = r2;
+        }
+        __syncthreads();
+        // replay of the prefixes written with an unknown history, block after block (uniform; the stores by lane 0)
+        uint32_t rerr = 0;
+        for (uint32_t j = 0; j < nb; ++j) {
+            const ZeShare& s = L.sh[j];
+            uint64_t* const rj = recs + s.rec_at;
+            for (uint32_t k = 0; k < s.n_sym; ++k) {
+                const uint64_t w = __hip_atomic_load(&rj[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const uint32_t w0 = static_cast<uint32_t>(w);
+                if (w0 & kRecRep) {
+                    const uint32_t code = w0 & 0xFFu;
+                    uint32_t off;
+                    if (code == 0x10u) {
+                        off = hist0;
+                    } else {
+                        const uint32_t idx = code - 1u + ((w0 & kRecFlag) ? 1u : 0u);
+                        if (idx == 0u) {
+                            off = hist0;
+                        } else if (idx == 1u) {
+                            off = hist1;
+                            hist1 = hist0;
+                            hist0 = off;
+                        } else if (idx == 2u) {
+                            off = hist2;
+                            hist2 = hist1;
+                            hist1 = hist0;
+                            hist0 = off;
+                        } else {
+                            off = hist0 - 1u;
+                            hist2 = hist1;
+                            hist1 = hist0;
+                            hist0 = off;
+                        }
+                        if (off == 0u) rerr = kZstdBadOffset;
+                    }
+                    if (lane == 0u) rj[k] = (w & 0xFFFFFFFF00000000ull) | (off & 0x3FFFFFFFu);
+                } else if (!(w0 & kRecFlag)) {
+                    hist2 = hist1;
+                    hist1 = hist0;
+                    hist0 = w0;
+                }
+            }
+            if (s.hist_known) {
+                hist0 = s.hist[0];
+                hist1 = s.hist[1];
+                hist2 = s.hist[2];
+            }
+        }
+        if (rerr) {
+            fail(rerr);
+            break;
+        }
+        // checkpoints: positions in the frame, records valid; the slots a block did not use point at its end
+        for (uint32_t j = 0; j < nb; ++j) {
+            const ZeShare& s = L.sh[j];
+            const uint32_t first_slot = s.rec_at >> 6, nslot = s.rec_cap >> 6;
+            for (uint32_t q = lane; q < nslot; q += 64u) {
+                const uint32_t first = q * 64u;
+                uint4 c;
+                if (first < s.nrec) {
+                    c = ck[first_slot + q];
+                    c.x += out_top;
+                    c.y += s.lit_at;
+                    c.z = s.nrec - first < 64u ? s.nrec - first : 64u;
+                } else {
+                    c = make_uint4(out_top + s.out_len, s.lit_at + s.nlit, 0u, 0u);
+                }
+                ck[first_slot + q] = c;
+            }
+            out_top += s.out_len;
+            nrec_all += s.nrec;
+        }
+        __syncthreads();
+    }
+    if (!err && p != n) fail(kZstdTrailingData);
+    if (!err && out_top != dst_len) fail(kZstdBadSize);
+    if (lane == 0u) {
+        hdr->nslots = err ? 0u : rec_top >> 6;
+        hdr->nrec = nrec_all;
+        hdr->out_len = out_top;
+        hdr->nblk = nblk;
+        status[fi] = err;
+        if (!err) atomicAdd(&tally[0], static_cast<unsigned long long>(nrec_all));
+        if (PROF) {
+            atomicAdd(&tally[17], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
+            atomicAdd(&tally[18], t_lit);
+            atomicAdd(&tally[19], t_tab);
+            atomicAdd(&tally[20], t_seq);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ zstd_execute
+constexpr uint32_t kZxEmit = 3, kZxScan = 3;
+constexpr uint32_t kZxThreads = 64u * (kZxEmit + kZxScan + 1u);
+constexpr uint32_t kZxNear = 65535u;   // matches up to this far back read the ring; farther ones the flushed output
+
+struct __attribute__((aligned(16))) ZxLds {
+    static constexpr uint32_t kNR = 65536u + 4096u, kMR = 2048u, kK = 512u, kChunk = 256u, kFlush = 1024u, kScan = kZxScan;
+    static constexpr bool kPublishFlush = true;
+    static constexpr uint32_t kAhead = kNR - 65536u - kChunk;   // the emitters' position may lead the copier's by this much
+    static constexpr uint32_t kSpan = 1536u;                    // most output bytes an emitter writes before publishing
+    uint8_t ring[kNR];
+    uint32_t mark[kMR];
+    uint32_t fsrc[kK];
+    uint32_t e_pos[kZxEmit], f_op;       // per emitter: where its first unfinished batch starts; copier: output flushed AND landed (16 bytes)
+    uint32_t s_clr[kZxScan], d_op;       // (16 bytes: one read)
+    uint32_t s_done[kZxScan];
+    uint32_t c_ready, s_carry[8], err;
+};
+static_assert(ZxLds::kSpan + ZxLds::kChunk <= ZxLds::kMR && ZxLds::kSpan + ZxLds::kChunk + ZxLds::kK <= ZxLds::kAhead + ZxLds::kChunk, "no cyclic wait");
+static_assert(sizeof(ZxLds) <= 81920, "two workgroups per CU");
+
+// ---- emitters: records -> markers, literal bytes.  Emitter `which` takes the batches (64 records, one checkpoint)
+// which, which + kZxEmit, ...; a checkpoint carries the batch's output and literal positions, so the emitters do not depend
+// on each other.  Records and the first 256 literal bytes of a batch are loaded one batch ahead, checkpoints two.
+template <bool PROF>
+__device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ lits,
+                        const uint32_t lit_cap, const uint8_t* __restrict__ dst, const uint32_t nslots, const uint32_t oend, const uint32_t lane,
+                        const uint32_t which, unsigned long long* __restrict__ tally)
+{
+    uint32_t err = 0, s_seen = 0, d_seen = 0, nfar = 0;
+    unsigned long long t_wait = 0, n_groups = 0, n_batches = 0;
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    auto room = [&](uint32_t at, uint32_t nbytes) -> bool {
+        if (__builtin_expect(at + nbytes <= s_seen + ZxLds::kMR && at + nbytes <= d_seen + ZxLds::kAhead, 1)) return true;
+        return wg_wait_timed<PROF>(L, t_wait, [&] {
+            const uint4 t = wg_ld4(L.s_clr);
+            s_seen = umin3(t.x, t.y, t.z);
+            d_seen = t.w;
+            return at + nbytes <= s_seen + ZxLds::kMR && at + nbytes <= d_seen + ZxLds::kAhead;
+        });
+    };
+    auto ring_at = [](uint32_t pos) -> uint32_t { return pos % ZxLds::kNR; };
+    const uint4 ck_end = make_uint4(oend, 0u, 0u, 0u);
+    auto load_ck = [&](uint32_t g) -> uint4 {
+        const uint4 c = g < nslots ? ck[g] : ck_end;
+        return make_uint4(__builtin_amdgcn_readfirstlane(c.x), __builtin_amdgcn_readfirstlane(c.y), __builtin_amdgcn_readfirstlane(c.z), 0u);
+    };
+    auto load_lit = [&](const uint4& c) -> uint32_t {
+        // the 256 literal bytes from the 4-byte boundary at or below the batch's literal position
+        const uint32_t at = (c.y & ~3u) + 4u * lane;
+        return c.z && at + 4u <= lit_cap ? *reinterpret_cast<const uint32_t*>(lits + at) : 0u;
+    };
+    uint4 c0 = load_ck(which), c1 = load_ck(which + kZxEmit);
+    uint64_t rec0 = which < nslots && lane < c0.z ? recs[static_cast<uint64_t>(which) * 64u + lane] : 0ull;
+    uint32_t lit0 = load_lit(c0);
+    wg_st(&L.e_pos[which], c0.x);
+    for (uint32_t g = which; g < nslots; g += kZxEmit) {
+        // loads for the next two batches first
+        const uint4 c2 = load_ck(g + 2u * kZxEmit);
+        const uint64_t rec1 = g + kZxEmit < nslots && lane < c1.z ? recs[static_cast<uint64_t>(g + kZxEmit) * 64u + lane] : 0ull;
+        const uint32_t lit1 = load_lit(c1);
+        const uint32_t nvalid = c0.z;
+        if (nvalid) {
+            ++n_batches;
+            const bool valid = lane < nvalid;
+            const uint32_t w0 = static_cast<uint32_t>(rec0), w1 = static_cast<uint32_t>(rec0 >> 32);
+            const uint32_t ll = valid ? w1 & 16383u : 0u, ml = valid ? (w1 >> 14) & 16383u : 0u, off = w0 & 0x3FFFFFFFu;
+            const uint32_t len = ll + ml;
+            const uint32_t incl = wave_scan_add(len), lincl = wave_scan_add(ll);
+            const uint32_t total = __builtin_amdgcn_readlane(incl, 63), ltotal = __builtin_amdgcn_readlane(lincl, 63);
+            const uint32_t rel = incl - len;
+            const uint32_t op = c0.x + rel, mpos = op + ll, lp = c0.y + lincl - ll;
+            if (__builtin_expect(__builtin_amdgcn_ballot_w64(valid & (ml > 0u) & ((off == 0u) | (off > mpos))) != 0ull, 0)) {
+                err = kZstdBadOffset;
+                break;
+            }
+            if (__builtin_expect(c0.x > oend || total > oend - c0.x || c0.y + ltotal > lit_cap || __builtin_amdgcn_ballot_w64(valid & ((w0 & kRecRep) != 0u)) != 0ull, 0)) {
+                err = kZstdBadSize;
+                break;
+            }
+            const bool far = valid & (ml > 0u) & (off > kZxNear);
+            // literal bytes of short runs come out of the 256 prefetched ones: byte a of them is this run's first
+            const uint32_t a = (c0.y & 3u) + (lincl - ll);
+            const uint32_t d_lo = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>((a >> 2) << 2), static_cast<int>(lit0)));
+            const uint32_t d_hi = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(((a >> 2) + 1u) << 2), static_cast<int>(lit0)));
+            const uint32_t lit4 = __builtin_amdgcn_alignbyte(d_hi, d_lo, a & 3u);
+            const uint32_t ri = ring_at(op);
+            // short: 1..4 literal bytes in reach of the prefetch, a match behind them that takes what a 4-byte store writes too
+            // much, not across the end of the ring
+            const bool shortlit = valid & (ll >= 1u) & (ll <= 4u) & (ll + ml >= 4u) & (a + 4u <= 252u) & (ri + 4u <= ZxLds::kNR);
+            const bool longlit = valid & (ll >= 1u) & !shortlit;
+            uint32_t lo = 0;  // records [0, lo) of the batch are done
+            bool failed = false;
+            while (lo < nvalid) {
+                ++n_groups;
+                // the records [lo, hi) whose output fits one publication
+                const uint32_t base_rel = __builtin_amdgcn_readlane(rel, lo);
+                const bool ingroup = valid & (lane >= lo) & (incl - base_rel <= ZxLds::kSpan);
+                const uint32_t cnt = static_cast<uint32_t>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(ingroup)));
+                if (cnt == 0u) {
+                    // ONE record longer than a publication (a long literal run, a long far match): in pieces, the whole wave
+                    const uint32_t r_ll = __builtin_amdgcn_readlane(ll, lo), r_ml = __builtin_amdgcn_readlane(ml, lo);
+                    const uint32_t r_op = __builtin_amdgcn_readlane(op, lo), r_lp = __builtin_amdgcn_readlane(lp, lo);
+                    const uint32_t r_off = __builtin_amdgcn_readlane(off, lo);
+                    const bool r_far = r_ml > 0u && r_off > kZxNear;
+                    const uint32_t nlit_bytes = r_ll + (r_far ? r_ml : 0u);   // bytes this record puts into the ring itself
+                    if (r_far) {
+                        ++nfar;
+                        const uint32_t src_end = r_op + r_ll - r_off + r_ml;
+                        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.f_op) >= src_end; })) {
+                            failed = true;
+                            break;
+                        }
+                    }
+                    for (uint32_t done = 0; done < nlit_bytes || done == 0u;) {
+                        const uint32_t piece = nlit_bytes - done < 1024u ? nlit_bytes - done : 1024u;
+                        if (!room(r_op + done, piece + 1u)) {
+                            failed = true;
+                            break;
+                        }
+                        // (markers where room has just been granted: "literal" with the first piece, the match with the last)
+                        if (lane == 0u) {
+                            if (done == 0u && nlit_bytes) L.mark[r_op & (ZxLds::kMR - 1u)] = kMarkLiteral;
+                            if (done + piece == nlit_bytes && r_ml && !r_far) L.mark[(r_op + r_ll) & (ZxLds::kMR - 1u)] = r_off;
+                        }
+                        for (uint32_t b = done + lane; b < done + piece; b += 64u) {
+                            uint8_t v;
+                            if (b < r_ll)
+                                v = lits[r_lp + b];
+                            else
+                                v = __hip_atomic_load(&dst[r_op + b - r_off], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            L.ring[ring_at(r_op + b)] = v;
+                        }
+                        done += piece;
+                        if (done < nlit_bytes) wg_st(&L.e_pos[which], r_op + done);
+                        if (piece == 0u) break;
+                    }
+                    if (failed) break;
+                    lo += 1u;
+                    wg_st(&L.e_pos[which], lo < nvalid ? __builtin_amdgcn_readlane(op, lo) : c1.x);
+                    continue;
+                }
+                const uint32_t hi = lo + cnt;
+                const uint32_t span_end = __builtin_amdgcn_readlane(incl, hi - 1u);
+                if (!room(c0.x + base_rel, span_end - base_rel)) {
+                    failed = true;
+                    break;
+                }
+                const bool now = valid & (lane >= lo) & (lane < hi);
+                // markers: a near match at its first byte, "literal" where this record's own bytes start
+                if (now & (ml > 0u) & !far) L.mark[mpos & (ZxLds::kMR - 1u)] = off;
+                if (now & ((ll > 0u) | far)) L.mark[(ll > 0u ? op : mpos) & (ZxLds::kMR - 1u)] = kMarkLiteral;
+                if (now & shortlit) __builtin_memcpy(&L.ring[ri], &lit4, 4);
+                // longer literal runs: the whole wave, run after run
+                uint64_t lm = __builtin_amdgcn_ballot_w64(now & longlit);
+                while (lm) {
+                    const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(lm));
+                    lm &= lm - 1ull;
+                    const uint32_t r_ll = __builtin_amdgcn_readlane(ll, j), r_op = __builtin_amdgcn_readlane(op, j), r_lp = __builtin_amdgcn_readlane(lp, j);
+                    for (uint32_t b = lane; b < r_ll; b += 64u) L.ring[ring_at(r_op + b)] = lits[r_lp + b];
+                }
+                // far matches: every lane its own, read from the flushed output (device-scope loads, past the L1)
+                const uint64_t fm = __builtin_amdgcn_ballot_w64(now & far);
+                if (fm) {
+                    nfar += static_cast<uint32_t>(__builtin_popcountll(fm));
+                    const uint32_t src = mpos - off;
+                    uint32_t src_end = (now & far) ? src + ml : 0u;
+                    src_end = wave_scan_max(src_end);
+                    src_end = __builtin_amdgcn_readlane(src_end, 63);
+                    if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.f_op) >= src_end; })) {
+                        failed = true;
+                        break;
+                    }
+                    if (now & far) {
+                        const uint32_t* const s4 = reinterpret_cast<const uint32_t*>(dst + (src & ~3u));
+                        const uint32_t sh = src & 3u;
+                        const uint32_t rm = ring_at(mpos);
+                        for (uint32_t b = 0; b < ml; b += 16u) {
+                            const uint32_t nw = (ml - b + sh + 3u) >> 2;  // aligned words this round needs (<= 5)
+                            uint32_t d[5];
+#pragma unroll
+                            for (uint32_t k = 0; k < 5u; ++k)
+                                d[k] = k < nw ? __hip_atomic_load(&s4[(b >> 2) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
+#pragma unroll
+                            for (uint32_t k = 0; k < 4u; ++k) {
+                                const uint32_t u = __builtin_amdgcn_alignbyte(d[k + 1u], d[k], sh);
+                                const uint32_t at = b + 4u * k;
+                                if (at + 4u <= ml && rm + at + 4u <= ZxLds::kNR) {
+                                    __builtin_memcpy(&L.ring[rm + at], &u, 4);
+                                } else {
+                                    for (uint32_t x = 0; x < 4u && at + x < ml; ++x) L.ring[ring_at(mpos + at + x)] = static_cast<uint8_t>(u >> (8u * x));
+                                }
+                            }
+                        }
+                    }
+                }
+                lo = hi;
+                wg_st(&L.e_pos[which], lo < nvalid ? c0.x + span_end : c1.x);
+            }
+            if (failed) break;
+        } else {
+            wg_st(&L.e_pos[which], c1.x);
+        }
+        c0 = c1;
+        c1 = c2;
+        rec0 = rec1;
+        lit0 = lit1;
+    }
+    if (err) wg_st(&L.err, err);
+    if (!err && !wg_ld(&L.err)) wg_st(&L.e_pos[which], oend);
+    if (lane == 0u) {
+        atomicAdd(&tally[1], static_cast<unsigned long long>(nfar));
+        if (PROF) {
+            atomicAdd(&tally[15], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
+            atomicAdd(&tally[16], t_wait);
+            atomicAdd(&tally[5], n_batches);
+            atomicAdd(&tally[6], n_groups);
+        }
+    }
+}
+
+template <bool PROF>
+__global__ __launch_bounds__(kZxThreads, 4) void zstd_execute(const GpuBlock* __restrict__ blocks, const uint8_t* __restrict__ scratch, const ZLayout lay,
+                                                              uint8_t* __restrict__ out, uint32_t* __restrict__ status, unsigned long long* __restrict__ tally)
+{
+    __shared__ ZxLds L;
+    const uint32_t fi = blockIdx.x;
+    if (status[fi] != 0u) return;  // (the entropy stage failed this frame: its status stands; uniform for the workgroup)
+    const GpuBlock b = blocks[fi];
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint32_t role = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const ZFrameHdr hdr = reinterpret_cast<const ZFrameHdr*>(scratch + lay.hdr_at)[fi];
+    const uint4* const ck = reinterpret_cast<const uint4*>(scratch + lay.ck_at) + static_cast<uint64_t>(fi) * lay.ck_stride;
+    const uint64_t* const recs = reinterpret_cast<const uint64_t*>(scratch + lay.rec_at) + static_cast<uint64_t>(fi) * lay.rec_stride;
+    const uint8_t* const lits = scratch + lay.lit_at + static_cast<uint64_t>(fi) * lay.lit_stride;
+    const uint32_t nslots = hdr.nslots <= lay.ck_stride ? hdr.nslots : 0u;
+    for (uint32_t i = threadIdx.x; i < ZxLds::kMR; i += kZxThreads) L.mark[i] = 0u;
+    if (threadIdx.x == 0u) {
+        for (uint32_t i = 0; i < kZxEmit; ++i) L.e_pos[i] = 0u;
+        L.f_op = 0u;
+        for (uint32_t i = 0; i < kZxScan; ++i) {
+            L.s_clr[i] = i * ZxLds::kChunk;
+            L.s_done[i] = 0u;
+        }
+        L.d_op = 0u;
+        L.c_ready = 0u;
+        L.err = 0u;
+    }
+    __syncthreads();
+    if (role < kZxEmit)
+        zx_emit<PROF>(L, ck, recs, lits, lay.lit_stride, out + b.dst_off, nslots, b.dst_len, lane, role, tally);
+    else if (role < kZxEmit + kZxScan) {
+        // the position below which every marker and literal byte is in place: the first batch some emitter has not finished
+        auto frontier = []() -> uint32_t {
+            const uint4 a = wg_ld4(L.e_pos);
+            return umin3(a.x, a.y, a.z);
+        };
+        wgpipe_scan<PROF>(L, b.dst_len, lane, role - kZxEmit, frontier, tally);
+    } else
+        wgpipe_copy<PROF>(L, out + b.dst_off, b.dst_len, lane, tally);
+    __syncthreads();
+    if (threadIdx.x == 0u) status[fi] = L.err == 9u ? static_cast<uint32_t>(kZstdStuck) : L.err;
+}
+
+}  // namespace fsk
+
+extern "C" uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes) { return fsk::zstd_layout(max_dst_len, nframes).total; }
+
+extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
+                                      unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int prof, hipStream_t stream)
+{
+    if (nblocks == 0) return hipSuccess;
+    if (!comp || !blocks || !out || !status || !tally || !scratch) return hipErrorInvalidValue;
+    if ((reinterpret_cast<uintptr_t>(comp) & 7u) || (reinterpret_cast<uintptr_t>(scratch) & 255u)) return hipErrorInvalidValue;
+    const fsk::ZLayout lay = fsk::zstd_layout(max_dst_len, nblocks);
+    if (lay.total > scratch_bytes) return hipErrorInvalidValue;
+    uint8_t* const sc = static_cast<uint8_t*>(scratch);
+    const dim3 grid(nblocks);
+    if (prof) {
+        hipLaunchKernelGGL((fsk::zstd_entropy<true>), grid, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_execute<true>), grid, dim3(fsk::kZxThreads), 0, stream, blocks, sc, lay, out, status, tally);
+    } else {
+        hipLaunchKernelGGL((fsk::zstd_entropy<false>), grid, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_execute<false>), grid, dim3(fsk::kZxThreads), 0, stream, blocks, sc, lay, out, status, tally);
+    }
+    return hipGetLastError();
+}
+
+extern "C" int fsk_zstd_frames_per_cu(void)
+{
+    int n = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, fsk::zstd_execute<false>, fsk::kZxThreads, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    return n;
+}

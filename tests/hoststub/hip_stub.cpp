@@ -513,3 +513,41 @@ extern "C" hipError_t fsk_lz4_decode(int kernel, const uint8_t* comp, const fsk:
     return hipSuccess;
 }
 extern "C" int fsk_lz4_blocks_per_cu(int) { return 2; }
+
+// ---- the GPU Zstandard decoder's launcher: the stand-in "kernels" are the image's libzstd (what the product's host
+// pipeline calls too, resolved at run time like there), on the stream's worker thread
+#include <dlfcn.h>
+
+#include "../../libflagstats_amd/csrc/flagstat_zstd_kernels.h"
+
+extern "C" uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes) { return 4096 + (static_cast<uint64_t>(max_dst_len) / 64 + 64) * nframes; }
+extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
+                                      unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int, hipStream_t stream)
+{
+    if (nblocks == 0) return hipSuccess;
+    if (!comp || !blocks || !out || !status || !tally || !scratch || scratch_bytes < fsk_zstd_scratch_bytes(max_dst_len, nblocks)) return hipErrorInvalidValue;
+    typedef size_t (*decompress_fn)(void*, size_t, const void*, size_t);
+    typedef unsigned (*is_error_fn)(size_t);
+    static void* handle = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
+    static decompress_fn decompress = handle ? reinterpret_cast<decompress_fn>(dlsym(handle, "ZSTD_decompress")) : nullptr;
+    static is_error_fn is_error = handle ? reinterpret_cast<is_error_fn>(dlsym(handle, "ZSTD_isError")) : nullptr;
+    if (!decompress || !is_error) return hipErrorInvalidValue;
+    enqueue(stream, [=] {
+        uint8_t* sc = static_cast<uint8_t*>(scratch);
+        for (uint32_t i = 0; i < nblocks; ++i) {
+            const fsk::GpuBlock b = blocks[i];
+            std::vector<uint8_t> tmp(b.dst_len + 64);
+            const size_t got = decompress(tmp.data(), b.dst_len, comp + b.src_off, b.src_len);
+            sc[i & 4095u] = static_cast<uint8_t>(i);  // (the scratch is written by the launch: a use-after-release shows under TSan)
+            if (!is_error(got) && got == b.dst_len) {
+                std::memcpy(out + b.dst_off, tmp.data(), b.dst_len & ~1u);
+                status[i] = 0;
+            } else {
+                status[i] = 5;
+            }
+            __atomic_fetch_add(&tally[0], 1ull, __ATOMIC_RELAXED);
+        }
+    });
+    return hipSuccess;
+}
+extern "C" int fsk_zstd_frames_per_cu(void) { return 2; }

@@ -1,0 +1,202 @@
+"""Zstandard block files decoded ON the GPU (libflagstats_amd/csrc/flagstat_zstd_kernels.hip; knob "zstd_decoder"): the
+product entries against the oracle and against the libzstd host pipeline, on the reference-written .zst goldens, on
+synthetic streams of every compressor level, on damaged and on unsupported-but-valid frames.
+The reference decodes every payload with ZSTD_decompress (benchmark/flagstats.cpp:636-682)."""
+import json
+import os
+import random
+import struct
+import sys
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+sys.path.insert(0, HERE)
+import blockfile_tool as bt  # noqa: E402
+from test_gpu_blockfile import expect  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(HERE, "golden", "blockfiles")
+
+
+@pytest.fixture
+def zgpu(hip):
+    """knob zstd_decoder = 1: every .zst block file goes through the GPU decoder whatever its size, and a frame it does not
+    take is an error (default 2: from zstd_gpu_min_bytes, anything it does not take goes to libzstd on the host)"""
+    assert hip.FLAGSTATS_hip_get(b"zstd_decoder") == 2
+    assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+    yield hip
+    assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 2) == 0
+
+
+def image_of(raw_blocks, level=1):
+    """block file image (benchmark/flagstats.cpp:192-226 layout) from a list of raw byte blocks"""
+    out = bytearray()
+    for raw in raw_blocks:
+        comp = bt.compress_block(raw, "zstd", level)
+        out += struct.pack("<ii", len(raw), len(comp)) + comp
+    return bytes(out)
+
+
+def expect_blocks(raw_blocks):
+    import oracle
+    out = np.zeros(32, dtype=np.uint64)
+    for raw in raw_blocks:
+        k = len(raw) >> 1
+        out += oracle.flagstat_hist(np.frombuffer(raw[:2 * k], dtype=np.uint16))
+    return out
+
+
+def test_reference_written_zstd_files_on_the_gpu_decoder(zgpu):
+    from libflagstats_amd import blockfile
+    manifest = json.load(open(os.path.join(GOLD, "manifest.json")))
+    names = [k for k, e in manifest["files"].items() if e.get("codec") == "zstd"]
+    assert len(names) >= 3
+    for name in names:
+        e = manifest["files"][name]
+        path = os.path.join(GOLD, name)
+        want = np.array(e["scalar_counters"], dtype=np.uint64)
+        got, st = blockfile.flagstat_zstd_file(path, threads=2)
+        assert st["gpu_decode"] == 1 and st["n_flags"] == e["n_flags"]
+        assert zgpu.FLAGSTATS_hip_set(b"zstd_decoder", 0) == 0
+        host, st0 = blockfile.flagstat_zstd_file(path, threads=2)
+        assert zgpu.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+        assert st0["gpu_decode"] == 0 and np.array_equal(got, host), name
+        assert np.array_equal(got[:len(want)], want), name
+        img, _ = blockfile.flagstat_zstd_image(open(path, "rb").read(), threads=2)
+        assert np.array_equal(img, host)
+
+
+@pytest.mark.parametrize("level", [1, 3, 9, 19, -5])
+def test_block_file_entries_with_the_gpu_zstd_decoder(zgpu, tmp_path, level):
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_NA12878, 30 + abs(level), 1, 0, 512000 * 3 + 12345)
+    path = tmp_path / "na.zst"
+    size = bt.write_block_file(path, flags, mode="zstd", level=level)
+    want, n = expect(flags, bt.BLOCK_BYTES)
+    for threads in (1, 0):
+        got, st = blockfile.flagstat_zstd_file(str(path), threads)
+        assert np.array_equal(got, want), (level, threads)
+        assert st["n_flags"] == n and st["compressed_bytes"] == size and st["gpu_decode"] == 1
+    got, st = blockfile.flagstat_zstd_image(open(path, "rb").read(), 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 1
+    sup_gpu, st = blockfile.flagstat_file(str(path), 2, superset=True)
+    assert st["gpu_decode"] == 1
+    assert zgpu.FLAGSTATS_hip_set(b"zstd_decoder", 0) == 0
+    sup_host, st = blockfile.flagstat_file(str(path), 2, superset=True)
+    assert zgpu.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+    assert st["gpu_decode"] == 0 and np.array_equal(sup_gpu, sup_host)
+
+
+def synthetic_blocks(seed):
+    import oracle
+    r = np.random.default_rng(seed)
+    a = r.integers(0, 256, 40000, dtype=np.uint8).tobytes()
+    return [
+        b"", b"ab", bytes(1000), bytes(300000), r.integers(0, 256, 300, dtype=np.uint8).tobytes(),
+        r.integers(0, 256, 200000, dtype=np.uint8).tobytes(),                      # raw blocks
+        b"hello world, " * 3000,
+        oracle.generate(oracle.GEN_NA12878, seed, 1, 0, 700000).tobytes(),          # eleven blocks: two passes of the entropy kernel
+        r.integers(0, 4, 300000, dtype=np.uint8).tobytes(),                         # literal-heavy: four Huffman streams a block
+        r.integers(0, 60, 200000, dtype=np.uint8).tobytes(),
+        r.integers(0, 3000, 100000, dtype=np.uint16).tobytes(),
+        a + bytes(50000) + a + r.integers(0, 256, 20000, dtype=np.uint8).tobytes() + a[:30000] + bytes(100000),   # runs above 16,383, far matches
+        (r.integers(0, 256, 17000, dtype=np.uint8).tobytes() + b"x" * 17000) * 12,
+        oracle.generate(oracle.GEN_UNIFORM, seed, 0x0FFF, 0, 512000).tobytes(),
+    ]
+
+
+@pytest.mark.parametrize("level", [1, 5, 12, 19, -5])
+def test_gpu_zstd_decoder_on_synthetic_streams(zgpu, level):
+    from libflagstats_amd import blockfile
+    blocks = synthetic_blocks(100 + abs(level))
+    img = image_of(blocks, level)
+    got, st = blockfile.flagstat_zstd_image(img, 2)
+    assert st["gpu_decode"] == 1 and st["n_blocks"] == len(blocks)
+    assert np.array_equal(got, expect_blocks(blocks)), level
+    # every block on its own as well (a wrong block shows up by name)
+    for i, raw in enumerate(blocks):
+        got, _ = blockfile.flagstat_zstd_image(image_of([raw], level), 2)
+        assert np.array_equal(got, expect_blocks([raw])), (level, i)
+
+
+def test_gpu_zstd_decoder_is_chosen_by_size_and_rejects_loudly(zgpu, tmp_path):
+    import oracle
+    from libflagstats_amd import _lib, blockfile
+    hip = zgpu
+    flags = oracle.generate(oracle.GEN_NA12878, 21, 1, 0, 512000 * 2 + 100)
+    img = bt.block_file_image(flags, mode="zstd", level=1)
+    want = expect(flags, bt.BLOCK_BYTES)[0]
+    assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 2) == 0
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", len(img) + 1) == 0
+    got, st = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 0
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", len(img)) == 0
+    got, st = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 1
+    # a damaged payload: by size the file goes to libzstd, whose verdict counts; forced, the GPU decoder's code is the error
+    bad = bytearray(img)
+    bad[8 + 40] ^= 0x55
+    bad[8 + 41] ^= 0xAA
+    with pytest.raises(_lib.FlagstatsHipError):
+        blockfile.flagstat_zstd_image(bytes(bad), 2)
+    assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+    with pytest.raises(_lib.FlagstatsHipError):
+        blockfile.flagstat_zstd_image(bytes(bad), 2)
+    assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 3) != 0
+    for cut in (3, 8 + 10, len(img) - 1):
+        with pytest.raises(_lib.FlagstatsHipError):
+            blockfile.flagstat_zstd_image(img[:cut], 2)
+    # valid Zstandard the GPU decoder does not take -- two frames in one payload: forced it is an error, by size libzstd decodes it
+    raw = flags.tobytes()[:200000]
+    two = bt.compress_block(raw[:100000], "zstd", 1) + bt.compress_block(raw[100000:], "zstd", 1)
+    img2 = struct.pack("<ii", len(raw), len(two)) + two
+    with pytest.raises(_lib.FlagstatsHipError):
+        blockfile.flagstat_zstd_image(img2, 2)
+    assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 2) == 0
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 1) == 0
+    got, st = blockfile.flagstat_zstd_image(img2, 2)
+    assert st["gpu_decode"] == 0 and np.array_equal(got, expect_blocks([raw]))
+    got, st = blockfile.flagstat_zstd_image(img, 2)
+    assert st["gpu_decode"] == 1 and np.array_equal(got, want)
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 4 << 20) == 0
+    assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+
+
+def test_gpu_zstd_decoder_and_libzstd_agree_on_damaged_frames(zgpu):
+    """Bit flips in the payloads: the GPU decoder may be stricter than libzstd, never more lenient, and what both accept
+    counts the same."""
+    import oracle
+    from libflagstats_amd import _lib, blockfile
+    hip = zgpu
+    rng = random.Random(11)
+    raw = oracle.generate(oracle.GEN_NA12878, 5, 1, 0, 60000).tobytes()
+    strict = agree = 0
+    for level in (1, 19):
+        comp = bt.compress_block(raw, "zstd", level)
+        for _ in range(40):
+            bad = bytearray(comp)
+            for _ in range(rng.randrange(1, 4)):
+                bad[rng.randrange(len(bad))] ^= 1 << rng.randrange(8)
+            img = struct.pack("<ii", len(raw), len(bad)) + bytes(bad)
+            assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 0) == 0
+            try:
+                host, _ = blockfile.flagstat_zstd_image(img, 1)
+            except _lib.FlagstatsHipError:
+                host = None
+            assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+            try:
+                gpu, _ = blockfile.flagstat_zstd_image(img, 1)
+            except _lib.FlagstatsHipError:
+                gpu = None
+            if host is None:
+                assert gpu is None
+            elif gpu is None:
+                strict += 1
+            else:
+                assert np.array_equal(gpu, host)
+                agree += 1
+    assert agree > 10 and strict < 20
