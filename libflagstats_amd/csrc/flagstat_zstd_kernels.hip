@@ -66,7 +66,8 @@ constexpr uint32_t kBlockMax = 1u << 17;
 
 // ------------------------------------------------------------------------------------------------ zstd_entropy
 constexpr uint32_t kZeLanes = 8;          // blocks of a frame decoded side by side
-constexpr uint32_t kZeRing = 1024, kZeChunk = 256;
+constexpr uint32_t kZeRing = 512, kZeChunk = 128;   // bytes of a block's sequence bit stream staged in LDS, bytes a refill
+constexpr uint32_t kZeRound = 64;                    // steps of the serial chain between two vector passes
 
 __device__ const uint32_t kLLBase[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
 __device__ const uint8_t kLLBits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
@@ -96,10 +97,18 @@ struct ZeShare {  // what a lane tells the others about its block
 struct __attribute__((aligned(16))) ZeLds {
     ZeTables tab[kZeLanes];
     uint8_t ring[kZeLanes][kZeRing + 16];
-    uint8_t weights[kZeLanes][256];
-    int16_t counts[kZeLanes][64];
-    uint32_t rank[kZeLanes][16];
-    uint32_t ll_base[36], ml_base[53];  // (in LDS: a global load in the sequence loop would wait for the record stores before it)
+    union {
+        struct {  // while the tables are built
+            uint8_t weights[kZeLanes][256];
+            int16_t counts[kZeLanes][64];
+            uint32_t rank[kZeLanes][16];
+        };
+        struct {  // while the sequences are decoded: what the serial chain leaves for the vector pass, per block and step
+            uint32_t stash_code[kZeLanes][kZeRound];  // literal length code | match length code << 6 | offset code << 12
+            uint32_t stash_lo[kZeLanes][kZeRound], stash_hi[kZeLanes][kZeRound];  // the window whose top bits are the codes' extra bits
+        };
+    };
+    uint32_t ll_base[36], ml_base[53];  // value | extra bits << 24 (in LDS: a global load in the sequence loop would wait for the record stores)
     ZeShare sh[kZeLanes];
 };
 constexpr uint32_t kNone = ~0u, kRepeat = ~1u;
@@ -358,13 +367,13 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
     uint64_t* const recs = reinterpret_cast<uint64_t*>(scratch + lay.rec_at) + static_cast<uint64_t>(fi) * lay.rec_stride;
     uint8_t* const lits = scratch + lay.lit_at + static_cast<uint64_t>(fi) * lay.lit_stride;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long t_lit = 0, t_tab = 0, t_seq = 0;
+    unsigned long long t_lit = 0, t_tab = 0, t_seq = 0, t_chain = 0, t_vec = 0, n_refill = 0, t_v1 = 0, t_v2 = 0, t_v3 = 0, n_rep = 0;
     uint32_t err = 0;
     auto fail = [&](uint32_t code) {
         if (!err) err = code;
     };
-    if (lane < 36u) L.ll_base[lane] = kLLBase[lane];
-    if (lane < 53u) L.ml_base[lane] = kMLBase[lane];
+    if (lane < 36u) L.ll_base[lane] = kLLBase[lane] | (static_cast<uint32_t>(kLLBits[lane]) << 24);
+    if (lane < 53u) L.ml_base[lane] = kMLBase[lane] | (static_cast<uint32_t>(kMLBits[lane]) << 24);
     // ---- frame header (uniform)
     uint32_t p = 0;
     if (dst_len > kZstdMaxFrameBytes || n >= (1u << 27))
@@ -714,7 +723,7 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
         if (PROF) t_tab += __builtin_readcyclecounter() - t1;
         const unsigned long long t2 = PROF ? __builtin_readcyclecounter() : 0ull;
         // the bit stream ring of a lane holds frame bytes [rlo, rlo + kZeRing) at index (byte & (kZeRing - 1)), its first 16
-        // bytes once more behind its end; refills go downwards, 256 bytes at a time, by the whole wave
+        // bytes once more behind its end; refills go downwards, 128 bytes at a time, by the wave
         int32_t pos = seq_act ? static_cast<int32_t>(8u * (bend - 1u) + highbit(frame[bend - 1u])) : 0;
         const int32_t start_bit = static_cast<int32_t>(8u * bits_at);
         int32_t rlo = seq_act ? ((pos >> 3) & ~static_cast<int32_t>(kZeChunk - 1u)) + static_cast<int32_t>(kZeChunk) : 0;
@@ -727,6 +736,7 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
                 m &= m - 1ull;
                 const int32_t nlo = __builtin_amdgcn_readlane(rlo, j) - static_cast<int32_t>(kZeChunk);
                 // (never below the buffer, never beyond the 64 readable bytes behind the payload: what lies there is never used)
+                if (lane >= kZeChunk / 4u) continue;
                 int32_t rel = nlo + 4 * static_cast<int32_t>(lane);
                 if (rel > static_cast<int32_t>(n) + 56) rel = static_cast<int32_t>(n) + 56;
                 const int64_t src = static_cast<int64_t>(gb.src_off) + rel;
@@ -760,141 +770,256 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
                 seq_act = false;
             }
         }
-        uint32_t r0 = 0, r1 = 0, r2 = 0, known = 0;          // this block's view of the offset history; bit i of known: slot i holds a value
+        // What the whole wave needs of a block lives in the block's own lane and is read with readlane: the offset history as
+        // this block knows it (bit i of known: slot i holds a value), records written, output and literal bytes so far.
+        uint32_t r0 = 0, r1 = 0, r2 = 0, known = 0;
         uint32_t nrec = 0, out = 0, lit_pos = 0, n_sym = 0;
-        bool all_known = false;
-        uint64_t* const myrec = recs + rec_at;
-        auto put = [&](uint32_t w0, uint32_t ll, uint32_t ml) {
-            if ((nrec & 63u) == 0u && nrec < rec_cap) ck[(rec_at + nrec) >> 6] = make_uint4(out, lit_pos, 0u, 0u);
-            if (nrec < rec_cap) myrec[nrec] = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(ll | (ml << 14)) << 32);
-            ++nrec;
-            out += ll + ml;
-            lit_pos += ll;
+        // one record, written by lane 0 (arguments uniform): block `j`'s counters come in and go back through its lane
+        auto put_uniform = [&](uint32_t j, uint32_t w0, uint32_t ll, uint32_t ml) {
+            const uint32_t b_at = __builtin_amdgcn_readlane(rec_at, j), b_cap = __builtin_amdgcn_readlane(rec_cap, j);
+            const uint32_t b_n = __builtin_amdgcn_readlane(nrec, j), b_out = __builtin_amdgcn_readlane(out, j), b_lit = __builtin_amdgcn_readlane(lit_pos, j);
+            if (lane == 0u && b_n < b_cap) {
+                if ((b_n & 63u) == 0u) ck[(b_at + b_n) >> 6] = make_uint4(b_out, b_lit, 0u, 0u);
+                recs[b_at + b_n] = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(ll | (ml << 14)) << 32);
+            }
+            if (lane == j) {
+                nrec = b_n + 1u;
+                out = b_out + ll + ml;
+                lit_pos = b_lit + ll;
+            }
         };
-        auto literal_run = [&](uint32_t count) {
+        auto literal_run_uniform = [&](uint32_t j, uint32_t count) {
             while (count) {
                 const uint32_t piece = count < kRecLL ? count : kRecLL;
-                put(kRecFlag, piece, 0u);
+                put_uniform(j, kRecFlag, piece, 0u);
                 count -= piece;
             }
         };
         const ZeTables& T = L.tab[lane & (kZeLanes - 1u)];
+        const uint32_t home = lane & (kZeLanes - 1u);
         uint32_t i = 0;
         while (__builtin_amdgcn_ballot_w64(seq_act && i < nseq)) {
-            const bool step = seq_act && i < nseq;
-            // (a lane whose window is about to run out of staged bytes asks for a chunk; the whole wave copies)
-            if (__builtin_amdgcn_ballot_w64(step && (pos >> 3) - rlo < 48)) refill(step && (pos >> 3) - rlo < 512);
-            if (step) {
-                const uint32_t el = T.fse.ll[sl & 511u], eo = T.fse.of[so & 255u], em = T.fse.ml[sm & 511u];
-                uint64_t hi, lo;
-                window(hi, lo);
-                const uint32_t oc = (eo >> 10) & 31u, mlb = (em >> 10) & 31u, llb = (el >> 10) & 31u;
-                const bool lastseq = i + 1u == nseq;
-                const uint32_t nbl = lastseq ? 0u : (el >> 6) & 15u, nbm = lastseq ? 0u : (em >> 6) & 15u, nbo = lastseq ? 0u : (eo >> 6) & 15u;
-                const uint32_t ext = oc + mlb + llb;
-                const uint32_t t = (static_cast<uint32_t>(pos) & 7u) + 120u;
-                uint64_t w1 = top64(hi, lo, t);
-                const uint32_t obits = take(w1, oc), mbits = take(w1, mlb), lbits = take(w1, llb);
-                uint64_t w2 = top64(hi, lo, t - ext);
-                const uint32_t bl = take(w2, nbl), bm = take(w2, nbm), bo = take(w2, nbo);
-                pos -= static_cast<int32_t>(ext + nbl + nbm + nbo);
-                sl = (el >> 16) + bl;
-                sm = (em >> 16) + bm;
-                so = (eo >> 16) + bo;
-                const uint32_t lsym = el & 63u, msym = em & 63u;
+            const uint32_t i_before = i;
+            const unsigned long long ta = PROF ? __builtin_readcyclecounter() : 0ull;
+            // ---- A: the serial chain of every block, up to kZeRound steps: three states -> three entries and the window
+            // (ONE LDS round trip) -> the bits of the next states.  Nothing else: the codes and the window go to the stash.
+            for (uint32_t s0 = 0; s0 < kZeRound; s0 += 4u) {
+                if (!__builtin_amdgcn_ballot_w64(seq_act && i < nseq)) break;
+                // (a lane whose window would run out of staged bytes within four steps asks for a chunk; the wave copies)
+                if (__builtin_amdgcn_ballot_w64(seq_act && i < nseq && (pos >> 3) - rlo < 80)) {
+                    if (PROF) ++n_refill;
+                    refill(seq_act && i < nseq && (pos >> 3) - rlo < static_cast<int32_t>(kZeRing / 2u));
+                }
+#pragma unroll
+                for (uint32_t u = 0; u < 4u; ++u) {
+                    const uint32_t s = s0 + u;
+                    const bool step = seq_act && i < nseq;
+                    const uint32_t el = T.fse.ll[sl & 511u], eo = T.fse.of[so & 255u], em = T.fse.ml[sm & 511u];
+                    // the window: 16 bytes that end with the byte the position falls into, as four dwords; t = sh + 120 of its bits are unread
+                    uint32_t d[4];
+                    {
+                        const uint32_t ri = static_cast<uint32_t>((pos >> 3) - 15) & (kZeRing - 1u);
+                        __builtin_memcpy(d, &L.ring[home][ri], 16);
+                    }
+                    const uint32_t oc = (eo >> 10) & 31u, mlb = (em >> 10) & 31u, llb = (el >> 10) & 31u;
+                    const bool lastseq = i + 1u == nseq;
+                    const uint32_t nbl = lastseq ? 0u : (el >> 6) & 15u, nbm = lastseq ? 0u : (em >> 6) & 15u, nbo = lastseq ? 0u : (eo >> 6) & 15u;
+                    const uint32_t ext = oc + mlb + llb;
+                    const uint32_t sh = static_cast<uint32_t>(pos) & 7u;
+                    // bits [t - 64, t): the extra bits of the three codes lead them (for the vector pass)
+                    const uint32_t w1lo = __builtin_amdgcn_alignbit(d[2], d[1], sh + 24u), w1hi = __builtin_amdgcn_alignbit(d[3], d[2], sh + 24u);
+                    // the state bits follow the extra bits: the 32 bits of the window below bit t - ext (<= 26 are used)
+                    const uint32_t f = sh + 88u - ext;   // t - ext - 32: 25..95
+                    const uint32_t fk = f >> 5;
+                    const uint32_t x_lo = fk == 0u ? d[0] : (fk == 1u ? d[1] : d[2]), x_hi = fk == 0u ? d[1] : (fk == 1u ? d[2] : d[3]);
+                    uint32_t x = __builtin_amdgcn_alignbit(x_hi, x_lo, f & 31u);
+                    const uint32_t bl = __builtin_amdgcn_ubfe(x, 32u - nbl, nbl);
+                    x <<= nbl;
+                    const uint32_t bm = __builtin_amdgcn_ubfe(x, 32u - nbm, nbm);
+                    x <<= nbm;
+                    const uint32_t bo = __builtin_amdgcn_ubfe(x, 32u - nbo, nbo);
+                    if (step) {
+                        L.stash_code[home][s] = (el & 63u) | ((em & 63u) << 6) | (oc << 12);
+                        L.stash_lo[home][s] = w1lo;
+                        L.stash_hi[home][s] = w1hi;
+                        sl = (el >> 16) + bl;
+                        sm = (em >> 16) + bm;
+                        so = (eo >> 16) + bo;
+                        pos -= static_cast<int32_t>(ext + nbl + nbm + nbo);
+                        ++i;
+                        if (pos < start_bit) {
+                            lerr = kZstdBadBitstream;
+                            seq_act = false;
+                        }
+                    }
+                }
+            }
+            const uint32_t cnt = i - i_before;
+            __syncthreads();
+            const unsigned long long tb = PROF ? __builtin_readcyclecounter() : 0ull;
+            if (PROF) t_chain += tb - ta;
+            // ---- B: what the chain left behind, block after block, a lane per sequence: values of the codes, positions by
+            // prefix sums, repeat offsets (a scalar walk over the few lanes that have one), records and checkpoints
+            for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t nq = __builtin_amdgcn_readlane(cnt, j);
+                if (!nq) continue;
+                const bool valid = lane < nq;
+                const unsigned long long tv0 = PROF ? __builtin_readcyclecounter() : 0ull;
+                const uint32_t code = L.stash_code[j][lane], wlo = L.stash_lo[j][lane], whi = L.stash_hi[j][lane];
+                const uint32_t lsym = code & 63u, msym = (code >> 6) & 63u, oc = code >> 12;
+                const uint32_t lle = L.ll_base[lsym < 36u ? lsym : 35u], mle = L.ml_base[msym < 53u ? msym : 52u];   // value | extra bits << 24
+                uint64_t w = (static_cast<uint64_t>(whi) << 32) | wlo;
+                const uint32_t obits = take(w, oc), mbits = take(w, mle >> 24), lbits = take(w, lle >> 24);
                 const uint32_t ofv = (1u << oc) + obits;
-                uint32_t mlv = L.ml_base[msym < 53u ? msym : 52u] + mbits;
-                uint32_t llv = L.ll_base[lsym < 36u ? lsym : 35u] + lbits;
-                if (oc > 26u)
-                    lerr = kZstdBadOffset;
-                else if (pos < start_bit)
-                    lerr = kZstdBadBitstream;
-                else if (lit_pos + llv > nlit)
-                    lerr = kZstdBadLiterals;
-                else if (out + llv + mlv > kBlockMax)
-                    lerr = kZstdBadSize;
-                if (lerr) {
-                    seq_act = false;
+                const uint32_t mlv = valid ? (mle & 0xFFFFFFu) + mbits : 0u, llv = valid ? (lle & 0xFFFFFFu) + lbits : 0u;
+                const uint32_t lincl = wave_scan_add(llv), oincl = wave_scan_add(llv + mlv);
+                const uint32_t b_lit = __builtin_amdgcn_readlane(lit_pos, j), b_out = __builtin_amdgcn_readlane(out, j);
+                const uint32_t b_nlit = __builtin_amdgcn_readlane(nlit, j), b_n = __builtin_amdgcn_readlane(nrec, j);
+                const uint32_t my_lit = b_lit + lincl - llv, my_out = b_out + oincl - llv - mlv;
+                const uint32_t lit_all = __builtin_amdgcn_readlane(lincl, 63), out_all = __builtin_amdgcn_readlane(oincl, 63);
+                uint32_t berr = 0;
+                if (__builtin_amdgcn_ballot_w64(valid && oc > 26u))
+                    berr = kZstdBadOffset;
+                else if (b_lit + lit_all > b_nlit)
+                    berr = kZstdBadLiterals;
+                else if (b_out + out_all > kBlockMax)
+                    berr = kZstdBadSize;
+                if (berr) {
+                    if (lane == j) {
+                        lerr = berr;
+                        seq_act = false;
+                    }
+                    continue;
+                }
+                // repeat offsets (RFC 8878 3.1.1.5).  h0..h2 / kn: the history before lane `cur`; lanes between two repeat codes
+                // push their offsets; a repeat code met while a slot is still unknown stays in the record as it is (replayed below)
+                const bool isrep = valid && ofv <= 3u;
+                uint32_t w0 = ofv - 3u;
+                uint32_t h0 = __builtin_amdgcn_readlane(r0, j), h1 = __builtin_amdgcn_readlane(r1, j), h2 = __builtin_amdgcn_readlane(r2, j);
+                uint32_t kn = __builtin_amdgcn_readlane(known, j), sym_end = __builtin_amdgcn_readlane(n_sym, j);
+                uint32_t cur = 0;
+                auto push_to = [&](uint32_t upto) {   // lanes [cur, upto) hold plain offsets: the last three of them enter the history
+                    const uint32_t k = upto - cur;
+                    const uint32_t p1 = __builtin_amdgcn_readlane(w0, (upto - 1u) & 63u), p2 = __builtin_amdgcn_readlane(w0, (upto - 2u) & 63u);
+                    const uint32_t p3 = __builtin_amdgcn_readlane(w0, (upto - 3u) & 63u);
+                    const uint32_t n0 = k >= 1u ? p1 : h0;
+                    const uint32_t n1 = k >= 2u ? p2 : (k == 1u ? h0 : h1);
+                    const uint32_t n2 = k >= 3u ? p3 : (k == 2u ? h0 : (k == 1u ? h1 : h2));
+                    kn = k >= 3u ? 7u : ((kn << k) | ((1u << k) - 1u)) & 7u;
+                    h0 = n0;
+                    h1 = n1;
+                    h2 = n2;
+                };
+                uint64_t repm = __builtin_amdgcn_ballot_w64(isrep);
+                const unsigned long long tv1 = PROF ? __builtin_readcyclecounter() : 0ull;
+                if (PROF) {
+                    t_v1 += tv1 - tv0;
+                    n_rep += static_cast<unsigned long long>(__builtin_popcountll(repm));
+                }
+                while (repm) {
+                    const uint32_t b = static_cast<uint32_t>(__builtin_ctzll(repm));
+                    repm &= repm - 1ull;
+                    push_to(b);
+                    const bool resolved = kn == 7u;
+                    const uint32_t rcode = __builtin_amdgcn_readlane(ofv, b);
+                    const bool ll0 = __builtin_amdgcn_readlane(llv, b) == 0u;
+                    const uint32_t idx = rcode - 1u + (ll0 ? 1u : 0u);   // 0..3
+                    const uint32_t o = idx == 0u ? h0 : (idx == 1u ? h1 : (idx == 2u ? h2 : h0 - 1u));
+                    const uint32_t k0 = kn & 1u, k1 = (kn >> 1) & 1u, k2 = (kn >> 2) & 1u;
+                    const uint32_t ko = idx == 1u ? k1 : (idx == 2u ? k2 : k0);
+                    const uint32_t t1 = idx == 0u ? h1 : h0, t2 = idx <= 1u ? h2 : h1;
+                    kn = ko | ((idx == 0u ? k1 : k0) << 1) | ((idx <= 1u ? k2 : k1) << 2);
+                    h0 = o;
+                    h1 = t1;
+                    h2 = t2;
+                    if (resolved && o == 0u) berr = kZstdBadOffset;
+                    const uint32_t v = resolved ? (o & 0x3FFFFFFFu) : (kRecRep | (ll0 ? kRecFlag : 0u) | rcode);
+                    sym_end = resolved ? sym_end : b_n + b + 1u;   // (with runs split below the index moves: the slow path sets it again)
+                    w0 = lane == b ? v : w0;
+                    cur = b + 1u;
+                }
+                push_to(nq);
+                const unsigned long long tv2 = PROF ? __builtin_readcyclecounter() : 0ull;
+                if (PROF) t_v2 += tv2 - tv1;
+                if (berr) {
+                    if (lane == j) {
+                        lerr = berr;
+                        seq_act = false;
+                    }
+                    continue;
+                }
+                if (__builtin_expect(__builtin_amdgcn_ballot_w64(valid && (llv > kRecLL || mlv > kRecML)) == 0ull, 1)) {
+                    // one record per sequence
+                    const uint32_t b_at = __builtin_amdgcn_readlane(rec_at, j), b_cap = __builtin_amdgcn_readlane(rec_cap, j);
+                    const uint32_t ridx = b_n + lane;
+                    if (valid && ridx < b_cap) {
+                        if ((ridx & 63u) == 0u) ck[(b_at + ridx) >> 6] = make_uint4(my_out, my_lit, 0u, 0u);
+                        recs[b_at + ridx] = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(llv | (mlv << 14)) << 32);
+                    }
+                    if (lane == j) {
+                        nrec = b_n + nq;
+                        out = b_out + out_all;
+                        lit_pos = b_lit + lit_all;
+                    }
                 } else {
-                    // repeat offsets (RFC 8878 3.1.1.5); the history may still hold slots this block does not know
-                    uint32_t w0;
-                    if (ofv > 3u) {
-                        r2 = r1;
-                        r1 = r0;
-                        r0 = ofv - 3u;
-                        known = ((known << 1) | 1u) & 7u;
-                        w0 = r0;
-                    } else {
-                        const uint32_t idx = ofv - 1u + (llv == 0u ? 1u : 0u);
-                        uint32_t off;
-                        if (idx == 0u) {
-                            off = r0;
-                        } else if (idx == 1u) {
-                            off = r1;
-                            r1 = r0;
-                            r0 = off;
-                            known = (known & 4u) | ((known & 1u) << 1) | ((known >> 1) & 1u);
-                        } else if (idx == 2u) {
-                            off = r2;
-                            r2 = r1;
-                            r1 = r0;
-                            r0 = off;
-                            known = ((known << 1) & 6u) | ((known >> 2) & 1u);
-                        } else {
-                            off = r0 - 1u;
-                            r2 = r1;
-                            r1 = r0;
-                            r0 = off;
-                            known = ((known << 1) & 6u) | (known & 1u);
+                    // a run above 16,383 somewhere in the batch: record after record, the long ones in pieces
+                    for (uint32_t q = 0; q < nq; ++q) {
+                        uint32_t q_ll = __builtin_amdgcn_readlane(llv, q), q_ml = __builtin_amdgcn_readlane(mlv, q);
+                        const uint32_t q_w0 = __builtin_amdgcn_readlane(w0, q);
+                        while (q_ll > kRecLL) {
+                            put_uniform(j, kRecFlag, kRecLL, 0u);
+                            q_ll -= kRecLL;
                         }
-                        if (all_known) {
-                            if (off == 0u) {
-                                lerr = kZstdBadOffset;
-                                seq_act = false;
-                            }
-                            w0 = off & 0x3FFFFFFFu;
-                        } else {
-                            w0 = kRecRep | (llv == 0u ? kRecFlag : 0u) | ofv;
+                        uint32_t piece = q_ml < kRecML ? q_ml : kRecML;
+                        put_uniform(j, q_w0, q_ll, piece);
+                        q_ml -= piece;
+                        while (q_ml) {
+                            piece = q_ml < kRecML ? q_ml : kRecML;
+                            put_uniform(j, (q_w0 & kRecRep) ? (kRecRep | kRecFlag | 0x10u) : (q_w0 | kRecFlag), 0u, piece);
+                            q_ml -= piece;
+                        }
+                        if (q_w0 & kRecRep) sym_end = __builtin_amdgcn_readlane(nrec, j);
+                    }
+                }
+                if (lane == j) {
+                    r0 = h0;
+                    r1 = h1;
+                    r2 = h2;
+                    known = kn;
+                    n_sym = sym_end;
+                }
+                if (PROF) t_v3 += __builtin_readcyclecounter() - tv2;
+            }
+            __syncthreads();
+            if (PROF) t_vec += __builtin_readcyclecounter() - tb;
+        }
+        if (mine && my_type == 2u && nseq > 0u && !lerr && pos != start_bit) lerr = kZstdBadBitstream;
+        // what is left of every block: the literals behind its last sequence; raw and RLE blocks whole
+        if (!__builtin_amdgcn_ballot_w64(lerr != 0u)) {
+            for (uint32_t j = 0; j < nb; ++j) {
+                const uint32_t b_type = __builtin_amdgcn_readlane(my_type, j), b_size = __builtin_amdgcn_readlane(my_size, j);
+                if (b_type == 0u) {
+                    literal_run_uniform(j, b_size);
+                } else if (b_type == 1u) {
+                    if (b_size) {
+                        uint32_t left = b_size - 1u;
+                        uint32_t piece = left < kRecML ? left : kRecML;
+                        put_uniform(j, (piece ? 1u : 0u) | kRecFlag, 1u, piece);
+                        left -= piece;
+                        while (left) {
+                            piece = left < kRecML ? left : kRecML;
+                            put_uniform(j, 1u | kRecFlag, 0u, piece);
+                            left -= piece;
                         }
                     }
-                    while (llv > kRecLL) {
-                        put(kRecFlag, kRecLL, 0u);
-                        llv -= kRecLL;
-                    }
-                    uint32_t piece = mlv < kRecML ? mlv : kRecML;
-                    put(w0, llv, piece);
-                    mlv -= piece;
-                    while (mlv) {
-                        piece = mlv < kRecML ? mlv : kRecML;
-                        put((w0 & kRecRep) ? (kRecRep | kRecFlag | 0x10u) : (w0 | kRecFlag), 0u, piece);
-                        mlv -= piece;
-                    }
-                    if (!all_known && known == 7u) {
-                        all_known = true;
-                        n_sym = nrec;
-                    }
-                    ++i;
+                } else {
+                    literal_run_uniform(j, __builtin_amdgcn_readlane(nlit, j) - __builtin_amdgcn_readlane(lit_pos, j));
                 }
             }
         }
-        if (mine && my_type == 2u && nseq > 0u && !lerr && pos != start_bit) lerr = kZstdBadBitstream;
+        const bool all_known = known == 7u;
         if (mine && !lerr) {
-            if (my_type == 0u) {
-                literal_run(my_size);
-            } else if (my_type == 1u) {
-                if (my_size) {
-                    uint32_t left = my_size - 1u;
-                    uint32_t piece = left < kRecML ? left : kRecML;
-                    put((piece ? 1u : 0u) | kRecFlag, 1u, piece);
-                    left -= piece;
-                    while (left) {
-                        piece = left < kRecML ? left : kRecML;
-                        put(1u | kRecFlag, 0u, piece);
-                        left -= piece;
-                    }
-                }
-            } else {
-                literal_run(nlit - lit_pos);
+            if (my_type == 2u) {
                 if (!all_known) n_sym = nrec;
                 if (out > kBlockMax) lerr = kZstdBadSize;
             }
@@ -1006,6 +1131,13 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
             atomicAdd(&tally[18], t_lit);
             atomicAdd(&tally[19], t_tab);
             atomicAdd(&tally[20], t_seq);
+            atomicAdd(&tally[21], t_chain);
+            atomicAdd(&tally[22], t_vec);
+            atomicAdd(&tally[23], n_refill);
+            atomicAdd(&tally[24], t_v1);
+            atomicAdd(&tally[25], t_v2);
+            atomicAdd(&tally[26], t_v3);
+            atomicAdd(&tally[27], n_rep);
         }
     }
 }
