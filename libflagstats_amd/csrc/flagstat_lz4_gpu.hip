@@ -199,9 +199,11 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     if (ck) {
         npieces = static_cast<uint32_t>(std::atoi(ck));
     } else if (zstd) {
-        // Zstandard: 256 frames a piece (two launches fill the chip; the records, literals and checkpoints between the two
-        // kernels take 4 MB of scratch per frame and decode stream)
-        npieces = static_cast<uint32_t>((blocks.size() + 255) / 256);
+        // Zstandard: at most 1024 frames a piece, two pieces at least -- the chain kernel holds 1536 frames at a time and a
+        // frame takes ~8 ms through the four kernels whatever else runs, so few large launches, two of them in flight; the
+        // stash, records, literals and checkpoints between the kernels take 8.5 MB of scratch per frame and decode stream
+        npieces = static_cast<uint32_t>((blocks.size() + 1023) / 1024);
+        if (npieces < 2) npieces = 2;
     } else if (kernel == fsk::LZ4K_WORKGROUP) {
         uint64_t per = blocks.size() / 16;
         per = per < 256 ? 256 : (per > 512 ? 512 : per);
@@ -421,14 +423,15 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     LZG_TRY(hipEventElapsedTime(&pipe, e.lz4_ev[0], e.lz4_ev[2]));
     if (prof && zstd) {
         const double nb = static_cast<double>(blocks.size());
-        const int ne = 3, ns = 3;
-        std::fprintf(stderr, "zstd gpu profile: %d frame(s) per CU fit (execution kernel); cycles per frame: entropy wave %.3g (literals %.3g, tables %.3g, sequences %.3g) | "
+        const int ne = fsk::kZstdEmitters, ns = fsk::kZstdScanners;
+        std::fprintf(stderr, "zstd gpu profile: %d frame(s) per CU fit (execution kernel); cycles per frame: prepare %.3g (literals %.3g, tables %.3g) | "
+                             "chain %.3g per wave of two frames, %.0f steps a frame | records %.3g (%.1f relaxation rounds a batch) | "
                              "emit %.3g x %d (waiting %.1f %%), scan %.3g x %d (waiting %.1f %%), copy %.3g (waiting %.1f %%) | per frame: %.0f records, %.0f far matches, "
                              "%.0f batches in %.0f groups, %.0f chunks, %.1f %% with pointers inside (%.2f doubling rounds each)\n",
-                     fsk_zstd_frames_per_cu(), tally[17] / nb, tally[18] / nb, tally[19] / nb, tally[20] / nb, tally[15] / nb / ne, ne,
-                     100.0 * tally[16] / (tally[15] + 1e-9), tally[8] / nb / ns, ns, 100.0 * tally[9] / (tally[8] + 1e-9), tally[12] / nb,
-                     100.0 * tally[13] / (tally[12] + 1e-9), tally[0] / nb, tally[1] / nb, tally[5] / nb, tally[6] / nb, tally[14] / nb,
-                     100.0 * tally[11] / (tally[14] + 1e-9), tally[11] ? static_cast<double>(tally[10]) / tally[11] : 0.0);
+                     fsk_zstd_frames_per_cu(), tally[17] / nb, tally[18] / nb, tally[19] / nb, tally[20] / (tally[21] + 1e-9), tally[22] / nb, tally[23] / nb,
+                     tally[24] / (tally[25] + 1e-9), tally[15] / nb / ne, ne, 100.0 * tally[16] / (tally[15] + 1e-9), tally[8] / nb / ns, ns,
+                     100.0 * tally[9] / (tally[8] + 1e-9), tally[12] / nb, 100.0 * tally[13] / (tally[12] + 1e-9), tally[0] / nb, tally[1] / nb, tally[5] / nb,
+                     tally[6] / nb, tally[14] / nb, 100.0 * tally[11] / (tally[14] + 1e-9), tally[11] ? static_cast<double>(tally[10]) / tally[11] : 0.0);
     } else if (prof) {
         std::fprintf(stderr, "lz4 gpu profile: kernel %d, %d block(s) per CU fit\n", kernel, fsk_lz4_blocks_per_cu(kernel));
         if (kernel == fsk::LZ4K_WORKGROUP) {

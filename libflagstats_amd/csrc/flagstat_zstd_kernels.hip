@@ -37,8 +37,21 @@ namespace fsk {
 
 // ------------------------------------------------------------------------------------------------ scratch layout
 struct ZLayout {
-    uint64_t hdr_at, ck_at, rec_at, lit_at, total;
-    uint32_t rec_stride, ck_stride, lit_stride, nframes;
+    uint64_t hdr_at, blk_at, tab_at, ck_at, rec_at, lit_at, stash_at, total;
+    uint32_t rec_stride, ck_stride, lit_stride, blk_cap, nframes;
+};
+constexpr uint32_t kTabBytes = 3584;   // per block: chain entries LL 512 x 2, OF 256 x 2, ML 512 x 2; symbols LL 512, ML 512
+constexpr uint32_t kTabOF = 1024, kTabML = 1536, kTabSymLL = 2560, kTabSymML = 3072;
+struct ZFrameHdr {
+    uint32_t nslots, nrec, out_len, nblk;
+};
+struct ZBlk {  // one Zstandard block, between the kernels
+    uint32_t type, size, at;           // block type, size field, payload position in the frame
+    uint32_t nseq, nlit, lit_at;       // sequences; literals and where they start in the frame's literal buffer
+    uint32_t rec_at, rec_cap, stash_at;  // its records (a multiple of 64), its sequences in the stash
+    uint32_t bits_at, bend, logs;      // sequence bit stream [bits_at, bend); accuracy logs LL | OF << 8 | ML << 16
+    uint32_t chain_err;                // zstd_chain: 0 or a status code
+    uint32_t nrec, out_len, out_at, n_sym, hist_known, hist[3];   // zstd_records
 };
 static inline ZLayout zstd_layout(uint32_t max_dst_len, uint32_t nframes)
 {
@@ -47,27 +60,29 @@ static inline ZLayout zstd_layout(uint32_t max_dst_len, uint32_t nframes)
     y.rec_stride = ((max_dst_len / 3u + 64u) & ~63u) + 96u * kZstdMaxBlocks;
     y.ck_stride = y.rec_stride / 64u;
     y.lit_stride = (max_dst_len + 64u + 15u) & ~15u;
+    // blocks per frame the scratch holds tables for: twice what 128 KiB blocks need, and some (more: kZstdTooManyBlocks)
+    y.blk_cap = 2u * ((max_dst_len + 131071u) / 131072u) + 8u;
+    if (y.blk_cap > kZstdMaxBlocks) y.blk_cap = kZstdMaxBlocks;
     auto up = [](uint64_t v) { return (v + 255u) & ~255ull; };
+    const uint64_t nf = nframes;
     y.hdr_at = 0;
-    y.ck_at = up(static_cast<uint64_t>(nframes) * 16u);
-    y.rec_at = y.ck_at + up(static_cast<uint64_t>(nframes) * y.ck_stride * 16u);
-    y.lit_at = y.rec_at + up(static_cast<uint64_t>(nframes) * y.rec_stride * 8u);
-    y.total = y.lit_at + up(static_cast<uint64_t>(nframes) * y.lit_stride) + 256u;
+    y.blk_at = up(nf * sizeof(ZFrameHdr));
+    y.tab_at = y.blk_at + up(nf * y.blk_cap * sizeof(ZBlk));
+    y.ck_at = y.tab_at + up(nf * y.blk_cap * kTabBytes);
+    y.rec_at = y.ck_at + up(nf * y.ck_stride * 16u);
+    y.lit_at = y.rec_at + up(nf * y.rec_stride * 8u);
+    y.stash_at = y.lit_at + up(nf * y.lit_stride);
+    y.total = y.stash_at + up(nf * y.rec_stride * 12u) + 256u;
     return y;
 }
-struct ZFrameHdr {
-    uint32_t nslots, nrec, out_len, nblk;
-};
 
 constexpr uint32_t kRecLL = 16383u, kRecML = 16383u;   // longest runs of one record
 constexpr uint32_t kRecRep = 1u << 31;                  // word 0: a repeat code not resolved yet (low byte: the code; 0x10: "what the record before resolved to")
 constexpr uint32_t kRecFlag = 1u << 30;                 // word 0: with kRecRep, the sequence had no literals; without, the record does not enter the offset history
 constexpr uint32_t kBlockMax = 1u << 17;
 
-// ------------------------------------------------------------------------------------------------ zstd_entropy
-constexpr uint32_t kZeLanes = 8;          // blocks of a frame decoded side by side
-constexpr uint32_t kZeRing = 512, kZeChunk = 128;   // bytes of a block's sequence bit stream staged in LDS, bytes a refill
-constexpr uint32_t kZeRound = 64;                    // steps of the serial chain between two vector passes
+// ------------------------------------------------------------------------------------------------ zstd_prepare
+constexpr uint32_t kZeLanes = 8;          // blocks of a frame prepared side by side
 
 __device__ const uint32_t kLLBase[36] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16, 18, 20, 22, 24, 28, 32, 40, 48, 64, 128, 256, 512, 1024, 2048, 4096, 8192, 16384, 32768, 65536};
 __device__ const uint8_t kLLBits[36] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 3, 3, 4, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16};
@@ -92,23 +107,13 @@ struct ZeShare {  // what a lane tells the others about its block
     uint32_t def_tab[3];     // per table: ~0 leaves it as it is, ~1 repeats, else mode << 28 | position
     uint32_t type, size, at; // block type, size field, payload position
     uint32_t lit_type, nlit, lit_at, lit_data, lit_end, streams, max_bits, stream_at;
-    uint32_t rec_at, rec_cap, nrec, out_len, n_sym, hist_known, hist[3];
+    uint32_t rec_at, rec_cap;
 };
 struct __attribute__((aligned(16))) ZeLds {
     ZeTables tab[kZeLanes];
-    uint8_t ring[kZeLanes][kZeRing + 16];
-    union {
-        struct {  // while the tables are built
-            uint8_t weights[kZeLanes][256];
-            int16_t counts[kZeLanes][64];
-            uint32_t rank[kZeLanes][16];
-        };
-        struct {  // while the sequences are decoded: what the serial chain leaves for the vector pass, per block and step
-            uint32_t stash_code[kZeLanes][kZeRound];  // literal length code | match length code << 6 | offset code << 12
-            uint32_t stash_lo[kZeLanes][kZeRound], stash_hi[kZeLanes][kZeRound];  // the window whose top bits are the codes' extra bits
-        };
-    };
-    uint32_t ll_base[36], ml_base[53];  // value | extra bits << 24 (in LDS: a global load in the sequence loop would wait for the record stores)
+    uint8_t weights[kZeLanes][256];
+    int16_t counts[kZeLanes][64];
+    uint32_t rank[kZeLanes][16];
     ZeShare sh[kZeLanes];
 };
 constexpr uint32_t kNone = ~0u, kRepeat = ~1u;
@@ -353,7 +358,7 @@ __device__ uint32_t huf_build(const uint8_t* frame, uint32_t at, uint32_t limit,
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks, uint8_t* __restrict__ scratch,
+__global__ __launch_bounds__(64) void zstd_prepare(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks, uint8_t* __restrict__ scratch,
                                                    const ZLayout lay, uint32_t* __restrict__ status, unsigned long long* __restrict__ tally)
 {
     __shared__ ZeLds L;
@@ -363,17 +368,15 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
     const uint8_t* const frame = comp + gb.src_off;
     const uint32_t n = gb.src_len, dst_len = gb.dst_len;
     ZFrameHdr* const hdr = reinterpret_cast<ZFrameHdr*>(scratch + lay.hdr_at) + fi;
-    uint4* const ck = reinterpret_cast<uint4*>(scratch + lay.ck_at) + static_cast<uint64_t>(fi) * lay.ck_stride;
-    uint64_t* const recs = reinterpret_cast<uint64_t*>(scratch + lay.rec_at) + static_cast<uint64_t>(fi) * lay.rec_stride;
+    ZBlk* const blk = reinterpret_cast<ZBlk*>(scratch + lay.blk_at) + static_cast<uint64_t>(fi) * lay.blk_cap;
+    uint8_t* const tabs = scratch + lay.tab_at + static_cast<uint64_t>(fi) * lay.blk_cap * kTabBytes;
     uint8_t* const lits = scratch + lay.lit_at + static_cast<uint64_t>(fi) * lay.lit_stride;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long t_lit = 0, t_tab = 0, t_seq = 0, t_chain = 0, t_vec = 0, n_refill = 0, t_v1 = 0, t_v2 = 0, t_v3 = 0, n_rep = 0;
+    unsigned long long t_lit = 0, t_tab = 0;
     uint32_t err = 0;
     auto fail = [&](uint32_t code) {
         if (!err) err = code;
     };
-    if (lane < 36u) L.ll_base[lane] = kLLBase[lane] | (static_cast<uint32_t>(kLLBits[lane]) << 24);
-    if (lane < 53u) L.ml_base[lane] = kMLBase[lane] | (static_cast<uint32_t>(kMLBits[lane]) << 24);
     // ---- frame header (uniform)
     uint32_t p = 0;
     if (dst_len > kZstdMaxFrameBytes || n >= (1u << 27))
@@ -405,9 +408,8 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
             }
         }
     }
-    uint32_t hist0 = 1u, hist1 = 4u, hist2 = 8u;   // offset history at the start of the pass (uniform)
     uint32_t carry_huf = kNone, carry_tab[3] = {kNone, kNone, kNone};
-    uint32_t rec_top = 0, lit_top = 0, out_top = 0, nblk = 0, nrec_all = 0;
+    uint32_t rec_top = 0, lit_top = 0, seq_top = 0, nblk = 0;
     bool last = false;
     while (!last && !err) {
         // ---- block headers of this pass (uniform walk: a header gives the position of the next one)
@@ -434,7 +436,7 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
             }
             p = at + span;
             ++nb;
-            if (++nblk > kZstdMaxBlocks) {
+            if (++nblk > lay.blk_cap) {
                 fail(kZstdTooManyBlocks);
                 break;
             }
@@ -720,430 +722,591 @@ __global__ __launch_bounds__(64) void zstd_entropy(const uint8_t* __restrict__ c
                 seq_act = false;
             }
         }
+        // ---- the tables leave for the chain kernel (x = next-state number | extra bits << 10: the bits of the next state
+        // are log - highbit(x), its base (x << bits) - size) and for the records kernel (symbols)
+        if (seq_act) {
+            const ZeTables& T = L.tab[lane];
+            uint8_t* const tg = tabs + static_cast<uint64_t>(nblk - nb + lane) * kTabBytes;
+            uint16_t* const t16 = reinterpret_cast<uint16_t*>(tg);
+            auto emit = [&](const uint32_t* src, uint32_t size, uint32_t at16, uint32_t sym_at) {
+                _Pragma("unroll 1") for (uint32_t u = 0; u < size; ++u) {
+                    const uint32_t e = src[u];
+                    const uint32_t nbits = (e >> 6) & 15u;
+                    t16[at16 + u] = static_cast<uint16_t>((((e >> 16) + size) >> nbits) | (((e >> 10) & 31u) << 10));
+                    if (sym_at) tg[sym_at + u] = static_cast<uint8_t>(e & 63u);
+                }
+            };
+            emit(T.fse.ll, 1u << logl, 0u, kTabSymLL);
+            emit(T.fse.of, 1u << logo, kTabOF / 2u, 0u);
+            emit(T.fse.ml, 1u << logm, kTabML / 2u, kTabSymML);
+        }
         if (PROF) t_tab += __builtin_readcyclecounter() - t1;
-        const unsigned long long t2 = PROF ? __builtin_readcyclecounter() : 0ull;
-        // the bit stream ring of a lane holds frame bytes [rlo, rlo + kZeRing) at index (byte & (kZeRing - 1)), its first 16
-        // bytes once more behind its end; refills go downwards, 128 bytes at a time, by the wave
-        int32_t pos = seq_act ? static_cast<int32_t>(8u * (bend - 1u) + highbit(frame[bend - 1u])) : 0;
-        const int32_t start_bit = static_cast<int32_t>(8u * bits_at);
-        int32_t rlo = seq_act ? ((pos >> 3) & ~static_cast<int32_t>(kZeChunk - 1u)) + static_cast<int32_t>(kZeChunk) : 0;
-        auto refill = [&](bool want) {
-            // lanes that want a chunk and have room for it: the bytes it overwrites lie above the window
-            const bool can = want && ((pos >> 3) - (rlo - static_cast<int32_t>(kZeChunk)) <= static_cast<int32_t>(kZeRing) - 1);
-            uint64_t m = __builtin_amdgcn_ballot_w64(can) & 0xFFull;
+        if (__builtin_amdgcn_ballot_w64(lerr != 0u)) {
+            const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(__builtin_amdgcn_ballot_w64(lerr != 0u)));
+            fail(__builtin_amdgcn_readlane(lerr, first));
+            break;
+        }
+        // ---- the block's description
+        const uint32_t seq_incl = wave_scan_add(mine ? nseq : 0u);
+        if (mine) {
+            ZBlk d;
+            d.type = my_type;
+            d.size = my_size;
+            d.at = my_at;
+            d.nseq = nseq;
+            d.nlit = nlit;
+            d.lit_at = lit_at;
+            d.rec_at = rec_at;
+            d.rec_cap = rec_cap;
+            d.stash_at = seq_top + seq_incl - nseq;
+            d.bits_at = bits_at;
+            d.bend = bend;
+            d.logs = logl | (logo << 8) | (logm << 16);
+            d.chain_err = 0u;
+            d.nrec = 0u;
+            d.out_len = 0u;
+            d.out_at = 0u;
+            d.n_sym = 0u;
+            d.hist_known = 0u;
+            d.hist[0] = d.hist[1] = d.hist[2] = 0u;
+            blk[nblk - nb + lane] = d;
+        }
+        seq_top += __builtin_amdgcn_readlane(seq_incl, 63);
+        if (seq_top > lay.rec_stride) {
+            fail(kZstdBadSize);
+            break;
+        }
+        __syncthreads();
+    }
+    if (!err && p != n) fail(kZstdTrailingData);
+    if (lane == 0u) {
+        hdr->nslots = err ? 0u : rec_top >> 6;
+        hdr->nrec = 0u;
+        hdr->out_len = 0u;
+        hdr->nblk = err ? 0u : nblk;
+        status[fi] = err;
+        if (PROF) {
+            atomicAdd(&tally[17], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
+            atomicAdd(&tally[18], t_lit);
+            atomicAdd(&tally[19], t_tab);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ zstd_chain
+// The serial part of a block's sequences section and nothing else: three FSE states -> three table entries and the bit
+// window (ONE LDS round trip) -> the bits of the next states.  A wave costs the same with one lane or sixty-four, and a
+// block's chain tables take 2.5 KB of LDS, so a wave walks the blocks of TWO frames at once, a lane per block; what a step
+// saw (the three states, 64 bits of the window) goes to the stash in global memory for zstd_records.
+constexpr uint32_t kZcFrames = 2, kZcLanes = 8u * kZcFrames;
+constexpr uint32_t kZcRing = 512, kZcChunk = 128;   // bytes of a block's bit stream staged in LDS, bytes a refill
+
+struct __attribute__((aligned(16))) ZcLds {
+    uint16_t tab[kZcLanes][1280];          // LL 512, OF 256, ML 512 entries: next-state number | extra bits << 10
+    uint8_t ring[kZcLanes][kZcRing + 16];  // frame bytes [rlo, rlo + kZcRing) at index (byte & (kZcRing - 1)), the first 16 once more behind the end
+};
+
+template <bool PROF>
+__global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks, uint8_t* __restrict__ scratch,
+                                                 const ZLayout lay, const uint32_t* __restrict__ status, unsigned long long* __restrict__ tally)
+{
+    __shared__ ZcLds L;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t slot = lane >> 3, bk = lane & 7u;
+    const uint32_t fi = blockIdx.x * kZcFrames + slot;
+    const bool fact = lane < kZcLanes && fi < lay.nframes && status[fi] == 0u;
+    const GpuBlock gb = fact ? blocks[fi] : GpuBlock{0, 0, 0, 0};
+    const uint8_t* const frame = comp + gb.src_off;
+    const uint32_t n = gb.src_len;
+    ZBlk* const blk = reinterpret_cast<ZBlk*>(scratch + lay.blk_at) + static_cast<uint64_t>(fact ? fi : 0u) * lay.blk_cap;
+    const uint8_t* const tabs = scratch + lay.tab_at + static_cast<uint64_t>(fact ? fi : 0u) * lay.blk_cap * kTabBytes;
+    uint32_t* const stash = reinterpret_cast<uint32_t*>(scratch + lay.stash_at) + static_cast<uint64_t>(fact ? fi : 0u) * lay.rec_stride * 3u;
+    const uint32_t nblk = fact ? reinterpret_cast<const ZFrameHdr*>(scratch + lay.hdr_at)[fi].nblk : 0u;
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long n_steps = 0;
+    // passes of eight blocks per frame, as many as the frame with the most blocks needs
+    uint32_t passes = (nblk + 7u) >> 3;
+    passes = __builtin_amdgcn_readlane(wave_scan_max(passes), 63);
+    for (uint32_t pass = 0; pass < passes; ++pass) {
+        const uint32_t b = pass * 8u + bk;
+        const bool have = fact && b < nblk;
+        const ZBlk d = have ? blk[b] : ZBlk{};
+        bool act = have && d.type == 2u && d.nseq > 0u;
+        const uint32_t nseq = act ? d.nseq : 0u;
+        const uint32_t logl = d.logs & 255u, logo = (d.logs >> 8) & 255u, logm = (d.logs >> 16) & 255u;
+        // ---- the chain tables of the active blocks: global -> LDS, the whole wave, block after block
+        {
+            uint64_t m = __builtin_amdgcn_ballot_w64(act);
             while (m) {
                 const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(m));
                 m &= m - 1ull;
-                const int32_t nlo = __builtin_amdgcn_readlane(rlo, j) - static_cast<int32_t>(kZeChunk);
-                // (never below the buffer, never beyond the 64 readable bytes behind the payload: what lies there is never used)
-                if (lane >= kZeChunk / 4u) continue;
-                int32_t rel = nlo + 4 * static_cast<int32_t>(lane);
-                if (rel > static_cast<int32_t>(n) + 56) rel = static_cast<int32_t>(n) + 56;
-                const int64_t src = static_cast<int64_t>(gb.src_off) + rel;
-                const uint32_t v = ld_le32(comp + (src < 0 ? 0 : src));
-                const uint32_t ri = (static_cast<uint32_t>(nlo) & (kZeRing - 1u)) + 4u * lane;
-                *reinterpret_cast<uint32_t*>(&L.ring[j][ri]) = v;
-                if (ri < 16u) *reinterpret_cast<uint32_t*>(&L.ring[j][kZeRing + ri]) = v;
+                const uint32_t jf = blockIdx.x * kZcFrames + (j >> 3), jb = pass * 8u + (j & 7u);
+                const uint4* const src = reinterpret_cast<const uint4*>(scratch + lay.tab_at + (static_cast<uint64_t>(jf) * lay.blk_cap + jb) * kTabBytes);
+                uint4* const dst = reinterpret_cast<uint4*>(L.tab[j]);
+                for (uint32_t q = lane; q < 2560u / 16u; q += 64u) dst[q] = src[q];
             }
-            if (can) rlo -= static_cast<int32_t>(kZeChunk);
+        }
+        // ---- the bit stream: `pos` bits are unread; staged through the ring, refilled downwards by the whole wave
+        uint32_t lerr = 0;
+        if (act && (d.bend <= d.bits_at || d.bend > n || frame[d.bend - 1u] == 0u)) {
+            lerr = kZstdBadBitstream;
+            act = false;
+        }
+        int32_t pos = act ? static_cast<int32_t>(8u * (d.bend - 1u) + highbit(frame[d.bend - 1u])) : 0;
+        const int32_t start_bit = static_cast<int32_t>(8u * d.bits_at);
+        int32_t rlo = act ? ((pos >> 3) & ~static_cast<int32_t>(kZcChunk - 1u)) + static_cast<int32_t>(kZcChunk) : 0;
+        const uint32_t src_lo = static_cast<uint32_t>(gb.src_off), src_hi = static_cast<uint32_t>(gb.src_off >> 32);
+        auto refill = [&](bool want) {
+            // lanes that want a chunk and have room for it: the bytes it overwrites lie above the window
+            const bool can = want && ((pos >> 3) - (rlo - static_cast<int32_t>(kZcChunk)) <= static_cast<int32_t>(kZcRing) - 1);
+            uint64_t m = __builtin_amdgcn_ballot_w64(can) & ((1ull << kZcLanes) - 1ull);
+            while (m) {
+                const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(m));
+                m &= m - 1ull;
+                const int32_t nlo = __builtin_amdgcn_readlane(rlo, j) - static_cast<int32_t>(kZcChunk);
+                const uint64_t joff = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src_lo), j))) |
+                                      (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src_hi), j))) << 32);
+                const int32_t jn = static_cast<int32_t>(__builtin_amdgcn_readlane(static_cast<int>(n), j));
+                if (lane >= kZcChunk / 4u) continue;
+                // (never below the buffer, never beyond the 64 readable bytes behind the payload: what lies there is never used)
+                int32_t rel = nlo + 4 * static_cast<int32_t>(lane);
+                if (rel > jn + 56) rel = jn + 56;
+                const int64_t src = static_cast<int64_t>(joff) + rel;
+                const uint32_t v = ld_le32(comp + (src < 0 ? 0 : src));
+                const uint32_t ri = (static_cast<uint32_t>(nlo) & (kZcRing - 1u)) + 4u * lane;
+                *reinterpret_cast<uint32_t*>(&L.ring[j][ri]) = v;
+                if (ri < 16u) *reinterpret_cast<uint32_t*>(&L.ring[j][kZcRing + ri]) = v;
+            }
+            if (can) rlo -= static_cast<int32_t>(kZcChunk);
         };
-        for (int k = 0; k < 4; ++k) refill(seq_act);
+        for (int k = 0; k < 4; ++k) refill(act);
         __syncthreads();
-        auto window = [&](uint64_t& hi, uint64_t& lo) {
-            const uint32_t ri = static_cast<uint32_t>((pos >> 3) - 15) & (kZeRing - 1u);
-            __builtin_memcpy(&lo, &L.ring[lane & (kZeLanes - 1u)][ri], 8);
-            __builtin_memcpy(&hi, &L.ring[lane & (kZeLanes - 1u)][ri + 8u], 8);
+        const uint32_t home = lane & (kZcLanes - 1u);
+        const uint16_t* const T = L.tab[home];
+        const uint32_t sizel = 1u << logl, sizeo = 1u << logo, sizem = 1u << logm;
+        // the window: 16 bytes that end with the byte the position falls into, as four dwords; (pos & 7) + 120 of its bits are unread
+        auto window = [&](uint32_t* dw) {
+            const uint32_t ri = static_cast<uint32_t>((pos >> 3) - 15) & (kZcRing - 1u);
+            __builtin_memcpy(dw, &L.ring[home][ri], 16);
         };
-        // bits [t - 64, t) of hi:lo for t >= 65, else bits [0, t) at the top
-        auto top64 = [](uint64_t hi, uint64_t lo, uint32_t t) -> uint64_t { return t >= 65u ? (hi << (128u - t)) | (lo >> (t - 64u)) : lo << (64u - t); };
         uint32_t sl = 0, so = 0, sm = 0;
-        if (seq_act) {
-            uint64_t hi, lo;
-            window(hi, lo);
-            uint64_t w = top64(hi, lo, (static_cast<uint32_t>(pos) & 7u) + 120u);
-            sl = take(w, logl);
-            so = take(w, logo);
-            sm = take(w, logm);
+        if (act) {
+            uint32_t dw[4];
+            window(dw);
+            const uint32_t sh = static_cast<uint32_t>(pos) & 7u;
+            uint64_t w = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(dw[3], dw[2], sh + 24u)) << 32) | __builtin_amdgcn_alignbit(dw[2], dw[1], sh + 24u);
+            sl = take(w, logl) & 511u;
+            so = take(w, logo) & 255u;
+            sm = take(w, logm) & 511u;
             pos -= static_cast<int32_t>(logl + logo + logm);
             if (pos < start_bit) {
                 lerr = kZstdBadBitstream;
-                seq_act = false;
+                act = false;
             }
         }
-        // What the whole wave needs of a block lives in the block's own lane and is read with readlane: the offset history as
-        // this block knows it (bit i of known: slot i holds a value), records written, output and literal bytes so far.
-        uint32_t r0 = 0, r1 = 0, r2 = 0, known = 0;
-        uint32_t nrec = 0, out = 0, lit_pos = 0, n_sym = 0;
-        // one record, written by lane 0 (arguments uniform): block `j`'s counters come in and go back through its lane
-        auto put_uniform = [&](uint32_t j, uint32_t w0, uint32_t ll, uint32_t ml) {
-            const uint32_t b_at = __builtin_amdgcn_readlane(rec_at, j), b_cap = __builtin_amdgcn_readlane(rec_cap, j);
-            const uint32_t b_n = __builtin_amdgcn_readlane(nrec, j), b_out = __builtin_amdgcn_readlane(out, j), b_lit = __builtin_amdgcn_readlane(lit_pos, j);
-            if (lane == 0u && b_n < b_cap) {
-                if ((b_n & 63u) == 0u) ck[(b_at + b_n) >> 6] = make_uint4(b_out, b_lit, 0u, 0u);
-                recs[b_at + b_n] = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(ll | (ml << 14)) << 32);
-            }
-            if (lane == j) {
-                nrec = b_n + 1u;
-                out = b_out + ll + ml;
-                lit_pos = b_lit + ll;
+        // One step: `update` = the states move on (every sequence but a block's last).  Straight-line; a lane that has no step
+        // left computes along and stores nothing.
+        uint32_t* my_st = stash + static_cast<uint64_t>(d.stash_at) * 3u;   // this lane's next stash entry: states | window (two dwords)
+        uint32_t i = 0;
+        auto chain_step = [&](const bool step, const bool update) {
+            const uint32_t el = T[sl], eo = T[512u + so], em = T[768u + sm];
+            uint32_t dw[4];
+            window(dw);
+            const uint32_t oc = eo >> 10, mlb = em >> 10, llb = el >> 10;
+            const uint32_t xl = el & 1023u, xo = eo & 1023u, xm = em & 1023u;
+            // bits of the next state: log - highbit(next-state number)
+            const uint32_t nbl = update ? logl - highbit(xl) : 0u, nbm = update ? logm - highbit(xm) : 0u, nbo = update ? logo - highbit(xo) : 0u;
+            const uint32_t ext = oc + mlb + llb;
+            const uint32_t sh = static_cast<uint32_t>(pos) & 7u;
+            // bits [t - 64, t) with t = sh + 120: the extra bits of the three codes lead them (for zstd_records)
+            const uint32_t w1lo = __builtin_amdgcn_alignbit(dw[2], dw[1], sh + 24u), w1hi = __builtin_amdgcn_alignbit(dw[3], dw[2], sh + 24u);
+            // the state bits follow the extra bits: the 32 bits of the window below bit t - ext (<= 26 are used)
+            const uint32_t f = sh + 88u - ext;   // t - ext - 32: 25..95
+            const uint32_t fk = f >> 5;
+            const uint32_t x_lo = fk == 0u ? dw[0] : (fk == 1u ? dw[1] : dw[2]), x_hi = fk == 0u ? dw[1] : (fk == 1u ? dw[2] : dw[3]);
+            const uint32_t x = __builtin_amdgcn_alignbit(x_hi, x_lo, f & 31u);
+            const uint32_t o1 = 32u - nbl, o2 = o1 - nbm, o3 = o2 - nbo;
+            const uint32_t bl = __builtin_amdgcn_ubfe(x, o1, nbl), bm = __builtin_amdgcn_ubfe(x, o2, nbm), bo = __builtin_amdgcn_ubfe(x, o3, nbo);
+            if (step) {
+                typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+                v3u e;
+                e.x = sl | (so << 9) | (sm << 17);
+                e.y = w1lo;
+                e.z = w1hi;
+                *reinterpret_cast<v3u*>(my_st) = e;
+                my_st += 3;
+                sl = (xl << nbl) - sizel + bl;
+                sm = (xm << nbm) - sizem + bm;
+                so = (xo << nbo) - sizeo + bo;
+                pos -= static_cast<int32_t>(ext + nbl + nbm + nbo);
+                ++i;
+                if (PROF) ++n_steps;
+                if (pos < start_bit) {
+                    lerr = kZstdBadBitstream;
+                    act = false;
+                }
             }
         };
-        auto literal_run_uniform = [&](uint32_t j, uint32_t count) {
+        const uint32_t nupd = nseq ? nseq - 1u : 0u;   // steps that move the states on
+        while (__builtin_amdgcn_ballot_w64(act && i < nupd)) {
+            // (a lane whose window would run out of staged bytes within four steps asks for a chunk; the wave copies)
+            if (__builtin_amdgcn_ballot_w64(act && i < nupd && (pos >> 3) - rlo < 80)) refill(act && i < nupd && (pos >> 3) - rlo < static_cast<int32_t>(kZcRing / 2u));
+#pragma unroll
+            for (uint32_t u = 0; u < 4u; ++u) chain_step(act && i < nupd, true);
+        }
+        // the last sequence of every block: its codes and extra bits, no bits for further states
+        if (__builtin_amdgcn_ballot_w64(act && (pos >> 3) - rlo < 80)) refill(act && (pos >> 3) - rlo < static_cast<int32_t>(kZcRing / 2u));
+        chain_step(act && i < nseq, false);
+        if (have && d.type == 2u && d.nseq > 0u && !lerr && pos != start_bit) lerr = kZstdBadBitstream;
+        if (have && lerr) blk[b].chain_err = lerr;
+        __syncthreads();
+    }
+    if (PROF && lane == 0u) {
+        atomicAdd(&tally[20], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
+        atomicAdd(&tally[21], 1ull);
+    }
+    if (PROF) atomicAdd(&tally[22], n_steps);
+}
+
+// ------------------------------------------------------------------------------------------------ zstd_records
+// What the chains left behind becomes records: a workgroup per frame, a wave per block, a lane per sequence, 64 at a time:
+// symbols from the states, values from the codes and the window, positions by prefix sums, repeat offsets by relaxation
+// over the lanes (a lane's history is its left neighbour's after the neighbour's sequence; three plain offsets in a row
+// fix it whatever came before, so a few rounds settle all 64), records and checkpoints.  Then, with every block of the
+// frame done: the repeat codes a block could not resolve because they reach into the block before it are replayed in frame
+// order by one wave, and the checkpoints get their positions in the frame.
+constexpr uint32_t kZvWaves = 8;
+
+struct ZvLds {
+    uint32_t ll_base[36], ml_base[53];  // value | extra bits << 24
+    uint32_t err;
+};
+
+template <bool PROF>
+__global__ __launch_bounds__(64 * kZvWaves) void zstd_records(const GpuBlock* __restrict__ blocks, uint8_t* __restrict__ scratch, const ZLayout lay,
+                                                              uint32_t* __restrict__ status, unsigned long long* __restrict__ tally)
+{
+    __shared__ ZvLds L;
+    const uint32_t fi = blockIdx.x;
+    if (status[fi] != 0u) return;  // (uniform for the workgroup)
+    const uint32_t lane = threadIdx.x & 63u, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t dst_len = blocks[fi].dst_len;
+    ZFrameHdr* const hdr = reinterpret_cast<ZFrameHdr*>(scratch + lay.hdr_at) + fi;
+    ZBlk* const blk = reinterpret_cast<ZBlk*>(scratch + lay.blk_at) + static_cast<uint64_t>(fi) * lay.blk_cap;
+    const uint8_t* const tabs = scratch + lay.tab_at + static_cast<uint64_t>(fi) * lay.blk_cap * kTabBytes;
+    uint4* const ck = reinterpret_cast<uint4*>(scratch + lay.ck_at) + static_cast<uint64_t>(fi) * lay.ck_stride;
+    uint64_t* const recs = reinterpret_cast<uint64_t*>(scratch + lay.rec_at) + static_cast<uint64_t>(fi) * lay.rec_stride;
+    const uint32_t* const stash = reinterpret_cast<const uint32_t*>(scratch + lay.stash_at) + static_cast<uint64_t>(fi) * lay.rec_stride * 3u;
+    const uint32_t nblk = hdr->nblk <= lay.blk_cap ? hdr->nblk : 0u;
+    const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
+    unsigned long long n_rounds = 0, n_batches = 0;
+    if (threadIdx.x < 36u) L.ll_base[threadIdx.x] = kLLBase[threadIdx.x] | (static_cast<uint32_t>(kLLBits[threadIdx.x]) << 24);
+    if (threadIdx.x < 53u) L.ml_base[threadIdx.x] = kMLBase[threadIdx.x] | (static_cast<uint32_t>(kMLBits[threadIdx.x]) << 24);
+    if (threadIdx.x == 0u) L.err = 0u;
+    __syncthreads();
+    for (uint32_t b = wave; b < nblk; b += kZvWaves) {
+        const ZBlk d = blk[b];
+        const uint8_t* const tg = tabs + static_cast<uint64_t>(b) * kTabBytes;
+        // (all of this wave-uniform) the block's records, output and literal bytes so far; its view of the offset history
+        uint32_t nrec = 0, out = 0, lit_pos = 0, n_sym = 0;
+        uint32_t h0 = 0, h1 = 0, h2 = 0, kn = 0;
+        uint32_t berr = d.chain_err;
+        const uint32_t rec_at = d.rec_at, rec_cap = d.rec_cap;
+        auto put = [&](uint32_t w0, uint32_t ll, uint32_t ml) {   // one record, by lane 0
+            if (lane == 0u && nrec < rec_cap) {
+                if ((nrec & 63u) == 0u) ck[(rec_at + nrec) >> 6] = make_uint4(out, lit_pos, 0u, 0u);
+                recs[rec_at + nrec] = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(ll | (ml << 14)) << 32);
+            }
+            ++nrec;
+            out += ll + ml;
+            lit_pos += ll;
+        };
+        auto literal_run = [&](uint32_t count) {
             while (count) {
                 const uint32_t piece = count < kRecLL ? count : kRecLL;
-                put_uniform(j, kRecFlag, piece, 0u);
+                put(kRecFlag, piece, 0u);
                 count -= piece;
             }
         };
-        const ZeTables& T = L.tab[lane & (kZeLanes - 1u)];
-        const uint32_t home = lane & (kZeLanes - 1u);
-        uint32_t i = 0;
-        while (__builtin_amdgcn_ballot_w64(seq_act && i < nseq)) {
-            const uint32_t i_before = i;
-            const unsigned long long ta = PROF ? __builtin_readcyclecounter() : 0ull;
-            // ---- A: the serial chain of every block, up to kZeRound steps: three states -> three entries and the window
-            // (ONE LDS round trip) -> the bits of the next states.  Nothing else: the codes and the window go to the stash.
-            for (uint32_t s0 = 0; s0 < kZeRound; s0 += 4u) {
-                if (!__builtin_amdgcn_ballot_w64(seq_act && i < nseq)) break;
-                // (a lane whose window would run out of staged bytes within four steps asks for a chunk; the wave copies)
-                if (__builtin_amdgcn_ballot_w64(seq_act && i < nseq && (pos >> 3) - rlo < 80)) {
-                    if (PROF) ++n_refill;
-                    refill(seq_act && i < nseq && (pos >> 3) - rlo < static_cast<int32_t>(kZeRing / 2u));
-                }
-#pragma unroll
-                for (uint32_t u = 0; u < 4u; ++u) {
-                    const uint32_t s = s0 + u;
-                    const bool step = seq_act && i < nseq;
-                    const uint32_t el = T.fse.ll[sl & 511u], eo = T.fse.of[so & 255u], em = T.fse.ml[sm & 511u];
-                    // the window: 16 bytes that end with the byte the position falls into, as four dwords; t = sh + 120 of its bits are unread
-                    uint32_t d[4];
-                    {
-                        const uint32_t ri = static_cast<uint32_t>((pos >> 3) - 15) & (kZeRing - 1u);
-                        __builtin_memcpy(d, &L.ring[home][ri], 16);
-                    }
-                    const uint32_t oc = (eo >> 10) & 31u, mlb = (em >> 10) & 31u, llb = (el >> 10) & 31u;
-                    const bool lastseq = i + 1u == nseq;
-                    const uint32_t nbl = lastseq ? 0u : (el >> 6) & 15u, nbm = lastseq ? 0u : (em >> 6) & 15u, nbo = lastseq ? 0u : (eo >> 6) & 15u;
-                    const uint32_t ext = oc + mlb + llb;
-                    const uint32_t sh = static_cast<uint32_t>(pos) & 7u;
-                    // bits [t - 64, t): the extra bits of the three codes lead them (for the vector pass)
-                    const uint32_t w1lo = __builtin_amdgcn_alignbit(d[2], d[1], sh + 24u), w1hi = __builtin_amdgcn_alignbit(d[3], d[2], sh + 24u);
-                    // the state bits follow the extra bits: the 32 bits of the window below bit t - ext (<= 26 are used)
-                    const uint32_t f = sh + 88u - ext;   // t - ext - 32: 25..95
-                    const uint32_t fk = f >> 5;
-                    const uint32_t x_lo = fk == 0u ? d[0] : (fk == 1u ? d[1] : d[2]), x_hi = fk == 0u ? d[1] : (fk == 1u ? d[2] : d[3]);
-                    uint32_t x = __builtin_amdgcn_alignbit(x_hi, x_lo, f & 31u);
-                    const uint32_t bl = __builtin_amdgcn_ubfe(x, 32u - nbl, nbl);
-                    x <<= nbl;
-                    const uint32_t bm = __builtin_amdgcn_ubfe(x, 32u - nbm, nbm);
-                    x <<= nbm;
-                    const uint32_t bo = __builtin_amdgcn_ubfe(x, 32u - nbo, nbo);
-                    if (step) {
-                        L.stash_code[home][s] = (el & 63u) | ((em & 63u) << 6) | (oc << 12);
-                        L.stash_lo[home][s] = w1lo;
-                        L.stash_hi[home][s] = w1hi;
-                        sl = (el >> 16) + bl;
-                        sm = (em >> 16) + bm;
-                        so = (eo >> 16) + bo;
-                        pos -= static_cast<int32_t>(ext + nbl + nbm + nbo);
-                        ++i;
-                        if (pos < start_bit) {
-                            lerr = kZstdBadBitstream;
-                            seq_act = false;
-                        }
-                    }
+        if (d.type == 0u) {
+            literal_run(d.size);
+        } else if (d.type == 1u) {
+            if (d.size) {
+                uint32_t left = d.size - 1u;
+                uint32_t piece = left < kRecML ? left : kRecML;
+                put((piece ? 1u : 0u) | kRecFlag, 1u, piece);
+                left -= piece;
+                while (left) {
+                    piece = left < kRecML ? left : kRecML;
+                    put(1u | kRecFlag, 0u, piece);
+                    left -= piece;
                 }
             }
-            const uint32_t cnt = i - i_before;
-            __syncthreads();
-            const unsigned long long tb = PROF ? __builtin_readcyclecounter() : 0ull;
-            if (PROF) t_chain += tb - ta;
-            // ---- B: what the chain left behind, block after block, a lane per sequence: values of the codes, positions by
-            // prefix sums, repeat offsets (a scalar walk over the few lanes that have one), records and checkpoints
-            for (uint32_t j = 0; j < nb; ++j) {
-                const uint32_t nq = __builtin_amdgcn_readlane(cnt, j);
-                if (!nq) continue;
+        } else if (!berr) {
+            const uint32_t nseq = d.nseq;
+            const uint32_t* const my_st = stash + static_cast<uint64_t>(d.stash_at) * 3u;   // entries of three dwords: states | window
+            auto load_stash = [&](uint32_t at, uint32_t& st_out, uint64_t& w_out) {
+                const bool in = at < nseq;
+                const uint32_t* const e = my_st + static_cast<uint64_t>(in ? at : 0u) * 3u;
+                st_out = in ? e[0] : 0u;
+                w_out = in ? (static_cast<uint64_t>(e[2]) << 32) | e[1] : 0ull;
+            };
+            // the stash of the first batch; the next one is loaded while this one is worked on
+            uint32_t st_n;
+            uint64_t w_n;
+            load_stash(lane, st_n, w_n);
+            for (uint32_t done = 0; done < nseq && !berr; done += 64u) {
+                const uint32_t nq = nseq - done < 64u ? nseq - done : 64u;
                 const bool valid = lane < nq;
-                const unsigned long long tv0 = PROF ? __builtin_readcyclecounter() : 0ull;
-                const uint32_t code = L.stash_code[j][lane], wlo = L.stash_lo[j][lane], whi = L.stash_hi[j][lane];
-                const uint32_t lsym = code & 63u, msym = (code >> 6) & 63u, oc = code >> 12;
-                const uint32_t lle = L.ll_base[lsym < 36u ? lsym : 35u], mle = L.ml_base[msym < 53u ? msym : 52u];   // value | extra bits << 24
-                uint64_t w = (static_cast<uint64_t>(whi) << 32) | wlo;
+                const uint32_t st = st_n;
+                uint64_t w = w_n;
+                load_stash(done + 64u + lane, st_n, w_n);
+                if (PROF) ++n_batches;
+                const uint32_t sl = st & 511u, so = (st >> 9) & 255u, sm = st >> 17;
+                const uint32_t lsym = tg[kTabSymLL + sl], msym = tg[kTabSymML + sm];
+                const uint32_t oc = static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(tg + kTabOF)[so]) >> 10;
+                const uint32_t lle = L.ll_base[lsym < 36u ? lsym : 35u], mle = L.ml_base[msym < 53u ? msym : 52u];
                 const uint32_t obits = take(w, oc), mbits = take(w, mle >> 24), lbits = take(w, lle >> 24);
                 const uint32_t ofv = (1u << oc) + obits;
                 const uint32_t mlv = valid ? (mle & 0xFFFFFFu) + mbits : 0u, llv = valid ? (lle & 0xFFFFFFu) + lbits : 0u;
                 const uint32_t lincl = wave_scan_add(llv), oincl = wave_scan_add(llv + mlv);
-                const uint32_t b_lit = __builtin_amdgcn_readlane(lit_pos, j), b_out = __builtin_amdgcn_readlane(out, j);
-                const uint32_t b_nlit = __builtin_amdgcn_readlane(nlit, j), b_n = __builtin_amdgcn_readlane(nrec, j);
-                const uint32_t my_lit = b_lit + lincl - llv, my_out = b_out + oincl - llv - mlv;
+                const uint32_t my_lit = lit_pos + lincl - llv, my_out = out + oincl - llv - mlv;
                 const uint32_t lit_all = __builtin_amdgcn_readlane(lincl, 63), out_all = __builtin_amdgcn_readlane(oincl, 63);
-                uint32_t berr = 0;
                 if (__builtin_amdgcn_ballot_w64(valid && oc > 26u))
                     berr = kZstdBadOffset;
-                else if (b_lit + lit_all > b_nlit)
+                else if (lit_pos + lit_all > d.nlit)
                     berr = kZstdBadLiterals;
-                else if (b_out + out_all > kBlockMax)
+                else if (out + out_all > kBlockMax)
                     berr = kZstdBadSize;
-                if (berr) {
-                    if (lane == j) {
-                        lerr = berr;
-                        seq_act = false;
-                    }
-                    continue;
-                }
-                // repeat offsets (RFC 8878 3.1.1.5).  h0..h2 / kn: the history before lane `cur`; lanes between two repeat codes
-                // push their offsets; a repeat code met while a slot is still unknown stays in the record as it is (replayed below)
+                if (berr) break;
+                // ---- repeat offsets (RFC 8878 3.1.1.5) by relaxation: (p0, p1, p2 | pk) is the history AFTER this lane's sequence,
+                // (q0, q1, q2 | qk) the one before it = the left neighbour's (lane 0: the block's so far); bit i of pk / qk: slot i holds
+                // a value.  A plain offset v makes (v, q0, q1); code 1 / 2 / 3 (+ 1 without literals) picks q0 / q1 / q2 / q0 - 1.
                 const bool isrep = valid && ofv <= 3u;
-                uint32_t w0 = ofv - 3u;
-                uint32_t h0 = __builtin_amdgcn_readlane(r0, j), h1 = __builtin_amdgcn_readlane(r1, j), h2 = __builtin_amdgcn_readlane(r2, j);
-                uint32_t kn = __builtin_amdgcn_readlane(known, j), sym_end = __builtin_amdgcn_readlane(n_sym, j);
-                uint32_t cur = 0;
-                auto push_to = [&](uint32_t upto) {   // lanes [cur, upto) hold plain offsets: the last three of them enter the history
-                    const uint32_t k = upto - cur;
-                    const uint32_t p1 = __builtin_amdgcn_readlane(w0, (upto - 1u) & 63u), p2 = __builtin_amdgcn_readlane(w0, (upto - 2u) & 63u);
-                    const uint32_t p3 = __builtin_amdgcn_readlane(w0, (upto - 3u) & 63u);
-                    const uint32_t n0 = k >= 1u ? p1 : h0;
-                    const uint32_t n1 = k >= 2u ? p2 : (k == 1u ? h0 : h1);
-                    const uint32_t n2 = k >= 3u ? p3 : (k == 2u ? h0 : (k == 1u ? h1 : h2));
-                    kn = k >= 3u ? 7u : ((kn << k) | ((1u << k) - 1u)) & 7u;
-                    h0 = n0;
-                    h1 = n1;
-                    h2 = n2;
-                };
-                uint64_t repm = __builtin_amdgcn_ballot_w64(isrep);
-                const unsigned long long tv1 = PROF ? __builtin_readcyclecounter() : 0ull;
-                if (PROF) {
-                    t_v1 += tv1 - tv0;
-                    n_rep += static_cast<unsigned long long>(__builtin_popcountll(repm));
-                }
-                while (repm) {
-                    const uint32_t b = static_cast<uint32_t>(__builtin_ctzll(repm));
-                    repm &= repm - 1ull;
-                    push_to(b);
-                    const bool resolved = kn == 7u;
-                    const uint32_t rcode = __builtin_amdgcn_readlane(ofv, b);
-                    const bool ll0 = __builtin_amdgcn_readlane(llv, b) == 0u;
-                    const uint32_t idx = rcode - 1u + (ll0 ? 1u : 0u);   // 0..3
-                    const uint32_t o = idx == 0u ? h0 : (idx == 1u ? h1 : (idx == 2u ? h2 : h0 - 1u));
-                    const uint32_t k0 = kn & 1u, k1 = (kn >> 1) & 1u, k2 = (kn >> 2) & 1u;
-                    const uint32_t ko = idx == 1u ? k1 : (idx == 2u ? k2 : k0);
-                    const uint32_t t1 = idx == 0u ? h1 : h0, t2 = idx <= 1u ? h2 : h1;
-                    kn = ko | ((idx == 0u ? k1 : k0) << 1) | ((idx <= 1u ? k2 : k1) << 2);
-                    h0 = o;
-                    h1 = t1;
-                    h2 = t2;
-                    if (resolved && o == 0u) berr = kZstdBadOffset;
-                    const uint32_t v = resolved ? (o & 0x3FFFFFFFu) : (kRecRep | (ll0 ? kRecFlag : 0u) | rcode);
-                    sym_end = resolved ? sym_end : b_n + b + 1u;   // (with runs split below the index moves: the slow path sets it again)
-                    w0 = lane == b ? v : w0;
-                    cur = b + 1u;
-                }
-                push_to(nq);
-                const unsigned long long tv2 = PROF ? __builtin_readcyclecounter() : 0ull;
-                if (PROF) t_v2 += tv2 - tv1;
-                if (berr) {
-                    if (lane == j) {
-                        lerr = berr;
-                        seq_act = false;
+                const uint32_t idx = ofv - 1u + (llv == 0u ? 1u : 0u);   // (for repeat codes: 0..3)
+                const uint32_t kind = !valid ? 5u : (isrep ? idx : 4u);  // 0..3 repeat, 4 plain offset, 5 nothing
+                uint32_t p0 = ofv - 3u, p1 = 0u, p2 = 0u, pk = kind == 4u ? 1u : 0u;
+                uint32_t q0 = 0u, q1 = 0u, q2 = 0u, qk = 0u;
+                for (uint32_t round = 0; round < 66u; ++round) {
+                    if (PROF) ++n_rounds;
+                    q0 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(h0), static_cast<int>(p0), 0x138, 0xF, 0xF, false));  // wave_shr:1
+                    q1 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(h1), static_cast<int>(p1), 0x138, 0xF, 0xF, false));
+                    q2 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(h2), static_cast<int>(p2), 0x138, 0xF, 0xF, false));
+                    qk = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(kn), static_cast<int>(pk), 0x138, 0xF, 0xF, false));
+                    const uint32_t k0 = qk & 1u, k1 = (qk >> 1) & 1u, k2 = (qk >> 2) & 1u;
+                    uint32_t n0, n1, n2, nk;
+                    if (kind == 4u) {
+                        n0 = ofv - 3u;
+                        n1 = q0;
+                        n2 = q1;
+                        nk = 1u | (k0 << 1) | (k1 << 2);
+                    } else if (kind == 0u || kind == 5u) {
+                        n0 = q0;
+                        n1 = q1;
+                        n2 = q2;
+                        nk = qk;
+                    } else if (kind == 1u) {
+                        n0 = q1;
+                        n1 = q0;
+                        n2 = q2;
+                        nk = k1 | (k0 << 1) | (k2 << 2);
+                    } else if (kind == 2u) {
+                        n0 = q2;
+                        n1 = q0;
+                        n2 = q1;
+                        nk = k2 | (k0 << 1) | (k1 << 2);
+                    } else {
+                        n0 = q0 - 1u;
+                        n1 = q0;
+                        n2 = q1;
+                        nk = k0 | (k0 << 1) | (k1 << 2);
                     }
-                    continue;
+                    const bool changed = nk != pk || (n0 != p0 && (nk & 1u)) || (n1 != p1 && (nk & 2u)) || (n2 != p2 && (nk & 4u));
+                    p0 = n0;
+                    p1 = n1;
+                    p2 = n2;
+                    pk = nk;
+                    if (!__builtin_amdgcn_ballot_w64(changed)) break;
                 }
+                // a repeat code met while the history before it still has an unknown slot stays in the record as it is
+                const bool resolved = qk == 7u;
+                uint32_t w0 = p0 & 0x3FFFFFFFu;
+                if (isrep && !resolved) w0 = kRecRep | (llv == 0u ? kRecFlag : 0u) | ofv;
+                if (__builtin_amdgcn_ballot_w64(isrep && resolved && p0 == 0u)) {
+                    berr = kZstdBadOffset;
+                    break;
+                }
+                const uint64_t flagged = __builtin_amdgcn_ballot_w64(isrep && !resolved);
                 if (__builtin_expect(__builtin_amdgcn_ballot_w64(valid && (llv > kRecLL || mlv > kRecML)) == 0ull, 1)) {
                     // one record per sequence
-                    const uint32_t b_at = __builtin_amdgcn_readlane(rec_at, j), b_cap = __builtin_amdgcn_readlane(rec_cap, j);
-                    const uint32_t ridx = b_n + lane;
-                    if (valid && ridx < b_cap) {
-                        if ((ridx & 63u) == 0u) ck[(b_at + ridx) >> 6] = make_uint4(my_out, my_lit, 0u, 0u);
-                        recs[b_at + ridx] = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(llv | (mlv << 14)) << 32);
+                    const uint32_t ridx = nrec + lane;
+                    if (valid && ridx < rec_cap) {
+                        if ((ridx & 63u) == 0u) ck[(rec_at + ridx) >> 6] = make_uint4(my_out, my_lit, 0u, 0u);
+                        recs[rec_at + ridx] = static_cast<uint64_t>(w0) | (static_cast<uint64_t>(llv | (mlv << 14)) << 32);
                     }
-                    if (lane == j) {
-                        nrec = b_n + nq;
-                        out = b_out + out_all;
-                        lit_pos = b_lit + lit_all;
-                    }
+                    if (flagged) n_sym = nrec + 64u - static_cast<uint32_t>(__builtin_clzll(flagged));
+                    nrec += nq;
+                    out += out_all;
+                    lit_pos += lit_all;
                 } else {
                     // a run above 16,383 somewhere in the batch: record after record, the long ones in pieces
                     for (uint32_t q = 0; q < nq; ++q) {
                         uint32_t q_ll = __builtin_amdgcn_readlane(llv, q), q_ml = __builtin_amdgcn_readlane(mlv, q);
                         const uint32_t q_w0 = __builtin_amdgcn_readlane(w0, q);
                         while (q_ll > kRecLL) {
-                            put_uniform(j, kRecFlag, kRecLL, 0u);
+                            put(kRecFlag, kRecLL, 0u);
                             q_ll -= kRecLL;
                         }
                         uint32_t piece = q_ml < kRecML ? q_ml : kRecML;
-                        put_uniform(j, q_w0, q_ll, piece);
+                        put(q_w0, q_ll, piece);
                         q_ml -= piece;
                         while (q_ml) {
                             piece = q_ml < kRecML ? q_ml : kRecML;
-                            put_uniform(j, (q_w0 & kRecRep) ? (kRecRep | kRecFlag | 0x10u) : (q_w0 | kRecFlag), 0u, piece);
+                            put((q_w0 & kRecRep) ? (kRecRep | kRecFlag | 0x10u) : (q_w0 | kRecFlag), 0u, piece);
                             q_ml -= piece;
                         }
-                        if (q_w0 & kRecRep) sym_end = __builtin_amdgcn_readlane(nrec, j);
+                        if (q_w0 & kRecRep) n_sym = nrec;
                     }
                 }
-                if (lane == j) {
-                    r0 = h0;
-                    r1 = h1;
-                    r2 = h2;
-                    known = kn;
-                    n_sym = sym_end;
-                }
-                if (PROF) t_v3 += __builtin_readcyclecounter() - tv2;
+                // the history after the batch: the last valid lane's
+                h0 = __builtin_amdgcn_readlane(p0, nq - 1u);
+                h1 = __builtin_amdgcn_readlane(p1, nq - 1u);
+                h2 = __builtin_amdgcn_readlane(p2, nq - 1u);
+                kn = __builtin_amdgcn_readlane(pk, nq - 1u);
             }
-            __syncthreads();
-            if (PROF) t_vec += __builtin_readcyclecounter() - tb;
-        }
-        if (mine && my_type == 2u && nseq > 0u && !lerr && pos != start_bit) lerr = kZstdBadBitstream;
-        // what is left of every block: the literals behind its last sequence; raw and RLE blocks whole
-        if (!__builtin_amdgcn_ballot_w64(lerr != 0u)) {
-            for (uint32_t j = 0; j < nb; ++j) {
-                const uint32_t b_type = __builtin_amdgcn_readlane(my_type, j), b_size = __builtin_amdgcn_readlane(my_size, j);
-                if (b_type == 0u) {
-                    literal_run_uniform(j, b_size);
-                } else if (b_type == 1u) {
-                    if (b_size) {
-                        uint32_t left = b_size - 1u;
-                        uint32_t piece = left < kRecML ? left : kRecML;
-                        put_uniform(j, (piece ? 1u : 0u) | kRecFlag, 1u, piece);
-                        left -= piece;
-                        while (left) {
-                            piece = left < kRecML ? left : kRecML;
-                            put_uniform(j, 1u | kRecFlag, 0u, piece);
-                            left -= piece;
-                        }
-                    }
-                } else {
-                    literal_run_uniform(j, __builtin_amdgcn_readlane(nlit, j) - __builtin_amdgcn_readlane(lit_pos, j));
-                }
+            if (!berr) {
+                literal_run(d.nlit - lit_pos);
+                if (kn != 7u) n_sym = nrec;
+                if (out > kBlockMax || nrec > rec_cap) berr = kZstdBadSize;
             }
         }
-        const bool all_known = known == 7u;
-        if (mine && !lerr) {
-            if (my_type == 2u) {
-                if (!all_known) n_sym = nrec;
-                if (out > kBlockMax) lerr = kZstdBadSize;
-            }
-            if (nrec > rec_cap) lerr = kZstdBadSize;
+        if (berr) {
+            if (lane == 0u) atomicMax(&L.err, berr);
+        } else if (lane == 0u) {
+            ZBlk& o = blk[b];
+            o.nrec = nrec;
+            o.out_len = out;
+            o.n_sym = n_sym;
+            o.hist_known = kn == 7u ? 1u : 0u;
+            o.hist[0] = h0;
+            o.hist[1] = h1;
+            o.hist[2] = h2;
         }
-        if (PROF) t_seq += __builtin_readcyclecounter() - t2;
-        if (__builtin_amdgcn_ballot_w64(lerr != 0u)) {
-            const uint32_t first = static_cast<uint32_t>(__builtin_ctzll(__builtin_amdgcn_ballot_w64(lerr != 0u)));
-            fail(__builtin_amdgcn_readlane(lerr, first));
-            break;
-        }
-        // ---- the records of this wave must be visible to the lane that replays them
-        __threadfence();
-        if (mine) {
-            ZeShare& s = L.sh[lane];
-            s.nrec = nrec;
-            s.out_len = out;
-            s.n_sym = n_sym;
-            s.hist_known = all_known ? 1u : 0u;
-            s.hist[0] = r0;
-            s.hist[1] = r1;
-            s.hist[2] = r2;
-        }
-        __syncthreads();
-        // replay of the prefixes written with an unknown history, block after block (uniform; the stores by lane 0)
-        uint32_t rerr = 0;
-        for (uint32_t j = 0; j < nb; ++j) {
-            const ZeShare& s = L.sh[j];
-            uint64_t* const rj = recs + s.rec_at;
-            for (uint32_t k = 0; k < s.n_sym; ++k) {
-                const uint64_t w = __hip_atomic_load(&rj[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const uint32_t w0 = static_cast<uint32_t>(w);
-                if (w0 & kRecRep) {
-                    const uint32_t code = w0 & 0xFFu;
-                    uint32_t off;
-                    if (code == 0x10u) {
-                        off = hist0;
-                    } else {
-                        const uint32_t idx = code - 1u + ((w0 & kRecFlag) ? 1u : 0u);
-                        if (idx == 0u) {
+    }
+    __threadfence();
+    __syncthreads();
+    uint32_t err = L.err;
+    // ---- in frame order, one wave: the prefixes written with an unknown history replayed; where each block's output starts
+    if (wave == 0u && !err) {
+        uint32_t hist0 = 1u, hist1 = 4u, hist2 = 8u, out_top = 0, rerr = 0, nrec_all = 0;
+        for (uint32_t b = 0; b < nblk; ++b) {
+            ZBlk& d = blk[b];
+            const uint32_t n_sym = __hip_atomic_load(&d.n_sym, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            uint64_t* const rj = recs + d.rec_at;
+            for (uint32_t k0 = 0; k0 < n_sym; k0 += 64u) {
+                // 64 records at a time into the lanes, walked by readlane (uniform); the stores by the lane that holds the record
+                const uint32_t k = k0 + lane;
+                const uint64_t w = k < n_sym ? __hip_atomic_load(&rj[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+                const uint32_t w0v = static_cast<uint32_t>(w);
+                uint32_t fixed = w0v;
+                const uint32_t cnt = n_sym - k0 < 64u ? n_sym - k0 : 64u;
+                uint64_t todo = __builtin_amdgcn_ballot_w64(k < n_sym && ((w0v & kRecRep) || !(w0v & kRecFlag)));
+                (void)cnt;
+                while (todo) {
+                    const uint32_t q = static_cast<uint32_t>(__builtin_ctzll(todo));
+                    todo &= todo - 1ull;
+                    const uint32_t w0 = __builtin_amdgcn_readlane(w0v, q);
+                    if (w0 & kRecRep) {
+                        const uint32_t code = w0 & 0xFFu;
+                        uint32_t off;
+                        if (code == 0x10u) {
                             off = hist0;
-                        } else if (idx == 1u) {
-                            off = hist1;
-                            hist1 = hist0;
-                            hist0 = off;
-                        } else if (idx == 2u) {
-                            off = hist2;
-                            hist2 = hist1;
-                            hist1 = hist0;
-                            hist0 = off;
                         } else {
-                            off = hist0 - 1u;
-                            hist2 = hist1;
-                            hist1 = hist0;
-                            hist0 = off;
+                            const uint32_t idx = code - 1u + ((w0 & kRecFlag) ? 1u : 0u);
+                            if (idx == 0u) {
+                                off = hist0;
+                            } else if (idx == 1u) {
+                                off = hist1;
+                                hist1 = hist0;
+                                hist0 = off;
+                            } else if (idx == 2u) {
+                                off = hist2;
+                                hist2 = hist1;
+                                hist1 = hist0;
+                                hist0 = off;
+                            } else {
+                                off = hist0 - 1u;
+                                hist2 = hist1;
+                                hist1 = hist0;
+                                hist0 = off;
+                            }
+                            if (off == 0u) rerr = kZstdBadOffset;
                         }
-                        if (off == 0u) rerr = kZstdBadOffset;
+                        fixed = lane == q ? (off & 0x3FFFFFFFu) : fixed;
+                    } else {
+                        hist2 = hist1;
+                        hist1 = hist0;
+                        hist0 = w0;
                     }
-                    if (lane == 0u) rj[k] = (w & 0xFFFFFFFF00000000ull) | (off & 0x3FFFFFFFu);
-                } else if (!(w0 & kRecFlag)) {
-                    hist2 = hist1;
-                    hist1 = hist0;
-                    hist0 = w0;
                 }
+                if (k < n_sym && (w0v & kRecRep)) rj[k] = (w & 0xFFFFFFFF00000000ull) | fixed;
             }
-            if (s.hist_known) {
-                hist0 = s.hist[0];
-                hist1 = s.hist[1];
-                hist2 = s.hist[2];
+            if (__hip_atomic_load(&d.hist_known, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
+                hist0 = __hip_atomic_load(&d.hist[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hist1 = __hip_atomic_load(&d.hist[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hist2 = __hip_atomic_load(&d.hist[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
+            if (lane == 0u) d.out_at = out_top;
+            out_top += __hip_atomic_load(&d.out_len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            nrec_all += __hip_atomic_load(&d.nrec, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (rerr) {
-            fail(rerr);
-            break;
+        if (!rerr && out_top != dst_len) rerr = kZstdBadSize;
+        if (lane == 0u) {
+            if (rerr) atomicMax(&L.err, rerr);
+            hdr->nrec = nrec_all;
+            hdr->out_len = out_top;
+            if (!rerr) atomicAdd(&tally[0], static_cast<unsigned long long>(nrec_all));
         }
-        // checkpoints: positions in the frame, records valid; the slots a block did not use point at its end
-        for (uint32_t j = 0; j < nb; ++j) {
-            const ZeShare& s = L.sh[j];
-            const uint32_t first_slot = s.rec_at >> 6, nslot = s.rec_cap >> 6;
+    }
+    __threadfence();
+    __syncthreads();
+    err = L.err;
+    // ---- checkpoints: positions in the frame, records valid; the slots a block did not use point at its end
+    if (!err) {
+        for (uint32_t b = wave; b < nblk; b += kZvWaves) {
+            const ZBlk& d = blk[b];
+            const uint32_t out_at = __hip_atomic_load(&d.out_at, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const uint32_t nrec = d.nrec, out_len = d.out_len;
+            const uint32_t first_slot = d.rec_at >> 6, nslot = d.rec_cap >> 6;
             for (uint32_t q = lane; q < nslot; q += 64u) {
                 const uint32_t first = q * 64u;
                 uint4 c;
-                if (first < s.nrec) {
+                if (first < nrec) {
                     c = ck[first_slot + q];
-                    c.x += out_top;
-                    c.y += s.lit_at;
-                    c.z = s.nrec - first < 64u ? s.nrec - first : 64u;
+                    c.x += out_at;
+                    c.y += d.lit_at;
+                    c.z = nrec - first < 64u ? nrec - first : 64u;
                 } else {
-                    c = make_uint4(out_top + s.out_len, s.lit_at + s.nlit, 0u, 0u);
+                    c = make_uint4(out_at + out_len, d.lit_at + d.nlit, 0u, 0u);
                 }
                 ck[first_slot + q] = c;
             }
-            out_top += s.out_len;
-            nrec_all += s.nrec;
         }
-        __syncthreads();
     }
-    if (!err && p != n) fail(kZstdTrailingData);
-    if (!err && out_top != dst_len) fail(kZstdBadSize);
-    if (lane == 0u) {
-        hdr->nslots = err ? 0u : rec_top >> 6;
-        hdr->nrec = nrec_all;
-        hdr->out_len = out_top;
-        hdr->nblk = nblk;
-        status[fi] = err;
-        if (!err) atomicAdd(&tally[0], static_cast<unsigned long long>(nrec_all));
+    if (threadIdx.x == 0u) {
+        if (err) status[fi] = err;
         if (PROF) {
-            atomicAdd(&tally[17], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
-            atomicAdd(&tally[18], t_lit);
-            atomicAdd(&tally[19], t_tab);
-            atomicAdd(&tally[20], t_seq);
-            atomicAdd(&tally[21], t_chain);
-            atomicAdd(&tally[22], t_vec);
-            atomicAdd(&tally[23], n_refill);
-            atomicAdd(&tally[24], t_v1);
-            atomicAdd(&tally[25], t_v2);
-            atomicAdd(&tally[26], t_v3);
-            atomicAdd(&tally[27], n_rep);
+            atomicAdd(&tally[23], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
         }
+    }
+    if (PROF && lane == 0u) {
+        atomicAdd(&tally[24], n_rounds);
+        atomicAdd(&tally[25], n_batches);
     }
 }
 
 // ------------------------------------------------------------------------------------------------ zstd_execute
-constexpr uint32_t kZxEmit = 3, kZxScan = 3;
+constexpr uint32_t kZxEmit = kZstdEmitters, kZxScan = kZstdScanners;   // (six emitters: a batch with far matches waits a microsecond or two for the global loads)
 constexpr uint32_t kZxThreads = 64u * (kZxEmit + kZxScan + 1u);
 constexpr uint32_t kZxNear = 65535u;   // matches up to this far back read the ring; farther ones the flushed output
 
@@ -1155,13 +1318,14 @@ struct __attribute__((aligned(16))) ZxLds {
     uint8_t ring[kNR];
     uint32_t mark[kMR];
     uint32_t fsrc[kK];
-    uint32_t e_pos[kZxEmit], f_op;       // per emitter: where its first unfinished batch starts; copier: output flushed AND landed (16 bytes)
+    uint32_t e_pos[8];                   // per emitter: where its first unfinished batch starts (unused slots: the end; two 16-byte reads)
+    uint32_t f_op, pad_[3];              // copier: output flushed AND landed
     uint32_t s_clr[kZxScan], d_op;       // (16 bytes: one read)
     uint32_t s_done[kZxScan];
     uint32_t c_ready, s_carry[8], err;
 };
 static_assert(ZxLds::kSpan + ZxLds::kChunk <= ZxLds::kMR && ZxLds::kSpan + ZxLds::kChunk + ZxLds::kK <= ZxLds::kAhead + ZxLds::kChunk, "no cyclic wait");
-static_assert(sizeof(ZxLds) <= 81920, "two workgroups per CU");
+static_assert(sizeof(ZxLds) <= 81920 && kZxEmit <= 8, "two workgroups per CU");
 
 // ---- emitters: records -> markers, literal bytes.  Emitter `which` takes the batches (64 records, one checkpoint)
 // which, which + kZxEmit, ...; a checkpoint carries the batch's output and literal positions, so the emitters do not depend
@@ -1380,7 +1544,7 @@ __global__ __launch_bounds__(kZxThreads, 4) void zstd_execute(const GpuBlock* __
     const uint32_t nslots = hdr.nslots <= lay.ck_stride ? hdr.nslots : 0u;
     for (uint32_t i = threadIdx.x; i < ZxLds::kMR; i += kZxThreads) L.mark[i] = 0u;
     if (threadIdx.x == 0u) {
-        for (uint32_t i = 0; i < kZxEmit; ++i) L.e_pos[i] = 0u;
+        for (uint32_t i = 0; i < 8u; ++i) L.e_pos[i] = i < kZxEmit ? 0u : ~0u;
         L.f_op = 0u;
         for (uint32_t i = 0; i < kZxScan; ++i) {
             L.s_clr[i] = i * ZxLds::kChunk;
@@ -1396,8 +1560,8 @@ __global__ __launch_bounds__(kZxThreads, 4) void zstd_execute(const GpuBlock* __
     else if (role < kZxEmit + kZxScan) {
         // the position below which every marker and literal byte is in place: the first batch some emitter has not finished
         auto frontier = []() -> uint32_t {
-            const uint4 a = wg_ld4(L.e_pos);
-            return umin3(a.x, a.y, a.z);
+            const uint4 a = wg_ld4(L.e_pos), c = wg_ld4(L.e_pos + 4);
+            return umin(umin(umin3(a.x, a.y, a.z), a.w), umin(umin3(c.x, c.y, c.z), c.w));
         };
         wgpipe_scan<PROF>(L, b.dst_len, lane, role - kZxEmit, frontier, tally);
     } else
@@ -1420,11 +1584,16 @@ extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* 
     if (lay.total > scratch_bytes) return hipErrorInvalidValue;
     uint8_t* const sc = static_cast<uint8_t*>(scratch);
     const dim3 grid(nblocks);
+    const dim3 pairs((nblocks + fsk::kZcFrames - 1u) / fsk::kZcFrames);
     if (prof) {
-        hipLaunchKernelGGL((fsk::zstd_entropy<true>), grid, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_prepare<true>), grid, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_chain<true>), pairs, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_records<true>), grid, dim3(64 * fsk::kZvWaves), 0, stream, blocks, sc, lay, status, tally);
         hipLaunchKernelGGL((fsk::zstd_execute<true>), grid, dim3(fsk::kZxThreads), 0, stream, blocks, sc, lay, out, status, tally);
     } else {
-        hipLaunchKernelGGL((fsk::zstd_entropy<false>), grid, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_prepare<false>), grid, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_chain<false>), pairs, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_records<false>), grid, dim3(64 * fsk::kZvWaves), 0, stream, blocks, sc, lay, status, tally);
         hipLaunchKernelGGL((fsk::zstd_execute<false>), grid, dim3(fsk::kZxThreads), 0, stream, blocks, sc, lay, out, status, tally);
     }
     return hipGetLastError();
