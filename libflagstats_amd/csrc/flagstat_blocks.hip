@@ -510,6 +510,8 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
         st->decode_cpu_s = pipe.decode_cpu_s;
         st->threads = threads;
         st->chunks = static_cast<int32_t>(chunks.size());
+        st->gpu_decode = 0;
+        st->reserved = 0;
     }
     return 0;
 }

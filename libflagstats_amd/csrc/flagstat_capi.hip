@@ -262,7 +262,9 @@ uint64_t FLAGSTATS_hip_get(const char* key)
         Engine* e = fsint::default_engine();
         if (!e) return 0;
         std::lock_guard<std::mutex> lk(e->mu);
-        return e->lz4_cap[0] + e->lz4_cap[1];
+        uint64_t held = e->lz4_cap[0] + e->lz4_cap[1];
+        for (uint64_t c : e->zstd_scratch_cap) held += c;
+        return held;
     }
     if (!std::strcmp(key, "fence_free_events")) return static_cast<uint64_t>(k.fence_free_events.load());
     if (!std::strcmp(key, "grid")) {

@@ -54,7 +54,7 @@ struct Knobs {
     std::atomic<uint64_t> lz4_gpu_keep_bytes{~0ull};  // device bytes the GPU LZ4 decoder may keep between calls; ~0 = automatic: what the
                                                   // last call needed, at most a quarter of the device, until 8 other calls have passed
     std::atomic<int> zstd_decoder{2};             // Zstandard block files: 0 = libzstd on host threads, 1 = decode on the GPU, 2 = by size
-    std::atomic<uint64_t> zstd_gpu_min_bytes{48ull << 20};  // zstd_decoder 2: GPU decode for files of at least this many bytes
+    std::atomic<uint64_t> zstd_gpu_min_bytes{64ull << 20};  // zstd_decoder 2: GPU decode for files of at least this many bytes
     std::atomic<int> fence_free_events{0};        // stream_wait_stream: 1 = ordering events without the system-scope fence (opt-in)
     std::atomic<int> numa{1};                     // block pipeline: 1 = pinned chunks + decoders on the GPU's NUMA node
 };

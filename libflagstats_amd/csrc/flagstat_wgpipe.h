@@ -5,7 +5,7 @@
 //
 // The LDS type a kernel passes in holds
 //   uint8_t ring[kNR]; uint32_t mark[kMR]; uint32_t fsrc[kK];
-//   uint32_t s_clr[kScan], d_op;   (16 bytes, aligned: read with one wg_ld4)
+//   uint32_t s_clr[kScan .. 7], d_op;   (16 or 32 bytes, aligned: read with one or two wg_ld4 by the kernel's own front end)
 //   uint32_t s_done[kScan]; uint32_t c_ready, s_carry[8], err;   (and f_op when kPublishFlush)
 // and the constants kNR, kMR, kK, kChunk, kFlush, kScan, kPublishFlush.
 #ifndef FLAGSTAT_WGPIPE_H_

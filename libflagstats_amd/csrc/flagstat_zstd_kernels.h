@@ -15,7 +15,7 @@ namespace fsk {
 constexpr uint32_t kZstdMaxBlocks = 256;        // Zstandard blocks per frame the GPU decoder takes (more: status kZstdTooManyBlocks)
 constexpr uint32_t kZstdMaxFrameBytes = 1u << 26;  // decoded bytes per frame it takes
 constexpr int kZstdTallyWords = 32;             // unsigned long long words of the tally the kernels add to
-constexpr int kZstdEmitters = 6, kZstdScanners = 3;  // waves per role of the execution kernel (profile output divides by them)
+constexpr int kZstdEmitters = 4, kZstdScanners = 5;  // waves per role of the execution kernel (profile output divides by them)
 
 // Status codes of a frame.  1..63: the frame is damaged; from 64: valid Zstandard this decoder does not take (skippable or
 // concatenated frames, dictionaries, content checksums, more than kZstdMaxBlocks blocks, frames above kZstdMaxFrameBytes) --

@@ -94,12 +94,10 @@ __device__ const int8_t kLLDefault[36] = {4, 3, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2, 2,
 __device__ const int8_t kMLDefault[53] = {1, 4, 3, 2, 2, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1, -1, -1};
 __device__ const int8_t kOFDefault[29] = {1, 1, 1, 1, 1, 1, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, -1, -1, -1, -1, -1};
 
-struct ZeTables {  // one lane's tables: Huffman while the literals are decoded, FSE afterwards
+struct ZeTables {  // one lane's table: Huffman while the literals are decoded, one FSE table at a time afterwards
     union {
         uint16_t huf[2048];  // symbol | bits << 8, indexed by the next max-bits bits of the stream
-        struct {
-            uint32_t ll[512], of[256], ml[512];  // symbol | state bits << 6 | extra bits << 10 | base << 16
-        } fse;
+        uint32_t fse[512];   // symbol | state bits << 6 | extra bits << 10 | base << 16
     };
 };
 struct ZeShare {  // what a lane tells the others about its block
@@ -282,7 +280,7 @@ __device__ uint32_t huf_build(const uint8_t* frame, uint32_t at, uint32_t limit,
         const uint32_t end = at + 1u + hb;
         uint32_t log, tafter;
         if (!fse_read_counts(frame, at + 1u, end, 12u, 6u, counts, log, tafter)) return 0u;
-        uint32_t* table = T.fse.ll;  // (the Huffman table is built after the weights are out)
+        uint32_t* table = T.fse;  // (the Huffman table is built after the weights are out)
         if (!fse_build(table, counts, 13u, log, [](uint32_t) { return 0u; })) return 0u;
         if (tafter >= end || frame[end - 1u] == 0u) return 0u;
         int32_t left = static_cast<int32_t>((end - tafter) * 8u) - static_cast<int32_t>(8u - highbit(frame[end - 1u]));  // bits below the end mark
@@ -709,11 +707,28 @@ __global__ __launch_bounds__(64) void zstd_prepare(const uint8_t* __restrict__ c
         const unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0ull;
         uint32_t logl = 0, logo = 0, logm = 0;
         bool seq_act = mine && my_type == 2u && nseq > 0u && !lerr;
+        // One table at a time, built in the lane's LDS area and sent off at once: to the chain kernel as next-state number | extra
+        // bits << 10 (the bits of the next state are log - highbit(number), its base (number << bits) - size), to the records
+        // kernel the symbols.
         if (seq_act) {
-            ZeTables& T = L.tab[lane];
-            logl = seq_table(frame, n, tab_src[0], T.fse.ll, L.counts[lane], kLLDefault, 36u, 6u, 35u, 9u, [](uint32_t s) { return s < 36u ? static_cast<uint32_t>(kLLBits[s]) : 0u; });
-            logo = seq_table(frame, n, tab_src[1], T.fse.of, L.counts[lane], kOFDefault, 29u, 5u, 31u, 8u, [](uint32_t s) { return s; });
-            logm = seq_table(frame, n, tab_src[2], T.fse.ml, L.counts[lane], kMLDefault, 53u, 6u, 52u, 9u, [](uint32_t s) { return s < 53u ? static_cast<uint32_t>(kMLBits[s]) : 0u; });
+            uint32_t* const work = L.tab[lane].fse;
+            uint8_t* const tg = tabs + static_cast<uint64_t>(nblk - nb + lane) * kTabBytes;
+            uint16_t* const t16 = reinterpret_cast<uint16_t*>(tg);
+            auto emit = [&](uint32_t log, uint32_t at16, uint32_t sym_at) {
+                const uint32_t size = 1u << log;
+                _Pragma("unroll 1") for (uint32_t u = 0; u < size; ++u) {
+                    const uint32_t e = work[u];
+                    const uint32_t nbits = (e >> 6) & 15u;
+                    t16[at16 + u] = static_cast<uint16_t>((((e >> 16) + size) >> nbits) | (((e >> 10) & 31u) << 10));
+                    if (sym_at) tg[sym_at + u] = static_cast<uint8_t>(e & 63u);
+                }
+            };
+            logl = seq_table(frame, n, tab_src[0], work, L.counts[lane], kLLDefault, 36u, 6u, 35u, 9u, [](uint32_t s) { return s < 36u ? static_cast<uint32_t>(kLLBits[s]) : 0u; });
+            if (logl != ~0u) emit(logl, 0u, kTabSymLL);
+            logo = seq_table(frame, n, tab_src[1], work, L.counts[lane], kOFDefault, 29u, 5u, 31u, 8u, [](uint32_t s) { return s; });
+            if (logo != ~0u) emit(logo, kTabOF / 2u, 0u);
+            logm = seq_table(frame, n, tab_src[2], work, L.counts[lane], kMLDefault, 53u, 6u, 52u, 9u, [](uint32_t s) { return s < 53u ? static_cast<uint32_t>(kMLBits[s]) : 0u; });
+            if (logm != ~0u) emit(logm, kTabML / 2u, kTabSymML);
             if (logl == ~0u || logo == ~0u || logm == ~0u) {
                 lerr = kZstdBadSequences;
                 seq_act = false;
@@ -721,24 +736,6 @@ __global__ __launch_bounds__(64) void zstd_prepare(const uint8_t* __restrict__ c
                 lerr = kZstdBadBitstream;
                 seq_act = false;
             }
-        }
-        // ---- the tables leave for the chain kernel (x = next-state number | extra bits << 10: the bits of the next state
-        // are log - highbit(x), its base (x << bits) - size) and for the records kernel (symbols)
-        if (seq_act) {
-            const ZeTables& T = L.tab[lane];
-            uint8_t* const tg = tabs + static_cast<uint64_t>(nblk - nb + lane) * kTabBytes;
-            uint16_t* const t16 = reinterpret_cast<uint16_t*>(tg);
-            auto emit = [&](const uint32_t* src, uint32_t size, uint32_t at16, uint32_t sym_at) {
-                _Pragma("unroll 1") for (uint32_t u = 0; u < size; ++u) {
-                    const uint32_t e = src[u];
-                    const uint32_t nbits = (e >> 6) & 15u;
-                    t16[at16 + u] = static_cast<uint16_t>((((e >> 16) + size) >> nbits) | (((e >> 10) & 31u) << 10));
-                    if (sym_at) tg[sym_at + u] = static_cast<uint8_t>(e & 63u);
-                }
-            };
-            emit(T.fse.ll, 1u << logl, 0u, kTabSymLL);
-            emit(T.fse.of, 1u << logo, kTabOF / 2u, 0u);
-            emit(T.fse.ml, 1u << logm, kTabML / 2u, kTabSymML);
         }
         if (PROF) t_tab += __builtin_readcyclecounter() - t1;
         if (__builtin_amdgcn_ballot_w64(lerr != 0u)) {
@@ -1051,20 +1048,31 @@ __global__ __launch_bounds__(64 * kZvWaves) void zstd_records(const GpuBlock* __
                 st_out = in ? e[0] : 0u;
                 w_out = in ? (static_cast<uint64_t>(e[2]) << 32) | e[1] : 0ull;
             };
-            // the stash of the first batch; the next one is loaded while this one is worked on
-            uint32_t st_n;
-            uint64_t w_n;
-            load_stash(lane, st_n, w_n);
+            // Two batches ahead the stash is loaded, one batch ahead the symbols of its states are gathered from the tables: a
+            // batch never waits for global memory.
+            auto gather = [&](uint32_t st, uint32_t& lsym_out, uint32_t& msym_out, uint32_t& oc_out) {
+                const uint32_t sl = st & 511u, so = (st >> 9) & 255u, sm = st >> 17;
+                lsym_out = tg[kTabSymLL + sl];
+                msym_out = tg[kTabSymML + sm];
+                oc_out = static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(tg + kTabOF)[so]) >> 10;
+            };
+            uint32_t st_a, st_b;
+            uint64_t w_a, w_b;
+            uint32_t lsym_a, msym_a, oc_a;
+            load_stash(lane, st_a, w_a);
+            load_stash(64u + lane, st_b, w_b);
+            gather(st_a, lsym_a, msym_a, oc_a);
             for (uint32_t done = 0; done < nseq && !berr; done += 64u) {
                 const uint32_t nq = nseq - done < 64u ? nseq - done : 64u;
                 const bool valid = lane < nq;
-                const uint32_t st = st_n;
-                uint64_t w = w_n;
-                load_stash(done + 64u + lane, st_n, w_n);
+                uint64_t w = w_a;
+                const uint32_t lsym = lsym_a, msym = msym_a, oc = oc_a;
+                // (for the next batch and the one after it)
+                gather(st_b, lsym_a, msym_a, oc_a);
+                st_a = st_b;
+                w_a = w_b;
+                load_stash(done + 128u + lane, st_b, w_b);
                 if (PROF) ++n_batches;
-                const uint32_t sl = st & 511u, so = (st >> 9) & 255u, sm = st >> 17;
-                const uint32_t lsym = tg[kTabSymLL + sl], msym = tg[kTabSymML + sm];
-                const uint32_t oc = static_cast<uint32_t>(reinterpret_cast<const uint16_t*>(tg + kTabOF)[so]) >> 10;
                 const uint32_t lle = L.ll_base[lsym < 36u ? lsym : 35u], mle = L.ml_base[msym < 53u ? msym : 52u];
                 const uint32_t obits = take(w, oc), mbits = take(w, mle >> 24), lbits = take(w, lle >> 24);
                 const uint32_t ofv = (1u << oc) + obits;
@@ -1320,12 +1328,12 @@ struct __attribute__((aligned(16))) ZxLds {
     uint32_t fsrc[kK];
     uint32_t e_pos[8];                   // per emitter: where its first unfinished batch starts (unused slots: the end; two 16-byte reads)
     uint32_t f_op, pad_[3];              // copier: output flushed AND landed
-    uint32_t s_clr[kZxScan], d_op;       // (16 bytes: one read)
+    uint32_t s_clr[7], d_op;             // per scanner: start of the next chunk it will clear (unused slots: ~0); copier: end of the last chunk copied (two 16-byte reads)
     uint32_t s_done[kZxScan];
     uint32_t c_ready, s_carry[8], err;
 };
 static_assert(ZxLds::kSpan + ZxLds::kChunk <= ZxLds::kMR && ZxLds::kSpan + ZxLds::kChunk + ZxLds::kK <= ZxLds::kAhead + ZxLds::kChunk, "no cyclic wait");
-static_assert(sizeof(ZxLds) <= 81920 && kZxEmit <= 8, "two workgroups per CU");
+static_assert(sizeof(ZxLds) <= 81920 && kZxEmit <= 8 && kZxScan <= 7, "two workgroups per CU");
 
 // ---- emitters: records -> markers, literal bytes.  Emitter `which` takes the batches (64 records, one checkpoint)
 // which, which + kZxEmit, ...; a checkpoint carries the batch's output and literal positions, so the emitters do not depend
@@ -1341,9 +1349,9 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
     auto room = [&](uint32_t at, uint32_t nbytes) -> bool {
         if (__builtin_expect(at + nbytes <= s_seen + ZxLds::kMR && at + nbytes <= d_seen + ZxLds::kAhead, 1)) return true;
         return wg_wait_timed<PROF>(L, t_wait, [&] {
-            const uint4 t = wg_ld4(L.s_clr);
-            s_seen = umin3(t.x, t.y, t.z);
-            d_seen = t.w;
+            const uint4 t = wg_ld4(L.s_clr), u = wg_ld4(L.s_clr + 4);
+            s_seen = umin(umin(umin3(t.x, t.y, t.z), t.w), umin3(u.x, u.y, u.z));
+            d_seen = u.w;
             return at + nbytes <= s_seen + ZxLds::kMR && at + nbytes <= d_seen + ZxLds::kAhead;
         });
     };
@@ -1546,10 +1554,8 @@ __global__ __launch_bounds__(kZxThreads, 4) void zstd_execute(const GpuBlock* __
     if (threadIdx.x == 0u) {
         for (uint32_t i = 0; i < 8u; ++i) L.e_pos[i] = i < kZxEmit ? 0u : ~0u;
         L.f_op = 0u;
-        for (uint32_t i = 0; i < kZxScan; ++i) {
-            L.s_clr[i] = i * ZxLds::kChunk;
-            L.s_done[i] = 0u;
-        }
+        for (uint32_t i = 0; i < 7u; ++i) L.s_clr[i] = i < kZxScan ? i * ZxLds::kChunk : ~0u;
+        for (uint32_t i = 0; i < kZxScan; ++i) L.s_done[i] = 0u;
         L.d_op = 0u;
         L.c_ready = 0u;
         L.err = 0u;

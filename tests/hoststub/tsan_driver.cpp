@@ -141,6 +141,39 @@ static void gpu_decoder_host_side(const std::vector<uint16_t>& flags, const uint
             FLAGSTATS_hip_set("lz4_decoder", 1);
         }
     }
+    // the same orchestration with Zstandard frames (scratch between the kernels per decode stream, two pieces at least)
+    if (!dir.empty() && FLAGSTATS_hip_zstd_available()) {
+        FLAGSTATS_hip_set("zstd_decoder", 1);
+        for (const char* name : {"zexact1_c1.zst", "zragged_c3.zst", "ztiny_c19.zst"}) {
+            uint64_t a[32] = {0}, b[32] = {0}, c[32] = {0};
+            FLAGSTATS_blockfile_stats st;
+            for (int readers : {1, 5}) {
+                for (uint64_t& v : a) v = 0;
+                CHECK(FLAGSTATS_hip_blockfile_zstd((dir + "/" + name).c_str(), readers, a, &st) == 0 && st.gpu_decode == 1, "%s on the GPU decoder's host side, %d readers: %s",
+                      name, readers, FLAGSTATS_hip_last_error());
+            }
+            FLAGSTATS_hip_set("zstd_decoder", 0);
+            const int rc_h = FLAGSTATS_hip_blockfile_zstd((dir + "/" + name).c_str(), 5, b, &st);
+            CHECK(rc_h == 0 && st.gpu_decode == 0 && same(a, b), "%s: host pipeline gives the same (rc %d, gpu_decode %d, a[0] %llu b[0] %llu, a[16] %llu b[16] %llu: %s)", name, rc_h,
+                  st.gpu_decode, (unsigned long long)a[0], (unsigned long long)b[0], (unsigned long long)a[16], (unsigned long long)b[16], FLAGSTATS_hip_last_error());
+            FLAGSTATS_hip_set("zstd_decoder", 1);
+            std::vector<unsigned char> zimg;
+            if (FILE* f = std::fopen((dir + "/" + name).c_str(), "rb")) {
+                unsigned char buf[65536];
+                size_t got;
+                while ((got = std::fread(buf, 1, sizeof buf, f)) > 0) zimg.insert(zimg.end(), buf, buf + got);
+                std::fclose(f);
+            }
+            CHECK(FLAGSTATS_hip_blockimage_zstd(zimg.data(), zimg.size(), 0, c, &st) == 0 && st.gpu_decode == 1 && same(a, c), "%s as an image", name);
+            if (zimg.size() > 40) {
+                zimg[8] ^= 0x5A;  // the first frame's magic number
+                uint64_t d[32] = {0};
+                CHECK(FLAGSTATS_hip_blockimage_zstd(zimg.data(), zimg.size(), 0, d, nullptr) != 0, "%s damaged must fail", name);
+                CHECK(FLAGSTATS_hip_get("lz4_gpu_kept_bytes") == 0, "a failed call keeps nothing on the device");
+            }
+        }
+        FLAGSTATS_hip_set("zstd_decoder", 2);
+    }
     FLAGSTATS_hip_set("chunk_flags", 32ull << 20);
     FLAGSTATS_hip_set("lz4_decoder", 2);
 }

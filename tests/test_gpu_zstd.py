@@ -162,7 +162,7 @@ def test_gpu_zstd_decoder_is_chosen_by_size_and_rejects_loudly(zgpu, tmp_path):
     assert st["gpu_decode"] == 0 and np.array_equal(got, expect_blocks([raw]))
     got, st = blockfile.flagstat_zstd_image(img, 2)
     assert st["gpu_decode"] == 1 and np.array_equal(got, want)
-    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 48 << 20) == 0
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 64 << 20) == 0
     assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
 
 

@@ -1,5 +1,5 @@
 #!/bin/bash
-# rocprofv3 kernel + memory-copy trace of ONE GPU-decoded LZ4 image: when does every piece land, when does its decode
+# rocprofv3 kernel + memory-copy trace of ONE GPU-decoded LZ4 (or Zstandard: mode zstd:1) image: when does every piece land, when does its decode
 # launch start and end.   gpurun -- 'bash tools/profile_lz4_timeline.sh 1073741824 fast:2'
 set -x
 N=${1:-1073741824}; MODE=${2:-fast:2}
@@ -21,6 +21,9 @@ for r in csv.DictReader(open(mc)):
 for r in csv.DictReader(open(kt)):
     if "lz4_decode" in r["Kernel_Name"]:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "decode %4d blocks" % (int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])), int(r.get("Queue_Id", 0) or 0)))
+    elif "zstd_" in r["Kernel_Name"]:
+        name = r["Kernel_Name"].split("zstd_")[1].split("<")[0].split("I")[0]
+        ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "%-8s %4d wg" % (name, int(r["Grid_Size_X"]) // int(r["Workgroup_Size_X"])), int(r.get("Queue_Id", 0) or 0)))
     elif "flagstat_count" in r["Kernel_Name"] and int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) > 50000:
         ev.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), "K1", int(r.get("Queue_Id", 0) or 0)))
 ev.sort()
