@@ -188,7 +188,14 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *                    workgroup per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default
  *                    64 MiB compressed: the measured break-even of an LZ4-fast file, an LZ4-HC file wins from 40 MiB,
  *                    profiles/r04/lz4_decoder_sweep.log), on the host below.  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
- *   "lz4_gpu_keep_bytes" device memory the GPU LZ4 decoder may keep between calls: its two buffers -- a segment's
+ *   "zstd_decoder"   Zstandard block files (blockfile_zstd, blockimage_zstd, blockfile): 0 = libzstd on host threads, 1 = decode
+ *                    on the GPU (four kernels: Huffman literals + FSE tables, the serial walk of the FSE states, sequence
+ *                    records, execution; a frame the decoder does not take -- dictionary, content checksum, concatenated
+ *                    or skippable frames, damage -- fails the call with its status code), 2 (default) = on the GPU for
+ *                    files of at least "zstd_gpu_min_bytes" (default 64 MiB: the measured break-even,
+ *                    profiles/r04/zstd_decoder_sweep.log), and a file with a frame the GPU decoder does not take is
+ *                    decoded by libzstd on the host threads instead.  env FLAGSTATS_HIP_ZSTD_DECODER / FLAGSTATS_HIP_ZSTD_GPU_MIN_BYTES
+ *   "lz4_gpu_keep_bytes" device memory the GPU LZ4 / Zstandard decoder may keep between calls: its two buffers -- a segment's
  *                    compressed and decoded bytes -- are reused by the next file (allocating them right after freeing
  *                    them was measured to stall ~0.5 s on the driver wiping the freed memory).  Default ~0 = automatic:
  *                    what the last call needed, at most a quarter of the device; in every mode they are released once
@@ -268,7 +275,9 @@ int FLAGSTATS_hip_blockimage_lz4(const void* image, uint64_t bytes, int threads,
 /* Zstandard block files (.zst: benchmark/flagstats.cpp:192-226 writer, :636-682 reader): same block header,
  * payload = one Zstandard frame.  libzstd stays the third-party dependency it is in the reference; it is
  * resolved at run time (libzstd.so.1, or env FLAGSTATS_HIP_ZSTD_LIB) when a .zst file is opened, and the
- * call fails loudly without it.  Same pipeline, threads and stats as the LZ4 entries. */
+ * call fails loudly without it.  Same pipeline, threads and stats as the LZ4 entries.  Files of 64 MiB and more are
+ * decoded on the GPU instead (knob "zstd_decoder"; stats->gpu_decode = 1), which needs libzstd only for files with
+ * frames the GPU decoder does not take. */
 int FLAGSTATS_hip_blockfile_zstd(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 int FLAGSTATS_hip_blockimage_zstd(const void* image, uint64_t bytes, int threads, uint64_t* out,
                                   FLAGSTATS_blockfile_stats* stats);

@@ -1,29 +1,36 @@
 // flagstat_zstd_kernels.hip -- Zstandard frame decode ON the GPU (row f1: the reference decodes every .zst block payload
 // with libzstd's ZSTD_decompress on the host, benchmark/flagstats.cpp:636-682).  Device code only; the host orchestration
 // is flagstat_lz4_gpu.hip (shared with the LZ4 decoder).  Written from RFC 8878; tests/zstd_model.py restates the format
-// and tests/zstd_gpu_model.py the two stages below, both pinned against libzstd on the CPU.
+// and tests/zstd_gpu_model.py the record / checkpoint layout, both pinned against libzstd on the CPU.
 //
 // A frame of the reference's writer is 1,024,000 decoded bytes in eight blocks of 128 KiB; a block is a Huffman-coded
 // literals section and an FSE-coded sequences section (literal length, match length, offset), one serial bit stream
-// each, read BACKWARDS.  Two kernels per piece of a file:
+// each, read BACKWARDS.  The one truly serial piece of work is the walk of a block's three FSE states (15 k steps a
+// block); everything around it is taken off that walk.  Four kernels per piece of a file, through scratch in global memory:
 //
-// zstd_entropy -- ONE WAVE PER FRAME, a lane per block (eight blocks side by side, more in further passes):
-//   every lane parses its block's section headers; tables a block repeats from an earlier one are rebuilt by the lane
-//   that needs them from the earlier block's description (no sharing, no ordering between lanes); Huffman streams are
-//   decoded by 32 lanes (four streams a block), four symbols per window; the sequence bit stream of every block is staged
-//   into a 1 KiB ring in LDS by the whole wave (256 bytes a refill) so that one step of the serial chain
-//   "three states -> three table entries -> bits -> three states" is ONE LDS round trip: three 4-byte entries (symbol,
-//   state bits, extra bits, base packed) and a 16-byte window, read together.  What leaves the kernel is flat:
-//   8-byte RECORDS (offset | literal length | match length, runs above 16,383 split), the literal bytes, and one
-//   CHECKPOINT per 64 records (output position, literal position, records valid).  Repeat offsets need the history the
-//   previous block ends with: a lane starts with an unknown history, writes the few repeat codes it cannot resolve as they
-//   are, and one lane replays those prefixes block after block at the end.
-//
-// zstd_execute -- ONE WORKGROUP OF SEVEN WAVES PER FRAME, the pipeline of the LZ4 kernel (flagstat_wgpipe.h) behind a
-//   new front end: three EMIT waves take batches of 64 records (a DPP prefix sum places them; markers and literal bytes
-//   go into the 64 KiB + 4 KiB output ring; a match from farther back than the ring -- 6-30 % of the sequences of a flag
-//   stream -- is read from the output already flushed to global memory and becomes literal bytes), three SCAN waves turn
-//   markers into one final source per byte, one COPY wave gathers, writes and flushes.
+// zstd_prepare -- ONE WAVE PER FRAME, a lane per block (eight side by side, more in further passes): block and section
+//   headers; tables a block repeats from an earlier one are rebuilt by the lane that needs them from the earlier block's
+//   description (no sharing, no ordering between lanes); Huffman streams decoded by 32 lanes (four streams a block), four
+//   symbols per window, into the frame's literal buffer; the three FSE tables of every block built and written out twice:
+//   2-byte CHAIN entries (next-state number | extra bits << 10 -- the bits a state reads are log - highbit(number), its
+//   base (number << bits) - size) and 1-byte symbols.
+// zstd_chain -- ONE WAVE PER TWO FRAMES, a lane per block, the walk and nothing else: a wave costs the same with one lane
+//   or sixty-four and a block's chain tables take 2.5 KB of LDS, so sixteen blocks walk side by side.  A step is ONE LDS
+//   round trip -- three table entries and a 16-byte window of the bit stream (staged through a 512-byte ring per lane,
+//   refilled 128 bytes at a time by the whole wave) -- and ~90 instructions; what it saw (three states, 64 bits of the
+//   window) goes to the stash in global memory.
+// zstd_records -- ONE WORKGROUP PER FRAME, a wave per block, a lane per sequence, 64 at a time: symbols gathered from the
+//   states (a batch ahead), values of the codes, positions by prefix sums, repeat offsets by RELAXATION over the lanes (a
+//   lane's history is its left neighbour's after the neighbour's sequence; three plain offsets in a row fix it whatever
+//   came before: ~6 rounds settle all 64).  What leaves is flat: 8-byte RECORDS (offset | literal length | match length,
+//   runs above 16,383 split) and one CHECKPOINT per 64 records (output position, literal position, records valid).  A
+//   block starts with an unknown offset history: the few repeat codes it cannot resolve stay in the records as they are,
+//   and one wave replays those prefixes in frame order at the end.
+// zstd_execute -- ONE WORKGROUP OF TEN WAVES PER FRAME, the pipeline of the LZ4 kernel (flagstat_wgpipe.h) behind a new
+//   front end: four EMIT waves take batches of 64 records (a DPP prefix sum places them; markers and literal bytes go into
+//   the 64 KiB + 4 KiB output ring; a match from farther back than the ring -- 6-30 % of the sequences of a flag stream --
+//   is read from the output already flushed to global memory and becomes literal bytes), five SCAN waves turn markers into
+//   one final source per byte, one COPY wave gathers, writes and flushes.
 //
 // Every index is masked, clamped or checked; a damaged frame sets its status word and cannot fault; every wait is bounded.
 #include <hip/hip_runtime.h>

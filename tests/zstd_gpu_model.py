@@ -1,11 +1,12 @@
-"""The GPU Zstandard decoder's two stages restated in Python, arithmetic for arithmetic (test infrastructure only).
+"""The GPU Zstandard decoder's record layer restated in Python (test infrastructure only).
 
-flagstat_zstd_kernels.hip decodes a frame in two kernels: `zstd_entropy` turns every block into sequence RECORDS, literal
-bytes and one CHECKPOINT per 64 records; `zstd_execute` turns those into output bytes.  This file follows the first
-kernel's bit arithmetic (16-byte windows over a backward stream, packed FSE entries, the split of long runs, repeat offsets
-resolved per block with an unknown incoming history and replayed afterwards) and the record / checkpoint layout the second
-kernel reads, so that the layout and the corner cases are pinned on the CPU against libzstd (tests/test_zstd_model.py)
-before the device code runs.  zstd_model.py is the plain RFC 8878 restatement this one is checked against."""
+flagstat_zstd_kernels.hip decodes a frame in four kernels: `zstd_prepare` (headers, literals, tables), `zstd_chain` (the
+serial walk of the FSE states), `zstd_records` (sequence RECORDS, one CHECKPOINT per 64 records) and `zstd_execute` (records
+-> output bytes).  This file follows the bit arithmetic of the walk (16-byte windows over a backward stream, packed FSE
+entries) and, exactly, the record / checkpoint layout the execution kernel reads: the split of long runs, repeat offsets
+resolved per block with an unknown incoming history and replayed afterwards in frame order -- so that the layout and its
+corner cases are pinned on the CPU against libzstd (tests/test_zstd_model.py) before the device code runs.
+zstd_model.py is the plain RFC 8878 restatement this one is checked against."""
 import struct
 
 import zstd_model as zm
