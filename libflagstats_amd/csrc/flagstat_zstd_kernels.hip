@@ -980,6 +980,7 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
 // frame done: the repeat codes a block could not resolve because they reach into the block before it are replayed in frame
 // order by one wave, and the checkpoints get their positions in the frame.
 constexpr uint32_t kZvWaves = 8;
+constexpr uint32_t kUnknown = 1u << 31;   // an offset-history slot whose value the block does not know (yet)
 
 struct ZvLds {
     uint32_t ll_base[36], ml_base[53];  // value | extra bits << 24
@@ -1013,7 +1014,7 @@ __global__ __launch_bounds__(64 * kZvWaves) void zstd_records(const GpuBlock* __
         const uint8_t* const tg = tabs + static_cast<uint64_t>(b) * kTabBytes;
         // (all of this wave-uniform) the block's records, output and literal bytes so far; its view of the offset history
         uint32_t nrec = 0, out = 0, lit_pos = 0, n_sym = 0;
-        uint32_t h0 = 0, h1 = 0, h2 = 0, kn = 0;
+        uint32_t h0 = kUnknown, h1 = kUnknown, h2 = kUnknown;   // (a slot this block does not know yet: bit 31)
         uint32_t berr = d.chain_err;
         const uint32_t rec_at = d.rec_at, rec_cap = d.rec_cap;
         auto put = [&](uint32_t w0, uint32_t ll, uint32_t ml) {   // one record, by lane 0
@@ -1094,57 +1095,34 @@ __global__ __launch_bounds__(64 * kZvWaves) void zstd_records(const GpuBlock* __
                 else if (out + out_all > kBlockMax)
                     berr = kZstdBadSize;
                 if (berr) break;
-                // ---- repeat offsets (RFC 8878 3.1.1.5) by relaxation: (p0, p1, p2 | pk) is the history AFTER this lane's sequence,
-                // (q0, q1, q2 | qk) the one before it = the left neighbour's (lane 0: the block's so far); bit i of pk / qk: slot i holds
-                // a value.  A plain offset v makes (v, q0, q1); code 1 / 2 / 3 (+ 1 without literals) picks q0 / q1 / q2 / q0 - 1.
+                // ---- repeat offsets (RFC 8878 3.1.1.5) by relaxation: (p0, p1, p2) is the history AFTER this lane's sequence,
+                // (q0, q1, q2) the one before it = the left neighbour's (lane 0: the block's so far); a slot nobody knows yet has bit
+                // 31 set.  A plain offset v makes (v, q0, q1); code 1 / 2 / 3 (+ 1 without literals) picks q0 / q1 / q2 / q0 - 1 and
+                // moves it to the front.  Which slot goes where is fixed per lane, so a round is three shifts and five selects.
                 const bool isrep = valid && ofv <= 3u;
                 const uint32_t idx = ofv - 1u + (llv == 0u ? 1u : 0u);   // (for repeat codes: 0..3)
                 const uint32_t kind = !valid ? 5u : (isrep ? idx : 4u);  // 0..3 repeat, 4 plain offset, 5 nothing
-                uint32_t p0 = ofv - 3u, p1 = 0u, p2 = 0u, pk = kind == 4u ? 1u : 0u;
-                uint32_t q0 = 0u, q1 = 0u, q2 = 0u, qk = 0u;
+                const bool push = kind == 4u, take1 = kind == 1u, take2 = kind == 2u, dec = kind == 3u;
+                const bool sel1 = kind >= 1u && kind <= 4u, sel2 = kind >= 2u && kind <= 4u;   // second slot <- q0, third slot <- q1
+                const uint32_t v = ofv - 3u;
+                uint32_t p0 = push ? v : kUnknown, p1 = kUnknown, p2 = kUnknown;
+                uint32_t q0 = 0u, q1 = 0u, q2 = 0u;
                 for (uint32_t round = 0; round < 66u; ++round) {
                     if (PROF) ++n_rounds;
                     q0 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(h0), static_cast<int>(p0), 0x138, 0xF, 0xF, false));  // wave_shr:1
                     q1 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(h1), static_cast<int>(p1), 0x138, 0xF, 0xF, false));
                     q2 = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(h2), static_cast<int>(p2), 0x138, 0xF, 0xF, false));
-                    qk = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(static_cast<int>(kn), static_cast<int>(pk), 0x138, 0xF, 0xF, false));
-                    const uint32_t k0 = qk & 1u, k1 = (qk >> 1) & 1u, k2 = (qk >> 2) & 1u;
-                    uint32_t n0, n1, n2, nk;
-                    if (kind == 4u) {
-                        n0 = ofv - 3u;
-                        n1 = q0;
-                        n2 = q1;
-                        nk = 1u | (k0 << 1) | (k1 << 2);
-                    } else if (kind == 0u || kind == 5u) {
-                        n0 = q0;
-                        n1 = q1;
-                        n2 = q2;
-                        nk = qk;
-                    } else if (kind == 1u) {
-                        n0 = q1;
-                        n1 = q0;
-                        n2 = q2;
-                        nk = k1 | (k0 << 1) | (k2 << 2);
-                    } else if (kind == 2u) {
-                        n0 = q2;
-                        n1 = q0;
-                        n2 = q1;
-                        nk = k2 | (k0 << 1) | (k1 << 2);
-                    } else {
-                        n0 = q0 - 1u;
-                        n1 = q0;
-                        n2 = q1;
-                        nk = k0 | (k0 << 1) | (k1 << 2);
-                    }
-                    const bool changed = nk != pk || (n0 != p0 && (nk & 1u)) || (n1 != p1 && (nk & 2u)) || (n2 != p2 && (nk & 4u));
+                    uint32_t t = take1 ? q1 : (take2 ? q2 : q0);
+                    t = (t - (dec ? 1u : 0u)) | (t & kUnknown);
+                    const uint32_t n0 = push ? v : t, n1 = sel1 ? q0 : q1, n2 = sel2 ? q1 : q2;
+                    const bool changed = n0 != p0 || n1 != p1 || n2 != p2;
                     p0 = n0;
                     p1 = n1;
                     p2 = n2;
-                    pk = nk;
                     if (!__builtin_amdgcn_ballot_w64(changed)) break;
                 }
                 // a repeat code met while the history before it still has an unknown slot stays in the record as it is
-                const bool resolved = qk == 7u;
+                const bool resolved = ((q0 | q1 | q2) & kUnknown) == 0u;
                 uint32_t w0 = p0 & 0x3FFFFFFFu;
                 if (isrep && !resolved) w0 = kRecRep | (llv == 0u ? kRecFlag : 0u) | ofv;
                 if (__builtin_amdgcn_ballot_w64(isrep && resolved && p0 == 0u)) {
@@ -1187,11 +1165,10 @@ __global__ __launch_bounds__(64 * kZvWaves) void zstd_records(const GpuBlock* __
                 h0 = __builtin_amdgcn_readlane(p0, nq - 1u);
                 h1 = __builtin_amdgcn_readlane(p1, nq - 1u);
                 h2 = __builtin_amdgcn_readlane(p2, nq - 1u);
-                kn = __builtin_amdgcn_readlane(pk, nq - 1u);
             }
             if (!berr) {
                 literal_run(d.nlit - lit_pos);
-                if (kn != 7u) n_sym = nrec;
+                if ((h0 | h1 | h2) & kUnknown) n_sym = nrec;
                 if (out > kBlockMax || nrec > rec_cap) berr = kZstdBadSize;
             }
         }
@@ -1202,7 +1179,7 @@ __global__ __launch_bounds__(64 * kZvWaves) void zstd_records(const GpuBlock* __
             o.nrec = nrec;
             o.out_len = out;
             o.n_sym = n_sym;
-            o.hist_known = kn == 7u ? 1u : 0u;
+            o.hist_known = ((h0 | h1 | h2) & kUnknown) ? 0u : 1u;
             o.hist[0] = h0;
             o.hist[1] = h1;
             o.hist[2] = h2;

@@ -200,3 +200,56 @@ def test_gpu_zstd_decoder_and_libzstd_agree_on_damaged_frames(zgpu):
                 assert np.array_equal(gpu, host)
                 agree += 1
     assert agree > 10 and strict < 20
+
+
+def test_gpu_zstd_decoder_goes_through_large_files_in_segments(zgpu, tmp_path, monkeypatch):
+    """A file the device cannot hold at once is decoded segment after segment (forced with a 3 MiB segment on 10 frames: image,
+    file, superset); every segment has its own pieces, kernels and scratch."""
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_NA12878, 31, 1, 0, 512000 * 9 + 4321)
+    path = tmp_path / "seg.zst"
+    bt.write_block_file(path, flags, mode="zstd", level=3)
+    want, n = expect(flags, bt.BLOCK_BYTES)
+    one, st = blockfile.flagstat_zstd_file(str(path), 2)
+    assert np.array_equal(one, want) and st["gpu_decode"] == 1
+    sup_one, _ = blockfile.flagstat_file(str(path), 2, superset=True)
+    for cap in (3 << 20, 1000):          # three frames per segment; one frame per segment
+        monkeypatch.setenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES", str(cap))
+        got, st = blockfile.flagstat_zstd_file(str(path), 3)
+        assert np.array_equal(got, want) and st["gpu_decode"] == 1 and st["n_flags"] == n
+        got, st = blockfile.flagstat_zstd_image(open(path, "rb").read(), 2)
+        assert np.array_equal(got, want) and st["gpu_decode"] == 1
+        sup, _ = blockfile.flagstat_file(str(path), 2, superset=True)
+        assert np.array_equal(sup, sup_one)
+        monkeypatch.delenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES")
+
+
+def test_gpu_zstd_decoder_keeps_and_releases_its_device_memory(zgpu):
+    """The two large buffers AND the scratch between the kernels stay with the engine for the next file, go after eight calls of
+    other entry points and after a failed call (knob lz4_gpu_keep_bytes; read-only lz4_gpu_kept_bytes)."""
+    import oracle
+    from libflagstats_amd import _lib, blockfile, pyflagstats
+    hip = zgpu
+    flags = oracle.generate(oracle.GEN_NA12878, 41, 1, 0, 512000 * 4)
+    img = bt.block_file_image(flags, mode="zstd", level=1)
+    want = expect(flags, bt.BLOCK_BYTES)[0]
+    got, _ = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want)
+    kept = hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes")
+    assert kept > len(img) + 2 * len(flags) + (16 << 20)       # compressed + decoded + scratch for two frames a stream
+    got, _ = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want) and hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == kept
+    a = oracle.generate(oracle.GEN_UNIFORM, 43, 0xFFFF, 0, 5000)
+    for i in range(7):
+        pyflagstats.counters_u32(a)
+        assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == kept, i
+    pyflagstats.counters_u32(a)
+    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
+    bad = bytearray(img)
+    bad[8] ^= 0xFF      # the first frame's magic number
+    with pytest.raises(_lib.FlagstatsHipError):
+        blockfile.flagstat_zstd_image(bytes(bad), 2)
+    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
+    got, _ = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want)
