@@ -64,12 +64,15 @@ static inline ZLayout zstd_layout(uint32_t max_dst_len, uint32_t nframes)
 {
     ZLayout y;
     y.nframes = nframes;
-    y.rec_stride = ((max_dst_len / 3u + 64u) & ~63u) + 96u * kZstdMaxBlocks;
+    // blocks per frame the scratch holds tables for: four times what 128 KiB blocks need (compressors that split blocks), and
+    // some (more: kZstdTooManyBlocks)
+    y.blk_cap = 4u * ((max_dst_len + 131071u) / 131072u) + 8u;
+    if (y.blk_cap > kZstdMaxBlocks) y.blk_cap = kZstdMaxBlocks;
+    // records: a sequence makes at least three bytes; per block up to 95 more (split runs, the literals behind the last
+    // sequence, rounding to whole batches of 64)
+    y.rec_stride = ((max_dst_len / 3u + 64u) & ~63u) + 96u * y.blk_cap;
     y.ck_stride = y.rec_stride / 64u;
     y.lit_stride = (max_dst_len + 64u + 15u) & ~15u;
-    // blocks per frame the scratch holds tables for: twice what 128 KiB blocks need, and some (more: kZstdTooManyBlocks)
-    y.blk_cap = 2u * ((max_dst_len + 131071u) / 131072u) + 8u;
-    if (y.blk_cap > kZstdMaxBlocks) y.blk_cap = kZstdMaxBlocks;
     auto up = [](uint64_t v) { return (v + 255u) & ~255ull; };
     const uint64_t nf = nframes;
     y.hdr_at = 0;
