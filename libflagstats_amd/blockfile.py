@@ -36,7 +36,9 @@ def flagstat_lz4_image(image: bytes, threads: int = 0):
 
 
 def flagstat_zstd_file(path: str, threads: int = 0):
-    """``.zst`` block file (``benchmark/flagstats.cpp:636-682``); needs libzstd.so.1 at run time."""
+    """``.zst`` block file (``benchmark/flagstats.cpp:636-682``).  Files of 64 MiB and more are decoded on the GPU (knob
+    ``zstd_decoder``; ``stats["gpu_decode"]`` says which ran); smaller ones, and files with frames the GPU decoder does not
+    take, by libzstd.so.1 on host threads (resolved at run time)."""
     out = np.zeros(32, dtype=np.uint64)
     st = _lib.BlockfileStats()
     _lib.check(_lib.lib().FLAGSTATS_hip_blockfile_zstd(str(path).encode(), threads, out.ctypes.data, ctypes.byref(st)),
