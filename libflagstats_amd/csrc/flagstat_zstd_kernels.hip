@@ -892,13 +892,15 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
         const uint16_t* const T = L.tab[home];
         const uint32_t sizel = 1u << logl, sizeo = 1u << logo, sizem = 1u << logm;
         // the window: 16 bytes that end with the byte the position falls into, as four dwords; (pos & 7) + 120 of its bits are unread
-        auto window = [&](uint32_t* dw) {
+        typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+        auto window = [&](v4u& dw) {
             const uint32_t ri = static_cast<uint32_t>((pos >> 3) - 15) & (kZcRing - 1u);
-            __builtin_memcpy(dw, &L.ring[home][ri], 16);
+            typedef uint32_t v4u1 __attribute__((ext_vector_type(4), aligned(1)));
+            dw = *reinterpret_cast<const v4u1*>(&L.ring[home][ri]);
         };
         uint32_t sl = 0, so = 0, sm = 0;
         if (act) {
-            uint32_t dw[4];
+            v4u dw;
             window(dw);
             const uint32_t sh = static_cast<uint32_t>(pos) & 7u;
             uint64_t w = (static_cast<uint64_t>(__builtin_amdgcn_alignbit(dw[3], dw[2], sh + 24u)) << 32) | __builtin_amdgcn_alignbit(dw[2], dw[1], sh + 24u);
@@ -911,23 +913,31 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
                 act = false;
             }
         }
-        // One step: `update` = the states move on (every sequence but a block's last).  Straight-line; a lane that has no step
-        // left computes along and stores nothing.
+        // One step: `update` = the states move on (every sequence but a block's last).  The entries and the window of a step
+        // are loaded at the END of the step before it, ahead of that step's book-keeping (stash store, counters), which so
+        // runs while the LDS round trip is under way.
         uint32_t* my_st = stash + static_cast<uint64_t>(d.stash_at) * 3u;   // this lane's next stash entry: states | window (two dwords)
         uint32_t i = 0;
-        auto chain_step = [&](const bool step, const bool update) {
-            const uint32_t el = T[sl], eo = T[512u + so], em = T[768u + sm];
-            uint32_t dw[4];
-            window(dw);
+        struct Loaded {   // what a step needs from LDS: its three table entries and the window
+            uint32_t el, eo, em;
+            v4u dw;
+        };
+        Loaded la, lb;   // (two sets, used in turn: the loads of a step land in the set the step after it reads, no copies)
+        la.el = T[sl];
+        la.eo = T[512u + so];
+        la.em = T[768u + sm];
+        window(la.dw);
+        lb = la;   // (only so that nothing is read uninitialised)
+        auto chain_step = [&](const bool step, const bool update, const Loaded& in, Loaded& out) {
+            const uint32_t el = in.el, eo = in.eo, em = in.em;
+            const v4u dw = in.dw;
             const uint32_t oc = eo >> 10, mlb = em >> 10, llb = el >> 10;
             const uint32_t xl = el & 1023u, xo = eo & 1023u, xm = em & 1023u;
             // bits of the next state: log - highbit(next-state number)
             const uint32_t nbl = update ? logl - highbit(xl) : 0u, nbm = update ? logm - highbit(xm) : 0u, nbo = update ? logo - highbit(xo) : 0u;
             const uint32_t ext = oc + mlb + llb;
             const uint32_t sh = static_cast<uint32_t>(pos) & 7u;
-            // bits [t - 64, t) with t = sh + 120: the extra bits of the three codes lead them (for zstd_records)
-            const uint32_t w1lo = __builtin_amdgcn_alignbit(dw[2], dw[1], sh + 24u), w1hi = __builtin_amdgcn_alignbit(dw[3], dw[2], sh + 24u);
-            // the state bits follow the extra bits: the 32 bits of the window below bit t - ext (<= 26 are used)
+            // the state bits follow the extra bits: the 32 bits of the window below bit t - ext (<= 26 are used), t = sh + 120
             const uint32_t f = sh + 88u - ext;   // t - ext - 32: 25..95
             const uint32_t fk = f >> 5;
             const uint32_t x_lo = fk == 0u ? dw[0] : (fk == 1u ? dw[1] : dw[2]), x_hi = fk == 0u ? dw[1] : (fk == 1u ? dw[2] : dw[3]);
@@ -935,17 +945,26 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
             const uint32_t o1 = 32u - nbl, o2 = o1 - nbm, o3 = o2 - nbo;
             const uint32_t bl = __builtin_amdgcn_ubfe(x, o1, nbl), bm = __builtin_amdgcn_ubfe(x, o2, nbm), bo = __builtin_amdgcn_ubfe(x, o3, nbo);
             if (step) {
-                typedef uint32_t v3u __attribute__((ext_vector_type(3)));
-                v3u e;
-                e.x = sl | (so << 9) | (sm << 17);
-                e.y = w1lo;
-                e.z = w1hi;
-                *reinterpret_cast<v3u*>(my_st) = e;
-                my_st += 3;
+                const uint32_t packed = sl | (so << 9) | (sm << 17);
                 sl = (xl << nbl) - sizel + bl;
                 sm = (xm << nbm) - sizem + bm;
                 so = (xo << nbo) - sizeo + bo;
-                pos -= static_cast<int32_t>(ext + nbl + nbm + nbo);
+                pos -= static_cast<int32_t>(ext + 32u - o3);
+                if (update) {
+                    // the next step's reads (a block whose stream ran out reads below its start: inside the ring, never used)
+                    out.el = T[sl];
+                    out.eo = T[512u + so];
+                    out.em = T[768u + sm];
+                    window(out.dw);
+                }
+                // ... and under them this step's book-keeping
+                typedef uint32_t v3u __attribute__((ext_vector_type(3)));
+                v3u e;
+                e.x = packed;
+                e.y = __builtin_amdgcn_alignbit(dw[2], dw[1], sh + 24u);   // bits [t - 64, t) with t = sh + 120: the extra bits of the
+                e.z = __builtin_amdgcn_alignbit(dw[3], dw[2], sh + 24u);   // three codes lead them (for zstd_records)
+                *reinterpret_cast<v3u*>(my_st) = e;
+                my_st += 3;
                 ++i;
                 if (PROF) ++n_steps;
                 if (pos < start_bit) {
@@ -956,14 +975,27 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
         };
         const uint32_t nupd = nseq ? nseq - 1u : 0u;   // steps that move the states on
         while (__builtin_amdgcn_ballot_w64(act && i < nupd)) {
-            // (a lane whose window would run out of staged bytes within four steps asks for a chunk; the wave copies)
-            if (__builtin_amdgcn_ballot_w64(act && i < nupd && (pos >> 3) - rlo < 80)) refill(act && i < nupd && (pos >> 3) - rlo < static_cast<int32_t>(kZcRing / 2u));
-#pragma unroll
-            for (uint32_t u = 0; u < 4u; ++u) chain_step(act && i < nupd, true);
+            // (a lane whose window would run out of staged bytes within five steps asks for a chunk; the wave copies -- and the
+            // lanes the refill served load their window again: it was read before the chunk arrived)
+            if (__builtin_amdgcn_ballot_w64(act && i < nupd && (pos >> 3) - rlo < 96)) {
+                refill(act && i < nupd && (pos >> 3) - rlo < static_cast<int32_t>(kZcRing / 2u));
+                window(la.dw);
+            }
+            // (every lane that still steps has taken a multiple of four steps here: its next step reads `la`)
+            chain_step(act && i < nupd, true, la, lb);
+            chain_step(act && i < nupd, true, lb, la);
+            chain_step(act && i < nupd, true, la, lb);
+            chain_step(act && i < nupd, true, lb, la);
         }
-        // the last sequence of every block: its codes and extra bits, no bits for further states
-        if (__builtin_amdgcn_ballot_w64(act && (pos >> 3) - rlo < 80)) refill(act && (pos >> 3) - rlo < static_cast<int32_t>(kZcRing / 2u));
-        chain_step(act && i < nseq, false);
+        // the last sequence of every block: its codes and extra bits, no bits for further states.  What its step reads was
+        // loaded by the step before it into the set that step wrote: `la` after an even number of steps, `lb` after an odd one.
+        Loaded fin;
+        fin.el = (nupd & 1u) ? lb.el : la.el;
+        fin.eo = (nupd & 1u) ? lb.eo : la.eo;
+        fin.em = (nupd & 1u) ? lb.em : la.em;
+        if (__builtin_amdgcn_ballot_w64(act && (pos >> 3) - rlo < 96)) refill(act && (pos >> 3) - rlo < static_cast<int32_t>(kZcRing / 2u));
+        window(fin.dw);
+        chain_step(act && i < nseq, false, fin, lb);
         if (have && d.type == 2u && d.nseq > 0u && !lerr && pos != start_bit) lerr = kZstdBadBitstream;
         if (have && lerr) blk[b].chain_err = lerr;
         __syncthreads();
