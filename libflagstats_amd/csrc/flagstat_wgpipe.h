@@ -207,33 +207,50 @@ template <bool PROF, class LDS>
 __device__ void wgpipe_copy(LDS& L, uint8_t* __restrict__ dst, const uint32_t oend, const uint32_t lane,
                             unsigned long long* __restrict__ tally)
 {
+    static_assert(LDS::kFlush == 4u * LDS::kChunk && LDS::kNR % LDS::kFlush == 0u, "a flush unit is four chunks and never wraps");
     uint32_t cidx = 0, flushed = 0, fidx = 0;
     const uint32_t oend_even = oend & ~1u;  // an odd trailing byte of a block is dropped like the reference's N = size >> 1
     unsigned long long t_wait = 0, n_chunks = 0;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     bool ok = true;
-    for (uint32_t c = 0; c < oend; c += LDS::kChunk) {
-        ok = wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.s_done[(c / LDS::kChunk) % LDS::kScan]) >= c + LDS::kChunk; });
-        if (!ok) break;
-        ++n_chunks;
-        const uint4 f = *reinterpret_cast<const uint4*>(&L.fsrc[(c & (LDS::kK - 1u)) + 4u * lane]);
-        const uint32_t b0 = L.ring[f.x < LDS::kNR ? f.x : LDS::kNR - 1u], b1 = L.ring[f.y < LDS::kNR ? f.y : LDS::kNR - 1u];
-        const uint32_t b2 = L.ring[f.z < LDS::kNR ? f.z : LDS::kNR - 1u], b3 = L.ring[f.w < LDS::kNR ? f.w : LDS::kNR - 1u];
-        *reinterpret_cast<uint32_t*>(&L.ring[cidx + 4u * lane]) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
-        wg_st(&L.d_op, c + LDS::kChunk);
-        cidx += LDS::kChunk;
-        if (cidx == LDS::kNR) cidx = 0;
-        if (c + LDS::kChunk - flushed == LDS::kFlush && c + LDS::kChunk <= oend_even) {
-            if constexpr (LDS::kPublishFlush) {
-                // what was flushed before has landed: readers of far matches (device-scope loads) may see it
-                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-                wg_st(&L.f_op, flushed);
-            }
-            *reinterpret_cast<uint4*>(dst + flushed + lane * 16u) = *reinterpret_cast<const uint4*>(&L.ring[fidx + lane * 16u]);
-            flushed += LDS::kFlush;
-            fidx += LDS::kFlush;
-            if (fidx == LDS::kNR) fidx = 0;
+    uint32_t sidx = 0;   // the scanner of the coming chunk: (c / kChunk) % kScan
+    // One chunk: "is it scanned?", its final sources, the bytes behind them, the write, the new position -- three dependent
+    // LDS round trips and as little else as possible: this wave is the one every byte of the block passes through in order,
+    // and a taken branch costs it ~50 cycles, a scalar instruction 5-12.
+    auto one_chunk = [&](const uint32_t c, const uint32_t at) {
+        if (ok && __builtin_expect(wg_ld(&L.s_done[sidx]) < c + LDS::kChunk, 0))
+            ok = wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.s_done[sidx]) >= c + LDS::kChunk; });
+        if (ok) {
+            const uint4 f = *reinterpret_cast<const uint4*>(&L.fsrc[(c & (LDS::kK - 1u)) + 4u * lane]);
+            const uint32_t b0 = L.ring[f.x < LDS::kNR ? f.x : LDS::kNR - 1u], b1 = L.ring[f.y < LDS::kNR ? f.y : LDS::kNR - 1u];
+            const uint32_t b2 = L.ring[f.z < LDS::kNR ? f.z : LDS::kNR - 1u], b3 = L.ring[f.w < LDS::kNR ? f.w : LDS::kNR - 1u];
+            *reinterpret_cast<uint32_t*>(&L.ring[at + 4u * lane]) = b0 | (b1 << 8) | (b2 << 16) | (b3 << 24);
+            wg_st(&L.d_op, c + LDS::kChunk);
+            sidx = sidx + 1u == LDS::kScan ? 0u : sidx + 1u;
         }
+    };
+    uint32_t c = 0;
+    // whole flush units: four chunks, then the KiB they made goes to global memory
+    for (; ok && c + LDS::kFlush <= oend_even; c += LDS::kFlush) {
+#pragma unroll
+        for (uint32_t k = 0; k < 4u; ++k) one_chunk(c + k * LDS::kChunk, cidx + k * LDS::kChunk);
+        if (!ok) break;
+        n_chunks += 4u;
+        if constexpr (LDS::kPublishFlush) {
+            // what was flushed before has landed: readers of far matches (device-scope loads) may see it
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            wg_st(&L.f_op, flushed);
+        }
+        *reinterpret_cast<uint4*>(dst + flushed + lane * 16u) = *reinterpret_cast<const uint4*>(&L.ring[fidx + lane * 16u]);
+        flushed += LDS::kFlush;
+        fidx = fidx + LDS::kFlush == LDS::kNR ? 0u : fidx + LDS::kFlush;
+        cidx = fidx;
+    }
+    // the chunks behind the last whole unit (at most four, the last one maybe short)
+    for (; ok && c < oend; c += LDS::kChunk) {
+        one_chunk(c, cidx);
+        ++n_chunks;
+        cidx = cidx + LDS::kChunk == LDS::kNR ? 0u : cidx + LDS::kChunk;
     }
     if (ok && !wg_ld(&L.err)) {
         // what is left in the ring: < 2 KiB, contiguous from fidx (a flush unit never wraps, the rest may)
