@@ -106,6 +106,11 @@ def synthetic_blocks(seed):
         a + bytes(50000) + a + r.integers(0, 256, 20000, dtype=np.uint8).tobytes() + a[:30000] + bytes(100000),   # runs above 16,383, far matches
         (r.integers(0, 256, 17000, dtype=np.uint8).tobytes() + b"x" * 17000) * 12,
         oracle.generate(oracle.GEN_UNIFORM, seed, 0x0FFF, 0, 512000).tobytes(),
+    ] + [
+        # a 3000-byte stretch repeated at distances around what the execution kernel keeps in LDS (matches up to 65,535 back read
+        # the ring, farther ones the flushed output) and around the ring's size
+        a[:3000] + r.integers(0, 256, dist - 3000, dtype=np.uint8).tobytes() + a[:3000] + b"tail" * 50
+        for dist in (65534, 65535, 65536, 65537, 68607, 69631, 69632, 69633, 131071, 131072, 131073)
     ]
 
 
