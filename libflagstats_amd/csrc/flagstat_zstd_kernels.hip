@@ -1362,7 +1362,7 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
                         const uint32_t lit_cap, const uint8_t* __restrict__ dst, const uint32_t nslots, const uint32_t oend, const uint32_t lane,
                         const uint32_t which, unsigned long long* __restrict__ tally)
 {
-    uint32_t err = 0, s_seen = 0, d_seen = 0, nfar = 0;
+    uint32_t err = 0, s_seen = 0, d_seen = 0, f_seen = 0, nfar = 0;
     unsigned long long t_wait = 0, n_groups = 0, n_batches = 0;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     auto room = [&](uint32_t at, uint32_t nbytes) -> bool {
@@ -1502,31 +1502,47 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
                     uint32_t src_end = (now & far) ? src + ml : 0u;
                     src_end = wave_scan_max(src_end);
                     src_end = __builtin_amdgcn_readlane(src_end, 63);
-                    if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.f_op) >= src_end; })) {
-                        failed = true;
-                        break;
+                    // (the copier's "flushed and landed" mark, as last seen: a far source lies 64 KiB back, the mark 2 KiB)
+                    if (__builtin_expect(src_end > f_seen, 0)) {
+                        if (!wg_wait_timed<PROF>(L, t_wait, [&] {
+                                f_seen = wg_ld(&L.f_op);
+                                return f_seen >= src_end;
+                            })) {
+                            failed = true;
+                            break;
+                        }
                     }
-                    if (now & far) {
-                        const uint32_t* const s4 = reinterpret_cast<const uint32_t*>(dst + (src & ~3u));
-                        const uint32_t sh = src & 3u;
-                        const uint32_t rm = ring_at(mpos);
-                        for (uint32_t b = 0; b < ml; b += 16u) {
-                            const uint32_t nw = (ml - b + sh + 3u) >> 2;  // aligned words this round needs (<= 5)
-                            uint32_t d[5];
+                    const bool fl = now & far;
+                    const uint8_t* sp = dst + (fl ? src : 0u);
+                    const uint32_t rm = ring_at(mpos);
+                    // Sixteen bytes a round, every far lane its own match, straight-line for the first round (most matches are
+                    // shorter): four dwords at the match's own (byte) address, past the L1 (what they hold behind the match is
+                    // inside the output buffer and not used), stored whole where the match has them and the ring does not wrap,
+                    // as bytes otherwise.
+                    for (uint32_t b = 0;; b += 16u) {
+                        uint32_t u0, u1, u2, u3;
+                        asm volatile("global_load_dword %0, %4, off sc0 sc1\n\t"
+                                     "global_load_dword %1, %4, off offset:4 sc0 sc1\n\t"
+                                     "global_load_dword %2, %4, off offset:8 sc0 sc1\n\t"
+                                     "global_load_dword %3, %4, off offset:12 sc0 sc1\n\t"
+                                     "s_waitcnt vmcnt(0)"
+                                     : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
+                                     : "v"(sp)
+                                     : "memory");
+                        const bool live = fl & (b < ml);
+                        const bool whole = rm + b + 16u <= ZxLds::kNR;
+                        const uint32_t uu[4] = {u0, u1, u2, u3};
 #pragma unroll
-                            for (uint32_t k = 0; k < 5u; ++k)
-                                d[k] = k < nw ? __hip_atomic_load(&s4[(b >> 2) + k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0u;
-#pragma unroll
-                            for (uint32_t k = 0; k < 4u; ++k) {
-                                const uint32_t u = __builtin_amdgcn_alignbyte(d[k + 1u], d[k], sh);
-                                const uint32_t at = b + 4u * k;
-                                if (at + 4u <= ml && rm + at + 4u <= ZxLds::kNR) {
-                                    __builtin_memcpy(&L.ring[rm + at], &u, 4);
-                                } else {
-                                    for (uint32_t x = 0; x < 4u && at + x < ml; ++x) L.ring[ring_at(mpos + at + x)] = static_cast<uint8_t>(u >> (8u * x));
-                                }
+                        for (uint32_t k = 0; k < 4u; ++k) {
+                            const uint32_t u = uu[k];
+                            const uint32_t at = b + 4u * k;
+                            if (live & whole & (at + 4u <= ml)) __builtin_memcpy(&L.ring[rm + at], &u, 4);
+                            if (live & (at < ml) & !(whole & (at + 4u <= ml))) {
+                                for (uint32_t x = 0; x < 4u && at + x < ml; ++x) L.ring[ring_at(mpos + at + x)] = static_cast<uint8_t>(u >> (8u * x));
                             }
                         }
+                        if (!__builtin_amdgcn_ballot_w64(fl & (b + 16u < ml))) break;
+                        sp += (fl & (b + 16u < ml)) ? 16 : 0;   // (a lane that is done stays where it is: inside the buffer)
                     }
                 }
                 lo = hi;
