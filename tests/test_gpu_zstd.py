@@ -315,3 +315,19 @@ def test_gpu_zstd_decoder_takes_frames_of_many_small_blocks(zgpu):
             assert st["gpu_decode"] == 0 and np.array_equal(got, expect_blocks([raw]))
             assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 64 << 20) == 0
             assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+
+
+@pytest.mark.parametrize("block_bytes", [9999, 70001, 4096000])
+def test_gpu_zstd_decoder_on_other_block_sizes(zgpu, tmp_path, block_bytes):
+    """Block files cut differently from the reference writer's 1,024,000 bytes: small odd frames (the odd last byte of a block is
+    no flag), frames of one block, frames of 32 blocks (four passes of the prepare and chain kernels)."""
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_NA12878, 51, 1, 0, 2048000 * 2 + 333)
+    path = tmp_path / "other.zst"
+    bt.write_block_file(path, flags, block_bytes=block_bytes, mode="zstd", level=2)
+    want, n = expect(flags, block_bytes)
+    got, st = blockfile.flagstat_zstd_file(str(path), 2)
+    assert st["gpu_decode"] == 1 and st["n_flags"] == n and np.array_equal(got, want)
+    got, st = blockfile.flagstat_zstd_image(open(path, "rb").read(), 2)
+    assert st["gpu_decode"] == 1 and np.array_equal(got, want)
