@@ -49,7 +49,10 @@ uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes);
 // Decode `nblocks` Zstandard frames on `stream`: frame i reads comp[blocks[i].src_off ..+src_len) and writes
 // out[blocks[i].dst_off ..+dst_len); status[i] = 0 or one of the codes above (the frame's output then holds garbage).
 // Two kernels: entropy decode (Huffman literals, FSE sequences -> records in `scratch`), then sequence execution.
-// tally[0] += sequence records, tally[1] += matches read back from global memory; prof != 0: cycle counters in tally[2..].
+// tally[0] += sequence records, tally[1] += matches read back from global memory; prof != 0: cycle counters --
+// [5] batches and [6] groups of the emitters, [8..11] scanners (cycles, waiting, doubling rounds, chunks with pointers inside),
+// [12..14] copier (cycles, waiting, chunks), [15] / [16] emitters (cycles, waiting), [17..19] prepare (cycles, literals, tables),
+// [20..22] chain (wave cycles, waves, steps), [23..25] records (workgroup cycles, relaxation rounds, batches).
 // `comp` must be readable for 64 bytes past the last payload; `scratch` holds fsk_zstd_scratch_bytes(max_dst_len, nblocks).
 hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
                            unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int prof,

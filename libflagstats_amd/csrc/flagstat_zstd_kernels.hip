@@ -126,7 +126,6 @@ struct __attribute__((aligned(16))) ZeLds {
 };
 constexpr uint32_t kNone = ~0u, kRepeat = ~1u;
 
-__device__ __forceinline__ uint32_t ld_u8(const uint8_t* p) { return *p; }
 __device__ __forceinline__ uint32_t ld_le16(const uint8_t* p) { return static_cast<uint32_t>(p[0]) | (static_cast<uint32_t>(p[1]) << 8); }
 __device__ __forceinline__ uint32_t ld_le24(const uint8_t* p) { return ld_le16(p) | (static_cast<uint32_t>(p[2]) << 16); }
 __device__ __forceinline__ uint32_t ld_le32(const uint8_t* p)
@@ -826,7 +825,6 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
     const uint8_t* const frame = comp + gb.src_off;
     const uint32_t n = gb.src_len;
     ZBlk* const blk = reinterpret_cast<ZBlk*>(scratch + lay.blk_at) + static_cast<uint64_t>(fact ? fi : 0u) * lay.blk_cap;
-    const uint8_t* const tabs = scratch + lay.tab_at + static_cast<uint64_t>(fact ? fi : 0u) * lay.blk_cap * kTabBytes;
     uint32_t* const stash = reinterpret_cast<uint32_t*>(scratch + lay.stash_at) + static_cast<uint64_t>(fact ? fi : 0u) * lay.rec_stride * 3u;
     const uint32_t nblk = fact ? reinterpret_cast<const ZFrameHdr*>(scratch + lay.hdr_at)[fi].nblk : 0u;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
