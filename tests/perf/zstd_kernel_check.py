@@ -96,6 +96,7 @@ def main():
     ap.add_argument("--prof", type=int, default=0)
     ap.add_argument("--many", type=int, default=0, help="also time this many copies of the 1,024,000-byte NA12878-like frame")
     ap.add_argument("--only", default="")
+    ap.add_argument("--many-kind", default="na12878", help="na12878 | uniform (12-bit uniform flags: no far matches)")
     args = ap.parse_args()
     lib = _lib.lib()
     _lib.check(lib.FLAGSTATS_hip_init(0), "init")
@@ -122,7 +123,7 @@ def main():
         per = 512000
         frames, sizes, raws = [], [], []
         for i in range(args.many):
-            raw = oracle.generate(oracle.GEN_NA12878, 7, 1, i * per, per).tobytes()
+            raw = (oracle.generate(oracle.GEN_UNIFORM, 3, 0x0FFF, i * per, per) if args.many_kind == "uniform" else oracle.generate(oracle.GEN_NA12878, 7, 1, i * per, per)).tobytes()
             frames.append(bt.compress_block(raw, "zstd", 1))
             sizes.append(len(raw))
             raws.append(raw)
