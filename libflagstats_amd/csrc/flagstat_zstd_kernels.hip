@@ -398,6 +398,8 @@ __global__ __launch_bounds__(64) void zstd_prepare(const uint8_t* __restrict__ c
         p = 5u + (single ? 0u : 1u);
         if (fhd & 8u)
             fail(kZstdBadHeader);
+        else if (!single && (frame[5] >> 3) > 21u)   // a window above 2^31 bytes: libzstd refuses the frame
+            fail(kZstdBadHeader);
         else if (fhd & 4u)
             fail(kZstdChecksum);
         else if (fhd & 3u)

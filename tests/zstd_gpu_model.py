@@ -91,6 +91,8 @@ def entropy_stage(frame, dst_len):
     if did_flag:
         raise Fail(DICTIONARY)
     if not single:
+        if (frame[p] >> 3) > 21:
+            raise Fail(BAD_HEADER, "window above 2^31 bytes")
         p += 1
     fcs_bytes = (1 if single else 0, 2, 4, 8)[fcs_flag]
     if p + fcs_bytes > n:

@@ -423,6 +423,8 @@ def parse_frame_header(data, pos=0):
     if not single:
         wd = data[p]
         p += 1
+        if (wd >> 3) > 21:
+            raise ZstdError("window above 2^31 bytes (libzstd: frame requires too much memory)")
         base = 1 << (10 + (wd >> 3))
         window = base + (base >> 3) * (wd & 7)
     did_bytes = (0, 1, 2, 4)[did_flag]
