@@ -59,6 +59,8 @@ def main():
         else:
             assert not ok, ("seed", seed, "host rejects, GPU accepts")
             damaged_rejected += 1
+        if seed % 100 == 99:
+            print("seed %d done" % seed, flush=True)    # (a GPU run that prints nothing for minutes is taken to be hung)
     _lib.check(lib.FLAGSTATS_hip_set(b"lz4_decoder", 2), "set")
     print("fuzz: %d seeds, %d synthetic blocks exact on the GPU; damaged blocks: %d still valid (same counters as the host decoder), "
           "%d rejected by both" % (args.seeds, blocks, damaged_ok, damaged_rejected))
