@@ -331,3 +331,28 @@ def test_gpu_zstd_decoder_on_other_block_sizes(zgpu, tmp_path, block_bytes):
     assert st["gpu_decode"] == 1 and st["n_flags"] == n and np.array_equal(got, want)
     got, st = blockfile.flagstat_zstd_image(open(path, "rb").read(), 2)
     assert st["gpu_decode"] == 1 and np.array_equal(got, want)
+
+
+def test_gpu_zstd_decoder_is_the_default_for_large_files(hip, tmp_path):
+    """With the knobs as shipped (zstd_decoder 2, zstd_gpu_min_bytes 64 MiB) a 300-frame file of NA12878-like flags (73 MiB
+    compressed: two pieces, several pinned spans in file mode) goes through the GPU decoder; incompressible flags (raw blocks,
+    Huffman-only blocks) and the reference writer's trailing empty block too; the counters are the oracle's."""
+    import oracle
+    from libflagstats_amd import blockfile
+    assert hip.FLAGSTATS_hip_get(b"zstd_decoder") == 2 and hip.FLAGSTATS_hip_get(b"zstd_gpu_min_bytes") == 64 << 20
+    flags = oracle.generate(oracle.GEN_NA12878, 61, 1, 0, 512000 * 300)        # an exact multiple: a trailing empty block
+    path = tmp_path / "big.zst"
+    size = bt.write_block_file(path, flags, mode="zstd", level=1)
+    assert size >= 64 << 20
+    want, n = expect(flags, bt.BLOCK_BYTES)
+    got, st = blockfile.flagstat_zstd_file(str(path), 0)
+    assert st["gpu_decode"] == 1 and st["n_flags"] == n and st["n_blocks"] == 301 and np.array_equal(got, want)
+    got, st = blockfile.flagstat_file(str(path), 4)
+    assert st["gpu_decode"] == 1 and np.array_equal(got, want)
+    # 12-bit uniform flags: Huffman-coded literals and hardly a sequence; 16-bit uniform flags: raw blocks
+    for hi_mask, nfl in ((0x0FFF, 512000 * 100 + 3), (0xFFFF, 512000 * 70 + 1)):
+        flags = oracle.generate(oracle.GEN_UNIFORM, 62, hi_mask, 0, nfl)
+        img = bt.block_file_image(flags, mode="zstd", level=1)
+        assert len(img) >= 64 << 20
+        got, st = blockfile.flagstat_zstd_image(img, 0)
+        assert st["gpu_decode"] == 1 and np.array_equal(got, expect(flags, bt.BLOCK_BYTES)[0])
