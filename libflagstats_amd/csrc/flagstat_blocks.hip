@@ -596,6 +596,7 @@ int run_gpu_lz4(fsint::Engine& eng, int codec, const uint8_t* img, int fd, uint6
     src.superset = superset;
     src.threads = threads;
     src.codec = codec;
+    src.by_size = (codec == 0 ? fsint::knobs().lz4_decoder.load() : fsint::knobs().zstd_decoder.load()) == 2;
     FLAGSTATS_gpu_lz4_stats g;
     const int rc = fsint::lz4_gpu_run(eng, src, out, &g);
     const bool forced = (codec == 0 ? fsint::knobs().lz4_decoder.load() : fsint::knobs().zstd_decoder.load()) == 1;

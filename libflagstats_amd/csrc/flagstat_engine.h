@@ -188,12 +188,14 @@ struct Lz4GpuSource {
     bool superset = false;
     int threads = 0;        // file mode: parallel preads (<= 0: up to 16)
     int codec = 0;          // payloads: 0 = LZ4 blocks, 1 = Zstandard frames
+    bool by_size = false;   // the decoder was chosen by the size rule: a file of flags that hardly compress is handed back (kGpuDecodeRejected)
 };
 int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, struct ::FLAGSTATS_gpu_lz4_stats* stats);  // e.mu held, device current
 // > 0 from lz4_gpu_run: the device could not hold the decoder's buffers (nothing was counted; the caller may take the host pipeline)
 constexpr int kLz4GpuNoMemory = 77;
-// > 0 from lz4_gpu_run, Zstandard only: the GPU decoder did not take a frame (damaged, or valid Zstandard outside what it
-// handles); nothing was counted, the message is set; the caller may decode the file with libzstd on the host
+// > 0 from lz4_gpu_run: the GPU decoder did not take the file -- a Zstandard frame it does not handle or finds damaged, or
+// (either codec, decoder chosen by size) flags that hardly compress; nothing was counted; the caller decodes the file on
+// the host threads
 constexpr int kGpuDecodeRejected = 78;
 void lz4_gpu_release(Engine& e, bool all);         // e.mu held: the two large buffers (all: streams, events, index too)
 void lz4_gpu_other_use(Engine& e);                 // e.mu held: another entry point ran (the idle rule of the kept buffers)

@@ -524,6 +524,14 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         stats->uncompressed_bytes = usum;
     }
     if (blocks.empty()) return 0;
+    // Flags that hardly compress: the host-thread pipeline then moves about as many bytes over PCIe as the GPU decoder and has
+    // next to nothing to decode (raw blocks, literal runs), while the GPU decoders' literal paths are their slow ones
+    // (profiles/r04/incompressible_blockfiles.log: 11 ms against 14 (LZ4) / 22-29 (Zstandard) for 512 MiB).  With the
+    // decoder chosen by size such a file goes to the host threads: decoded bytes below 1.25 x (LZ4) / 1.5 x (Zstandard) the file's.
+    {
+        const uint64_t pct = in.codec == 1 ? 150 : 125;
+        if (in.by_size && usum * 100 < bytes * pct) return kGpuDecodeRejected;
+    }
     // Segments: compressed and decoded bytes of a segment are resident on the device together, so a file larger than the
     // card can hold goes through in several of them, one after the other (each with its own pieces, decode launches and
     // counting pass).  Default: a third of the free device memory, at most 16 GiB of decoded bytes; env

@@ -506,3 +506,25 @@ def test_gpu_decoder_on_streams_with_long_matches_and_literal_runs(gpu_decoder, 
         want = expect(flags, block_bytes)[0]
         got, st = blockfile.flagstat_lz4_image(img, 2)
         assert st["gpu_decode"] == 1 and np.array_equal(got, want), (kind, mode, level, n, block_bytes)
+
+
+def test_size_rule_leaves_incompressible_files_to_the_host_threads(hip):
+    """With the decoder chosen by size, an LZ4 file whose blocks hardly compress (decoded bytes < 1.25 x the file's) stays with
+    the host-thread pipeline -- it is PCIe-bound there and the GPU decoder's literal path is its slow one; forced, the GPU
+    decoder takes it and gives the same counters."""
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_UNIFORM, 71, 0xFFFF, 0, 512000 * 3 + 9)
+    img = bt.block_file_image(flags)
+    want = expect(flags, bt.BLOCK_BYTES)[0]
+    assert hip.FLAGSTATS_hip_get(b"lz4_decoder") == 2
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 1) == 0
+    try:
+        got, st = blockfile.flagstat_lz4_image(img, 2)
+        assert st["gpu_decode"] == 0 and np.array_equal(got, want)
+        assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
+        got, st = blockfile.flagstat_lz4_image(img, 2)
+        assert st["gpu_decode"] == 1 and np.array_equal(got, want)
+    finally:
+        assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 2) == 0
+        assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 64 << 20) == 0
