@@ -188,7 +188,7 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *                    workgroup per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default
  *                    64 MiB compressed: the measured break-even of an LZ4-fast file, an LZ4-HC file wins from 40 MiB,
  *                    profiles/r04/lz4_decoder_sweep.log), on the host below -- and on the host whatever the size when
- *                    the blocks hardly compress (decoded bytes < 1.25 x the file's; Zstandard: 1.5 x): the host pipeline is
+ *                    the blocks hardly compress (decoded bytes < 1.25 x the file's; Zstandard: 1.9 x): the host pipeline is
  *                    PCIe-bound on such a file and the GPU decoders' literal paths are their slow ones
  *                    (profiles/r04/incompressible_blockfiles.log).  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
  *   "zstd_decoder"   Zstandard block files (blockfile_zstd, blockimage_zstd, blockfile): 0 = libzstd on host threads, 1 = decode
