@@ -15,7 +15,17 @@ namespace fsk {
 constexpr uint32_t kZstdMaxBlocks = 256;        // Zstandard blocks per frame the GPU decoder takes (more: status kZstdTooManyBlocks)
 constexpr uint32_t kZstdMaxFrameBytes = 1u << 26;  // decoded bytes per frame it takes
 constexpr int kZstdTallyWords = 32;             // unsigned long long words of the tally the kernels add to
-constexpr int kZstdEmitters = 4, kZstdScanners = 5;  // waves per role of the execution kernel (profile output divides by them)
+// Waves per role of the execution kernel: 4 emit + 3 scan + 1 copy = EIGHT waves, two per SIMD, so that a CU holds TWO
+// workgroups (2 x 80 KB of LDS).  With ten waves (4 + 5 + 1, what this kernel shipped with first) a workgroup puts 3 + 3 + 2 + 2
+// waves on the four SIMDs and the second workgroup's three do not fit beside them at 95 VGPRs: a CU then held ONE frame
+// (tests/perf/zstd_occupancy.sh: 256 / 512 / 768 / 1024 frames took 1.25 / 2.49 / 3.69 / 4.87 ms; eight waves: 1.44 / 1.76 ms for
+// 256 / 512).  Measurement builds override the split: make HIPFLAGS+=-DFLAGSTAT_ZSTD_EMITTERS=.. -DFLAGSTAT_ZSTD_SCANNERS=..
+#ifndef FLAGSTAT_ZSTD_EMITTERS
+#define FLAGSTAT_ZSTD_SHIPPED_SPLIT 1
+#define FLAGSTAT_ZSTD_EMITTERS 4
+#define FLAGSTAT_ZSTD_SCANNERS 3
+#endif
+constexpr int kZstdEmitters = FLAGSTAT_ZSTD_EMITTERS, kZstdScanners = FLAGSTAT_ZSTD_SCANNERS;  // waves per role of the execution kernel (profile output divides by them)
 
 // Status codes of a frame.  1..63: the frame is damaged; from 64: valid Zstandard this decoder does not take (skippable or
 // concatenated frames, dictionaries, content checksums, more than kZstdMaxBlocks blocks, frames above kZstdMaxFrameBytes) --
@@ -57,7 +67,10 @@ uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes);
 hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
                            unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int prof,
                            hipStream_t stream);
-// workgroups of the execution kernel one CU holds at once (occupancy query; 0 on failure)
+// waves per role of the execution kernel in this build
+void fsk_zstd_role_waves(int* emitters, int* scanners);
+// workgroups of the execution kernel one CU holds at once (the runtime's occupancy query, which counts registers and LDS per CU
+// but not how a workgroup's waves fall on the four SIMDs: tests/perf/zstd_occupancy.sh measures what really fits; 0 on failure)
 int fsk_zstd_frames_per_cu(void);
 }
 

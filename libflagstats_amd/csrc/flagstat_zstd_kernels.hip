@@ -26,10 +26,11 @@
 //   runs above 16,383 split) and one CHECKPOINT per 64 records (output position, literal position, records valid).  A
 //   block starts with an unknown offset history: the few repeat codes it cannot resolve stay in the records as they are,
 //   and one wave replays those prefixes in frame order at the end.
-// zstd_execute -- ONE WORKGROUP OF TEN WAVES PER FRAME, the pipeline of the LZ4 kernel (flagstat_wgpipe.h) behind a new
+// zstd_execute -- ONE WORKGROUP OF EIGHT WAVES PER FRAME (two per SIMD: a CU holds two frames; with ten waves it held one,
+//   flagstat_zstd_kernels.h), the pipeline of the LZ4 kernel (flagstat_wgpipe.h) behind a new
 //   front end: four EMIT waves take batches of 64 records (a DPP prefix sum places them; markers and literal bytes go into
 //   the 64 KiB + 4 KiB output ring; a match from farther back than the ring -- 6-30 % of the sequences of a flag stream --
-//   is read from the output already flushed to global memory and becomes literal bytes), five SCAN waves turn markers into
+//   is read from the output already flushed to global memory and becomes literal bytes), three SCAN waves turn markers into
 //   one final source per byte, one COPY wave gathers, writes and flushes.
 //
 // Every index is masked, clamped or checked; a damaged frame sets its status word and cannot fault; every wait is bounded.
@@ -1353,6 +1354,9 @@ struct __attribute__((aligned(16))) ZxLds {
 };
 static_assert(ZxLds::kSpan + ZxLds::kChunk <= ZxLds::kMR && ZxLds::kSpan + ZxLds::kChunk + ZxLds::kK <= ZxLds::kAhead + ZxLds::kChunk, "no cyclic wait");
 static_assert(sizeof(ZxLds) <= 81920 && kZxEmit <= 8 && kZxScan <= 7, "two workgroups per CU");
+#ifdef FLAGSTAT_ZSTD_SHIPPED_SPLIT
+static_assert(kZxThreads == 512, "two waves per SIMD: the second workgroup of a CU finds room on every SIMD");
+#endif
 
 // ---- emitters: records -> markers, literal bytes.  Emitter `which` takes the batches (64 records, one checkpoint)
 // which, which + kZxEmit, ...; a checkpoint carries the batch's output and literal positions, so the emitters do not depend
@@ -1638,6 +1642,12 @@ extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* 
         hipLaunchKernelGGL((fsk::zstd_execute<false>), grid, dim3(fsk::kZxThreads), 0, stream, blocks, sc, lay, out, status, tally);
     }
     return hipGetLastError();
+}
+
+extern "C" void fsk_zstd_role_waves(int* emitters, int* scanners)
+{
+    *emitters = fsk::kZstdEmitters;
+    *scanners = fsk::kZstdScanners;
 }
 
 extern "C" int fsk_zstd_frames_per_cu(void)

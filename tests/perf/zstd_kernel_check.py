@@ -131,10 +131,13 @@ def main():
         nbad = sum(1 for i in range(args.many) if st[i] != 0 or got[i] != raws[i])
         if args.prof:
             nb = float(args.many)
+            ne, ns = ctypes.c_int(0), ctypes.c_int(0)
+            lib.fsk_zstd_role_waves(ctypes.byref(ne), ctypes.byref(ns))
+            ne, ns = ne.value, ns.value
             print("cycles per frame: prepare %.3g (literals %.3g, tables %.3g) | chain %.3g per wave of two frames = %.0f per step (%.0f steps a frame) | records %.3g (%.1f relaxation rounds a batch, %.0f batches) | "
-                  "emit %.3g x4 (waiting %.0f %%), scan %.3g x5 (waiting %.0f %%), copy %.3g (waiting %.0f %%) | %.0f batches, %.0f groups, %.0f chunks" % (
+                  "emit %.3g x%d (waiting %.0f %%), scan %.3g x%d (waiting %.0f %%), copy %.3g (waiting %.0f %%) | %.0f batches, %.0f groups, %.0f chunks" % (
                 tally[17] / nb, tally[18] / nb, tally[19] / nb, tally[20] / max(tally[21], 1), tally[20] / max(tally[21], 1) / max(tally[22] / nb / 8, 1), tally[22] / nb, tally[23] / nb,
-                tally[24] / max(tally[25], 1), tally[25] / nb, tally[15] / nb / 4, 100.0 * tally[16] / max(tally[15], 1), tally[8] / nb / 5, 100.0 * tally[9] / max(tally[8], 1),
+                tally[24] / max(tally[25], 1), tally[25] / nb, tally[15] / nb / ne, ne, 100.0 * tally[16] / max(tally[15], 1), tally[8] / nb / ns, ns, 100.0 * tally[9] / max(tally[8], 1),
                 tally[12] / nb, 100.0 * tally[13] / max(tally[12], 1), tally[5] / nb, tally[6] / nb, tally[14] / nb))
         print("%d frames of 1,024,000 bytes (zstd-1): %d wrong, best %.2f ms = %.1f Gflags/s; %d records, %d far" % (args.many, nbad, ms, args.many * per / ms / 1e6, tally[0], tally[1]), flush=True)
         bad += nbad

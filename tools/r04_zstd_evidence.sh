@@ -15,4 +15,5 @@ rm -rf gpurun_out/zstd_stats
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/zstd_stats -- python3 tests/perf/trace_lz4_gpu.py 2147483648 zstd:1 > gpurun_out/zstd_stats.log 2>&1
 find gpurun_out/zstd_stats -name "*kernel_stats.csv" -exec cp {} gpurun_out/zstd_kernel_stats.csv \;
 rm -rf gpurun_out/zstd_stats gpurun_out/lz_timeline
+ZOCC_SIZES="256 512 768 1024 1536 2048" bash tests/perf/zstd_occupancy.sh gpurun_out/zstd_occupancy.log > /dev/null 2>&1
 tail -4 gpurun_out/zstd_*.log | head -120; head -12 gpurun_out/zstd_kernel_stats.csv
