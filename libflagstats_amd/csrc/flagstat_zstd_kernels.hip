@@ -830,6 +830,12 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
     ZBlk* const blk = reinterpret_cast<ZBlk*>(scratch + lay.blk_at) + static_cast<uint64_t>(fact ? fi : 0u) * lay.blk_cap;
     uint32_t* const stash = reinterpret_cast<uint32_t*>(scratch + lay.stash_at) + static_cast<uint64_t>(fact ? fi : 0u) * lay.rec_stride * 3u;
     const uint32_t nblk = fact ? reinterpret_cast<const ZFrameHdr*>(scratch + lay.hdr_at)[fi].nblk : 0u;
+    // the two frames' payloads, wave-uniform (lanes 0 and 8 hold them; a frame that is not walked has length 0 and no block asks)
+    const uint64_t off_a = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(gb.src_off)), 0))) |
+                           (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(gb.src_off >> 32)), 0))) << 32);
+    const uint64_t off_b = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(gb.src_off)), 8))) |
+                           (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(gb.src_off >> 32)), 8))) << 32);
+    const int32_t n_a = __builtin_amdgcn_readlane(static_cast<int>(n), 0), n_b = __builtin_amdgcn_readlane(static_cast<int>(n), 8);
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     unsigned long long n_steps = 0;
     // passes of eight blocks per frame, as many as the frame with the most blocks needs
@@ -863,27 +869,41 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
         int32_t pos = act ? static_cast<int32_t>(8u * (d.bend - 1u) + highbit(frame[d.bend - 1u])) : 0;
         const int32_t start_bit = static_cast<int32_t>(8u * d.bits_at);
         int32_t rlo = act ? ((pos >> 3) & ~static_cast<int32_t>(kZcChunk - 1u)) + static_cast<int32_t>(kZcChunk) : 0;
-        const uint32_t src_lo = static_cast<uint32_t>(gb.src_off), src_hi = static_cast<uint32_t>(gb.src_off >> 32);
+        // Refill: block j's chunk is 128 bytes = eight 16-byte pieces; lane l serves piece (l & 7) of block (l >> 3) (frame A's
+        // blocks) AND of block 8 + (l >> 3) (frame B's), so ONE pass serves all sixteen blocks with both global loads in flight
+        // together (a loop over the asking blocks, one dependent load each, paid a full memory latency per block -- and twice
+        // that while a copy from the host was running).
         auto refill = [&](bool want) {
             // lanes that want a chunk and have room for it: the bytes it overwrites lie above the window
             const bool can = want && ((pos >> 3) - (rlo - static_cast<int32_t>(kZcChunk)) <= static_cast<int32_t>(kZcRing) - 1);
-            uint64_t m = __builtin_amdgcn_ballot_w64(can) & ((1ull << kZcLanes) - 1ull);
-            while (m) {
-                const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(m));
-                m &= m - 1ull;
-                const int32_t nlo = __builtin_amdgcn_readlane(rlo, j) - static_cast<int32_t>(kZcChunk);
-                const uint64_t joff = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src_lo), j))) |
-                                      (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(src_hi), j))) << 32);
-                const int32_t jn = static_cast<int32_t>(__builtin_amdgcn_readlane(static_cast<int>(n), j));
-                if (lane >= kZcChunk / 4u) continue;
+            const uint32_t m = static_cast<uint32_t>(__builtin_amdgcn_ballot_w64(can)) & ((1u << kZcLanes) - 1u);
+            if (m) {
+                const uint32_t ba = lane >> 3, bb = 8u + (lane >> 3), piece = 16u * (lane & 7u);
+                const int32_t nlo_a = __builtin_amdgcn_ds_bpermute(static_cast<int>(4u * ba), rlo) - static_cast<int32_t>(kZcChunk);
+                const int32_t nlo_b = __builtin_amdgcn_ds_bpermute(static_cast<int>(4u * bb), rlo) - static_cast<int32_t>(kZcChunk);
+                const bool sa = (m >> ba) & 1u, sb = (m >> bb) & 1u;
+                typedef uint32_t v4u1 __attribute__((ext_vector_type(4), aligned(1)));
+                typedef uint32_t v4u16 __attribute__((ext_vector_type(4)));
                 // (never below the buffer, never beyond the 64 readable bytes behind the payload: what lies there is never used)
-                int32_t rel = nlo + 4 * static_cast<int32_t>(lane);
-                if (rel > jn + 56) rel = jn + 56;
-                const int64_t src = static_cast<int64_t>(joff) + rel;
-                const uint32_t v = ld_le32(comp + (src < 0 ? 0 : src));
-                const uint32_t ri = (static_cast<uint32_t>(nlo) & (kZcRing - 1u)) + 4u * lane;
-                *reinterpret_cast<uint32_t*>(&L.ring[j][ri]) = v;
-                if (ri < 16u) *reinterpret_cast<uint32_t*>(&L.ring[j][kZcRing + ri]) = v;
+                auto source = [&](const uint64_t joff, const int32_t jn, const int32_t nlo) -> const uint8_t* {
+                    int32_t rel = nlo + static_cast<int32_t>(piece);
+                    if (rel > jn + 48) rel = jn + 48;
+                    const int64_t src = static_cast<int64_t>(joff) + rel;
+                    return comp + (src < 0 ? 0 : src);
+                };
+                v4u16 va = {0u, 0u, 0u, 0u}, vb = {0u, 0u, 0u, 0u};
+                if (sa) va = *reinterpret_cast<const v4u1*>(source(off_a, n_a, nlo_a));
+                if (sb) vb = *reinterpret_cast<const v4u1*>(source(off_b, n_b, nlo_b));
+                if (sa) {
+                    const uint32_t ri = (static_cast<uint32_t>(nlo_a) & (kZcRing - 1u)) + piece;
+                    *reinterpret_cast<v4u16*>(&L.ring[ba][ri]) = va;
+                    if (ri == 0u) *reinterpret_cast<v4u16*>(&L.ring[ba][kZcRing]) = va;
+                }
+                if (sb) {
+                    const uint32_t ri = (static_cast<uint32_t>(nlo_b) & (kZcRing - 1u)) + piece;
+                    *reinterpret_cast<v4u16*>(&L.ring[bb][ri]) = vb;
+                    if (ri == 0u) *reinterpret_cast<v4u16*>(&L.ring[bb][kZcRing]) = vb;
+                }
             }
             if (can) rlo -= static_cast<int32_t>(kZcChunk);
         };
