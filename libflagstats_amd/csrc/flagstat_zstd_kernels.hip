@@ -837,7 +837,7 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
                            (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(static_cast<int>(static_cast<uint32_t>(gb.src_off >> 32)), 8))) << 32);
     const int32_t n_a = __builtin_amdgcn_readlane(static_cast<int>(n), 0), n_b = __builtin_amdgcn_readlane(static_cast<int>(n), 8);
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
-    unsigned long long n_steps = 0;
+    unsigned long long n_steps = 0, t_refill = 0, n_refill = 0;
     // passes of eight blocks per frame, as many as the frame with the most blocks needs
     uint32_t passes = (nblk + 7u) >> 3;
     passes = __builtin_amdgcn_readlane(wave_scan_max(passes), 63);
@@ -999,8 +999,14 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
             // (a lane whose window would run out of staged bytes within five steps asks for a chunk; the wave copies -- and the
             // lanes the refill served load their window again: it was read before the chunk arrived)
             if (__builtin_amdgcn_ballot_w64(act && i < nupd && (pos >> 3) - rlo < 96)) {
+                const unsigned long long t0 = PROF ? __builtin_readcyclecounter() : 0ull;
                 refill(act && i < nupd && (pos >> 3) - rlo < static_cast<int32_t>(kZcRing / 2u));
                 window(la.dw);
+                if (PROF) {
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    t_refill += __builtin_readcyclecounter() - t0;
+                    ++n_refill;
+                }
             }
             // (every lane that still steps has taken a multiple of four steps here: its next step reads `la`)
             chain_step(act && i < nupd, true, la, lb);
@@ -1024,6 +1030,8 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
     if (PROF && lane == 0u) {
         atomicAdd(&tally[20], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
         atomicAdd(&tally[21], 1ull);
+        atomicAdd(&tally[26], t_refill);
+        atomicAdd(&tally[27], n_refill);
     }
     if (PROF) atomicAdd(&tally[22], n_steps);
 }

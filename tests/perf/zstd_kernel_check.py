@@ -139,6 +139,9 @@ def main():
                 tally[17] / nb, tally[18] / nb, tally[19] / nb, tally[20] / max(tally[21], 1), tally[20] / max(tally[21], 1) / max(tally[22] / nb / 8, 1), tally[22] / nb, tally[23] / nb,
                 tally[24] / max(tally[25], 1), tally[25] / nb, tally[15] / nb / ne, ne, 100.0 * tally[16] / max(tally[15], 1), tally[8] / nb / ns, ns, 100.0 * tally[9] / max(tally[8], 1),
                 tally[12] / nb, 100.0 * tally[13] / max(tally[12], 1), tally[5] / nb, tally[6] / nb, tally[14] / nb))
+        if args.prof:
+            print("chain, per wave of two frames: %.0f refills of the bit-stream rings, %.0f cycles each = %.1f %% of the wave's cycles" % (
+                tally[27] / max(tally[21], 1), tally[26] / max(tally[27], 1), 100.0 * tally[26] / max(tally[20], 1)))
         print("%d frames of 1,024,000 bytes (zstd-1): %d wrong, best %.2f ms = %.1f Gflags/s; %d records, %d far" % (args.many, nbad, ms, args.many * per / ms / 1e6, tally[0], tally[1]), flush=True)
         bad += nbad
     print("FAILED: %d" % bad if bad else "all exact")
