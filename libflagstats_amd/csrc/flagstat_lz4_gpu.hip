@@ -199,9 +199,10 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     if (ck) {
         npieces = static_cast<uint32_t>(std::atoi(ck));
     } else if (zstd) {
-        // Zstandard: at most 1024 frames a piece, two pieces at least -- the chain kernel holds 1536 frames at a time and a
-        // frame takes ~8 ms through the four kernels whatever else runs, so few large launches, two of them in flight; the
-        // stash, records, literals and checkpoints between the kernels take 8.5 MB of scratch per frame and decode stream
+        // Zstandard: an equal share is at most 1024 frames, two pieces at least (the first is half a share, the others up to
+        // 1536 frames then: what the chain kernel holds at a time) -- a frame takes ~6 ms through the four kernels whatever
+        // else runs, so few large launches, two of them in flight; the stash, records, literals and checkpoints between the
+        // kernels take 8.5 MB of scratch per frame and decode stream
         npieces = static_cast<uint32_t>((blocks.size() + 1023) / 1024);
         if (npieces < 2) npieces = 2;
     } else if (kernel == fsk::LZ4K_WORKGROUP) {
@@ -241,9 +242,20 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         uint64_t first, last, lo, hi;
     };
     std::vector<Piece> pieces;
+    // Zstandard: the first piece is half an equal share -- the decode starts when it has landed, and its four kernels take
+    // 5 ms before the second stream has anything to do (2^31 flags 43.0 -> 40.5 ms, the README-size file 21.3 -> 19.1 ms;
+    // LZ4, whose pieces are a sixteenth of the file, does not gain: profiles/r04/first_piece.log).  env FLAGSTATS_HIP_GPU_FIRST_PIECE
+    // = per cent of an equal share overrides (0 / 100: equal pieces).
+    const char* fpk = std::getenv("FLAGSTATS_HIP_GPU_FIRST_PIECE");
+    int first_pct = fpk ? std::atoi(fpk) : (zstd ? 50 : 0);
+    if (first_pct < 0 || first_pct >= 100) first_pct = 0;
     for (uint64_t first = 0; pieces.size() < npieces && first < blocks.size();) {
         const uint64_t c = pieces.size();
-        const uint64_t target = bytes / npieces * (c + 1);
+        uint64_t target = bytes / npieces * (c + 1);
+        if (first_pct > 0 && npieces > 1) {
+            const uint64_t t0 = bytes / npieces * static_cast<uint64_t>(first_pct) / 100u;
+            target = t0 + (bytes - t0) / (npieces - 1) * c;
+        }
         uint64_t last = first + 1;
         while (last < blocks.size() && (c + 1 == npieces || blocks[last].src_off + blocks[last].src_len <= target)) ++last;
         pieces.push_back(Piece{first, last, blocks[first].src_off - 8, blocks[last - 1].src_off + blocks[last - 1].src_len});

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--mode", default="zstd:1")
     ap.add_argument("--pieces", default="0,3,4,5,6,8")
     ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--first", default="0", help="first piece as a percentage of an equal share (100: equal pieces; 0: the shipped rule), comma list")
     args = ap.parse_args()
     import oracle
     n = int(eval(args.flags))
@@ -41,7 +42,11 @@ def main():
     _lib.check(lib.FLAGSTATS_hip_set(b"zstd_decoder" if zstd else b"lz4_decoder", 1), "set")
     entry = lib.FLAGSTATS_hip_blockimage_zstd if zstd else lib.FLAGSTATS_hip_blockimage_lz4
     print("%s  %s-%s, %d flags, %.0f MiB" % (os.path.basename(_lib.LIB_PATH), mode, level, n, buf.size / 2**20), flush=True)
-    for pc in [int(x) for x in args.pieces.split(",")]:
+    for pc, fp in [(int(x), int(y)) for x in args.pieces.split(",") for y in args.first.split(",")]:
+        if fp:
+            os.environ["FLAGSTATS_HIP_GPU_FIRST_PIECE"] = str(fp)
+        else:
+            os.environ.pop("FLAGSTATS_HIP_GPU_FIRST_PIECE", None)
         if pc:
             os.environ["FLAGSTATS_HIP_GPU_LZ4_CHUNKS"] = str(pc)
         else:
@@ -55,7 +60,7 @@ def main():
             ts.append(time.perf_counter() - t0)
             assert np.array_equal(out, want) and st.gpu_decode == 1
         ts = ts[1:]
-        print("   pieces %-8s best %6.1f ms  median %6.1f ms  = %5.1f Gflags/s  (%d pieces ran)" % (pc or "rule", min(ts) * 1e3, sorted(ts)[len(ts) // 2] * 1e3, n / min(ts) / 1e9, st.chunks), flush=True)
+        print("   pieces %-8s first %3d %% (0 = rule)  best %6.1f ms  median %6.1f ms  = %5.1f Gflags/s  (%d pieces ran)" % (pc or "rule", fp, min(ts) * 1e3, sorted(ts)[len(ts) // 2] * 1e3, n / min(ts) / 1e9, st.chunks), flush=True)
 
 
 if __name__ == "__main__":
