@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--mode", default="zstd:1")
     ap.add_argument("--pieces", default="0,3,4,5,6,8")
     ap.add_argument("--reps", type=int, default=4)
+    ap.add_argument("--pinned", type=int, default=0, help="1: the image in page-locked host memory (the runtime then copies it with the DMA engines, not with a staged shader copy)")
     ap.add_argument("--first", default="0", help="first piece as a percentage of an equal share (100: equal pieces; 0: the shipped rule), comma list")
     args = ap.parse_args()
     import oracle
@@ -36,12 +37,17 @@ def main():
         buf = np.frombuffer(build_image(n, mode, int(level)), dtype=np.uint8)
         buf.tofile(cache)
     want = oracle.flagstat_generated(oracle.GEN_NA12878, 7, 1, 0, n)
+    if args.pinned:
+        import torch
+        keep = torch.empty(buf.size, dtype=torch.uint8).pin_memory()
+        keep.numpy()[:] = buf
+        buf = keep.numpy()
     lib = _lib.lib()
     _lib.check(lib.FLAGSTATS_hip_init(0), "init")
     zstd = mode == "zstd"
     _lib.check(lib.FLAGSTATS_hip_set(b"zstd_decoder" if zstd else b"lz4_decoder", 1), "set")
     entry = lib.FLAGSTATS_hip_blockimage_zstd if zstd else lib.FLAGSTATS_hip_blockimage_lz4
-    print("%s  %s-%s, %d flags, %.0f MiB" % (os.path.basename(_lib.LIB_PATH), mode, level, n, buf.size / 2**20), flush=True)
+    print("%s  %s-%s, %d flags, %.0f MiB%s" % (os.path.basename(_lib.LIB_PATH), mode, level, n, buf.size / 2**20, ", image page-locked" if args.pinned else ""), flush=True)
     for pc, fp in [(int(x), int(y)) for x in args.pieces.split(",") for y in args.first.split(",")]:
         if fp:
             os.environ["FLAGSTATS_HIP_GPU_FIRST_PIECE"] = str(fp)
