@@ -16,8 +16,8 @@
 //   base (number << bits) - size) and 1-byte symbols.
 // zstd_chain -- ONE WAVE PER TWO FRAMES, a lane per block, the walk and nothing else: a wave costs the same with one lane
 //   or sixty-four and a block's chain tables take 2.5 KB of LDS, so sixteen blocks walk side by side.  A step is ONE LDS
-//   round trip -- three table entries and a 16-byte window of the bit stream (staged through a 512-byte ring per lane,
-//   refilled 128 bytes at a time by the whole wave) -- and ~90 instructions; what it saw (three states, 64 bits of the
+//   round trip -- three table entries and a 16-byte window of the bit stream (staged through a 512-byte ring per lane;
+//   one refill pass serves all sixteen blocks, a lane per 16-byte piece, both loads in flight) -- and ~85 instructions; what it saw (three states, 64 bits of the
 //   window) goes to the stash in global memory.
 // zstd_records -- ONE WORKGROUP PER FRAME, a wave per block, a lane per sequence, 64 at a time: symbols gathered from the
 //   states (a batch ahead), values of the codes, positions by prefix sums, repeat offsets by RELAXATION over the lanes (a
