@@ -230,6 +230,41 @@ def test_gpu_zstd_decoder_goes_through_large_files_in_segments(zgpu, tmp_path, m
         monkeypatch.delenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES")
 
 
+def test_gpu_zstd_decoder_with_every_cut_of_the_pieces(zgpu, tmp_path, monkeypatch):
+    """The host side cuts a file into pieces of whole frames (the first one half an equal share by default) and decodes them
+    on two streams: every piece count from one to more than there are frames, with the first piece at 1 / 25 / 50 / 99 % of
+    a share and with equal pieces, gives the same counters -- image and file mode, frames of ragged sizes."""
+    import oracle
+    from libflagstats_amd import blockfile
+    rng = np.random.default_rng(77)
+    blocks = []
+    for i in range(13):
+        k = int(rng.integers(1, 60000))
+        blocks.append(oracle.generate(oracle.GEN_NA12878, 40 + i, 1, 0, k).tobytes())
+    blocks.append(oracle.generate(oracle.GEN_UNIFORM, 3, 0x0FFF, 0, 512000).tobytes())
+    img = image_of(blocks, level=3)
+    want = expect_blocks(blocks)
+    path = tmp_path / "cuts.zst"
+    path.write_bytes(img)
+    for pieces in (1, 2, 3, 5, 13, 14, 40):
+        for first in (None, 1, 25, 50, 99, 100):
+            monkeypatch.setenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS", str(pieces))
+            if first is None:
+                monkeypatch.delenv("FLAGSTATS_HIP_GPU_FIRST_PIECE", raising=False)
+            else:
+                monkeypatch.setenv("FLAGSTATS_HIP_GPU_FIRST_PIECE", str(first))
+            got, st = blockfile.flagstat_zstd_image(img, 2)
+            assert np.array_equal(got, want) and st["gpu_decode"] == 1, (pieces, first)
+            assert 1 <= st["chunks"] <= min(pieces, len(blocks))
+            if pieces in (2, 13):
+                got, st = blockfile.flagstat_zstd_file(str(path), 3)
+                assert np.array_equal(got, want) and st["gpu_decode"] == 1, (pieces, first)
+    monkeypatch.delenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS")
+    monkeypatch.delenv("FLAGSTATS_HIP_GPU_FIRST_PIECE", raising=False)
+    got, st = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want) and st["chunks"] == 2   # (the shipped rule: two pieces at least)
+
+
 def test_gpu_zstd_decoder_keeps_and_releases_its_device_memory(zgpu):
     """The two large buffers AND the scratch between the kernels stay with the engine for the next file, go after eight calls of
     other entry points and after a failed call (knob lz4_gpu_keep_bytes; read-only lz4_gpu_kept_bytes)."""
