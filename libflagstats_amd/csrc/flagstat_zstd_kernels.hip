@@ -808,6 +808,13 @@ __global__ __launch_bounds__(64) void zstd_prepare(const uint8_t* __restrict__ c
 // block's chain tables take 2.5 KB of LDS, so a wave walks the blocks of TWO frames at once, a lane per block; what a step
 // saw (the three states, 64 bits of the window) goes to the stash in global memory for zstd_records.
 constexpr uint32_t kZcFrames = 2, kZcLanes = 8u * kZcFrames;
+// Waves per workgroup: THREE, each with its own two frames and its own 49 KB of LDS, so that a workgroup fills a CU's LDS and
+// a launch of W waves takes W / 3 CUs whole instead of leaving one or two waves (49-98 KB) on every CU of the chip, beside
+// which not one 80 KB workgroup of the other stream's execution kernel fits.  The waves never meet: no barrier between them.
+#ifndef FLAGSTAT_ZSTD_CHAIN_WAVES
+#define FLAGSTAT_ZSTD_CHAIN_WAVES 3
+#endif
+constexpr uint32_t kZcWaves = FLAGSTAT_ZSTD_CHAIN_WAVES;
 constexpr uint32_t kZcRing = 512, kZcChunk = 128;   // bytes of a block's bit stream staged in LDS, bytes a refill
 
 struct __attribute__((aligned(16))) ZcLds {
@@ -816,13 +823,18 @@ struct __attribute__((aligned(16))) ZcLds {
 };
 
 template <bool PROF>
-__global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks, uint8_t* __restrict__ scratch,
+__global__ __launch_bounds__(64 * kZcWaves) void zstd_chain(const uint8_t* __restrict__ comp, const GpuBlock* __restrict__ blocks, uint8_t* __restrict__ scratch,
                                                  const ZLayout lay, const uint32_t* __restrict__ status, unsigned long long* __restrict__ tally)
 {
-    __shared__ ZcLds L;
-    const uint32_t lane = threadIdx.x;
+    __shared__ ZcLds Lw[kZcWaves];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    ZcLds& L = Lw[wave];
+    const uint32_t pair = blockIdx.x * kZcWaves + wave;   // this wave's two frames
+    const uint32_t lane = threadIdx.x & 63u;
+    // (orders this wave's LDS writes before its reads; the LDS operations of one wave execute in order)
+    auto wave_sync = [] { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); };
     const uint32_t slot = lane >> 3, bk = lane & 7u;
-    const uint32_t fi = blockIdx.x * kZcFrames + slot;
+    const uint32_t fi = pair * kZcFrames + slot;
     const bool fact = lane < kZcLanes && fi < lay.nframes && status[fi] == 0u;
     const GpuBlock gb = fact ? blocks[fi] : GpuBlock{0, 0, 0, 0};
     const uint8_t* const frame = comp + gb.src_off;
@@ -854,7 +866,7 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
             while (m) {
                 const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(m));
                 m &= m - 1ull;
-                const uint32_t jf = blockIdx.x * kZcFrames + (j >> 3), jb = pass * 8u + (j & 7u);
+                const uint32_t jf = pair * kZcFrames + (j >> 3), jb = pass * 8u + (j & 7u);
                 const uint4* const src = reinterpret_cast<const uint4*>(scratch + lay.tab_at + (static_cast<uint64_t>(jf) * lay.blk_cap + jb) * kTabBytes);
                 uint4* const dst = reinterpret_cast<uint4*>(L.tab[j]);
                 for (uint32_t q = lane; q < 2560u / 16u; q += 64u) dst[q] = src[q];
@@ -908,7 +920,7 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
             if (can) rlo -= static_cast<int32_t>(kZcChunk);
         };
         for (int k = 0; k < 4; ++k) refill(act);
-        __syncthreads();
+        wave_sync();
         const uint32_t home = lane & (kZcLanes - 1u);
         const uint16_t* const T = L.tab[home];
         const uint32_t sizel = 1u << logl, sizeo = 1u << logo, sizem = 1u << logm;
@@ -1025,7 +1037,7 @@ __global__ __launch_bounds__(64) void zstd_chain(const uint8_t* __restrict__ com
         chain_step(act && i < nseq, false, fin, lb);
         if (have && d.type == 2u && d.nseq > 0u && !lerr && pos != start_bit) lerr = kZstdBadBitstream;
         if (have && lerr) blk[b].chain_err = lerr;
-        __syncthreads();
+        wave_sync();
     }
     if (PROF && lane == 0u) {
         atomicAdd(&tally[20], static_cast<unsigned long long>(__builtin_readcyclecounter()) - t_begin);
@@ -1657,15 +1669,16 @@ extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* 
     if (lay.total > scratch_bytes) return hipErrorInvalidValue;
     uint8_t* const sc = static_cast<uint8_t*>(scratch);
     const dim3 grid(nblocks);
-    const dim3 pairs((nblocks + fsk::kZcFrames - 1u) / fsk::kZcFrames);
+    const uint32_t npairs = (nblocks + fsk::kZcFrames - 1u) / fsk::kZcFrames;
+    const dim3 pairs((npairs + fsk::kZcWaves - 1u) / fsk::kZcWaves);
     if (prof) {
         hipLaunchKernelGGL((fsk::zstd_prepare<true>), grid, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
-        hipLaunchKernelGGL((fsk::zstd_chain<true>), pairs, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_chain<true>), pairs, dim3(64 * fsk::kZcWaves), 0, stream, comp, blocks, sc, lay, status, tally);
         hipLaunchKernelGGL((fsk::zstd_records<true>), grid, dim3(64 * fsk::kZvWaves), 0, stream, blocks, sc, lay, status, tally);
         hipLaunchKernelGGL((fsk::zstd_execute<true>), grid, dim3(fsk::kZxThreads), 0, stream, blocks, sc, lay, out, status, tally);
     } else {
         hipLaunchKernelGGL((fsk::zstd_prepare<false>), grid, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
-        hipLaunchKernelGGL((fsk::zstd_chain<false>), pairs, dim3(64), 0, stream, comp, blocks, sc, lay, status, tally);
+        hipLaunchKernelGGL((fsk::zstd_chain<false>), pairs, dim3(64 * fsk::kZcWaves), 0, stream, comp, blocks, sc, lay, status, tally);
         hipLaunchKernelGGL((fsk::zstd_records<false>), grid, dim3(64 * fsk::kZvWaves), 0, stream, blocks, sc, lay, status, tally);
         hipLaunchKernelGGL((fsk::zstd_execute<false>), grid, dim3(fsk::kZxThreads), 0, stream, blocks, sc, lay, out, status, tally);
     }
