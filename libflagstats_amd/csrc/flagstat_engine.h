@@ -94,7 +94,10 @@ struct Engine {
     void* pinned[3] = {nullptr, nullptr, nullptr}; // block-file chunk buffers, kept across calls
     uint8_t* lz4_buf[2] = {nullptr, nullptr};      // GPU LZ4 decoder: compressed / decoded bytes of a segment, kept across calls
     uint64_t lz4_cap[2] = {0, 0};                  // (knob "lz4_gpu_keep_bytes"; released after kLz4IdleCalls other calls)
-    static constexpr int kLz4Streams = 2, kLz4MaxPieces = 64, kLz4IdleCalls = 8;
+#ifndef FLAGSTAT_DECODE_STREAMS   // (measurement builds: more decode streams)
+#define FLAGSTAT_DECODE_STREAMS 2
+#endif
+    static constexpr int kLz4Streams = FLAGSTAT_DECODE_STREAMS, kLz4MaxPieces = 64, kLz4IdleCalls = 8;
     hipStream_t lz4_stream[kLz4Streams] = {};      // ... its decode streams, events and small device buffers, made on first use
     hipEvent_t lz4_ev[4] = {};                     // start, copies queued, decoded + counted (timed); index on the device
     hipEvent_t lz4_landed[kLz4MaxPieces] = {}, lz4_joined[kLz4Streams] = {}, lz4_pin_free[3] = {};
