@@ -474,7 +474,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     stats->count_ms += 0;  // (a piece is counted behind its decode: part of decode_ms)
     stats->sequences += tally[0];
     stats->far_matches += tally[1];
-    stats->ring_kib = zstd ? 68 : (kernel == fsk::LZ4K_WORKGROUP ? 66 : (kernel == fsk::LZ4K_WAVE ? 8 : 16));
+    stats->ring_kib = zstd ? (fsk::kZstdWindow + 4096u) / 1024u : (kernel == fsk::LZ4K_WORKGROUP ? 66 : (kernel == fsk::LZ4K_WAVE ? 8 : 16));
     stats->chunks += pieces_done;
     stats->pipeline_ms += pipe;
     stats->readers = static_cast<uint64_t>(readers);

@@ -27,6 +27,17 @@ constexpr int kZstdTallyWords = 32;             // unsigned long long words of t
 #endif
 constexpr int kZstdEmitters = FLAGSTAT_ZSTD_EMITTERS, kZstdScanners = FLAGSTAT_ZSTD_SCANNERS;  // waves per role of the execution kernel (profile output divides by them)
 
+// Bytes of output the ring keeps for near matches: 32 KiB, not the 64 KiB it could.  What limits this kernel is LDS: a second
+// workgroup on a CU costs 22 % of its time and a third little more, and with 32 + 4 KiB of ring a workgroup takes 47 KB = THREE a CU
+// (24 waves: 80 VGPRs each, which costs four spilled registers); the matches between 32 and 64 KiB back take the far path
+// (flushed output, global loads) that those beyond 64 KiB take anyway.  2^31 flags 40.3 -> 37.1 ms at level 1, 43.3 -> 40.8 at level
+// 19 (profiles/r04/zstd_window.log).  Measurement builds: -DFLAGSTAT_ZSTD_WINDOW=65536 -DFLAGSTAT_ZSTD_EXEC_WAVES_PER_SIMD=4.
+#ifndef FLAGSTAT_ZSTD_WINDOW
+#define FLAGSTAT_ZSTD_WINDOW 32768
+#define FLAGSTAT_ZSTD_EXEC_WAVES_PER_SIMD 6
+#endif
+constexpr uint32_t kZstdWindow = FLAGSTAT_ZSTD_WINDOW;
+
 // Status codes of a frame.  1..63: the frame is damaged; from 64: valid Zstandard this decoder does not take (skippable or
 // concatenated frames, dictionaries, content checksums, more than kZstdMaxBlocks blocks, frames above kZstdMaxFrameBytes) --
 // the host decodes such a file with libzstd.

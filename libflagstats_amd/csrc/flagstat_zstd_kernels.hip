@@ -1376,12 +1376,13 @@ __global__ __launch_bounds__(64 * kZvWaves) void zstd_records(const GpuBlock* __
 // ------------------------------------------------------------------------------------------------ zstd_execute
 constexpr uint32_t kZxEmit = kZstdEmitters, kZxScan = kZstdScanners;   // (six emitters: a batch with far matches waits a microsecond or two for the global loads)
 constexpr uint32_t kZxThreads = 64u * (kZxEmit + kZxScan + 1u);
-constexpr uint32_t kZxNear = 65535u;   // matches up to this far back read the ring; farther ones the flushed output
+constexpr uint32_t kZxWindow = kZstdWindow;   // (flagstat_zstd_kernels.h)
+constexpr uint32_t kZxNear = kZxWindow - 1u;   // matches up to this far back read the ring; farther ones the flushed output
 
 struct __attribute__((aligned(16))) ZxLds {
-    static constexpr uint32_t kNR = 65536u + 4096u, kMR = 2048u, kK = 512u, kChunk = 256u, kFlush = 1024u, kScan = kZxScan;
+    static constexpr uint32_t kNR = kZxWindow + 4096u, kMR = 2048u, kK = 512u, kChunk = 256u, kFlush = 1024u, kScan = kZxScan;
     static constexpr bool kPublishFlush = true;
-    static constexpr uint32_t kAhead = kNR - 65536u - kChunk;   // the emitters' position may lead the copier's by this much
+    static constexpr uint32_t kAhead = kNR - kZxWindow - kChunk;   // the emitters' position may lead the copier's by this much
     static constexpr uint32_t kSpan = 1536u;                    // most output bytes an emitter writes before publishing
     uint8_t ring[kNR];
     uint32_t mark[kMR];
@@ -1393,7 +1394,7 @@ struct __attribute__((aligned(16))) ZxLds {
     uint32_t c_ready, s_carry[8], err;
 };
 static_assert(ZxLds::kSpan + ZxLds::kChunk <= ZxLds::kMR && ZxLds::kSpan + ZxLds::kChunk + ZxLds::kK <= ZxLds::kAhead + ZxLds::kChunk, "no cyclic wait");
-static_assert(sizeof(ZxLds) <= 81920 && kZxEmit <= 8 && kZxScan <= 7, "two workgroups per CU");
+static_assert(sizeof(ZxLds) <= (kZxWindow == 32768u ? 54000u : 81920u) && kZxEmit <= 8 && kZxScan <= 7, "three (two) workgroups per CU");
 #ifdef FLAGSTAT_ZSTD_SHIPPED_SPLIT
 static_assert(kZxThreads == 512, "two waves per SIMD: the second workgroup of a CU finds room on every SIMD");
 #endif
@@ -1483,16 +1484,25 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
                     const uint32_t r_off = __builtin_amdgcn_readlane(off, lo);
                     const bool r_far = r_ml > 0u && r_off > kZxNear;
                     const uint32_t nlit_bytes = r_ll + (r_far ? r_ml : 0u);   // bytes this record puts into the ring itself
-                    if (r_far) {
-                        ++nfar;
-                        const uint32_t src_end = r_op + r_ll - r_off + r_ml;
-                        if (!wg_wait_timed<PROF>(L, t_wait, [&] { return wg_ld(&L.f_op) >= src_end; })) {
-                            failed = true;
-                            break;
-                        }
-                    }
+                    if (r_far) ++nfar;
                     for (uint32_t done = 0; done < nlit_bytes || done == 0u;) {
                         const uint32_t piece = nlit_bytes - done < 1024u ? nlit_bytes - done : 1024u;
+                        // A piece with match bytes waits for ITS source only (one past its last source byte flushed and landed).
+                        // Waiting for the whole match's source before the first piece can never end: behind 16 KiB of literals
+                        // a 16 KiB match from 32 KiB back ends a few bytes before this record starts, and the copier cannot pass
+                        // the record's start until the pieces before have been published (found by the fuzz when the ring went
+                        // from 64 to 32 KiB; with 64 KiB the source always lay 32 KiB behind the record).  A piece's own source
+                        // lies > 31 KiB behind it, the copier at most 4 KiB + two flush units.
+                        if (r_far && done + piece > r_ll) {
+                            const uint32_t need = r_op + done + piece - r_off;
+                            if (need > f_seen && !wg_wait_timed<PROF>(L, t_wait, [&] {
+                                    f_seen = wg_ld(&L.f_op);
+                                    return f_seen >= need;
+                                })) {
+                                failed = true;
+                                break;
+                            }
+                        }
                         if (!room(r_op + done, piece + 1u)) {
                             failed = true;
                             break;
@@ -1615,7 +1625,7 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
 }
 
 template <bool PROF>
-__global__ __launch_bounds__(kZxThreads, 4) void zstd_execute(const GpuBlock* __restrict__ blocks, const uint8_t* __restrict__ scratch, const ZLayout lay,
+__global__ __launch_bounds__(kZxThreads, FLAGSTAT_ZSTD_EXEC_WAVES_PER_SIMD) void zstd_execute(const GpuBlock* __restrict__ blocks, const uint8_t* __restrict__ scratch, const ZLayout lay,
                                                               uint8_t* __restrict__ out, uint32_t* __restrict__ status, unsigned long long* __restrict__ tally)
 {
     __shared__ ZxLds L;

@@ -107,10 +107,21 @@ def synthetic_blocks(seed):
         (r.integers(0, 256, 17000, dtype=np.uint8).tobytes() + b"x" * 17000) * 12,
         oracle.generate(oracle.GEN_UNIFORM, seed, 0x0FFF, 0, 512000).tobytes(),
     ] + [
-        # a 3000-byte stretch repeated at distances around what the execution kernel keeps in LDS (matches up to 65,535 back read
-        # the ring, farther ones the flushed output) and around the ring's size
+        # a long literal run, then a long match from just beyond the 32 KiB the ring keeps: the match's source ends a few bytes
+        # before the record starts (a wait for the whole source before the record's first piece never ended: kZstdStuck)
+        # (levels 1 and 5 write ONE sequence of 16,383 literals and a 16,383-byte match from 33,266 ... 35,066 back)
+        a[:16383] + bytes(k) + r.integers(0, 256, 16383, dtype=np.uint8).tobytes() + a[:16383] + b"tail" * 9
+        for k in (2, 500, 1500, 2300, 4000)
+    ] + [
+        x + r.integers(0, 256, ly, dtype=np.uint8).tobytes() + x + b"tail" * 9
+        for x, ly in ((a[:17000], 16500), (a[:30000], 3000))
+    ] + [
+        # a 3000-byte stretch repeated at distances around what the execution kernel keeps in LDS (matches up to 32,767 back read
+        # the ring, farther ones the flushed output), around the ring's size (36 KiB), around the 64 KiB an earlier form of
+        # the kernel kept, and around the block size
         a[:3000] + r.integers(0, 256, dist - 3000, dtype=np.uint8).tobytes() + a[:3000] + b"tail" * 50
-        for dist in (65534, 65535, 65536, 65537, 68607, 69631, 69632, 69633, 131071, 131072, 131073)
+        for dist in (32766, 32767, 32768, 32769, 35839, 36863, 36864, 36865, 65534, 65535, 65536, 65537, 68607, 69631, 69632,
+                     69633, 131071, 131072, 131073)
     ]
 
 
