@@ -15,8 +15,8 @@ namespace fsk {
 constexpr uint32_t kZstdMaxBlocks = 256;        // Zstandard blocks per frame the GPU decoder takes (more: status kZstdTooManyBlocks)
 constexpr uint32_t kZstdMaxFrameBytes = 1u << 26;  // decoded bytes per frame it takes
 constexpr int kZstdTallyWords = 32;             // unsigned long long words of the tally the kernels add to
-// Waves per role of the execution kernel: 4 emit + 3 scan + 1 copy = EIGHT waves, two per SIMD, so that a CU holds TWO
-// workgroups (2 x 80 KB of LDS).  With ten waves (4 + 5 + 1, what this kernel shipped with first) a workgroup puts 3 + 3 + 2 + 2
+// Waves per role of the execution kernel: 4 emit + 3 scan + 1 copy = EIGHT waves, two per SIMD, so that a CU holds as many
+// workgroups as its LDS allows (two of 80 KB when this was measured, three of 47 KB now: see the ring below).  With ten waves (4 + 5 + 1, what this kernel shipped with first) a workgroup puts 3 + 3 + 2 + 2
 // waves on the four SIMDs and the second workgroup's three do not fit beside them at 95 VGPRs: a CU then held ONE frame
 // (tests/perf/zstd_occupancy.sh: 256 / 512 / 768 / 1024 frames took 1.25 / 2.49 / 3.69 / 4.87 ms; eight waves: 1.44 / 1.76 ms for
 // 256 / 512).  Measurement builds override the split: make HIPFLAGS+=-DFLAGSTAT_ZSTD_EMITTERS=.. -DFLAGSTAT_ZSTD_SCANNERS=..
@@ -30,7 +30,7 @@ constexpr int kZstdEmitters = FLAGSTAT_ZSTD_EMITTERS, kZstdScanners = FLAGSTAT_Z
 // Bytes of output the ring keeps for near matches: 32 KiB, not the 64 KiB it could.  What limits this kernel is LDS: a second
 // workgroup on a CU costs 22 % of its time and a third little more, and with 32 + 4 KiB of ring a workgroup takes 47 KB = THREE a CU
 // (24 waves: 80 VGPRs each, which costs four spilled registers); the matches between 32 and 64 KiB back take the far path
-// (flushed output, global loads) that those beyond 64 KiB take anyway.  2^31 flags 40.3 -> 37.1 ms at level 1, 43.3 -> 40.8 at level
+// (flushed output, global loads) that those beyond 64 KiB take anyway.  2^31 flags 39.9 -> 36.8 ms at level 1, 43.3 -> 39.3 at level
 // 19 (profiles/r04/zstd_window.log).  Measurement builds: -DFLAGSTAT_ZSTD_WINDOW=65536 -DFLAGSTAT_ZSTD_EXEC_WAVES_PER_SIMD=4.
 #ifndef FLAGSTAT_ZSTD_WINDOW
 #define FLAGSTAT_ZSTD_WINDOW 32768

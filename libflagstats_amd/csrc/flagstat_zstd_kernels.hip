@@ -26,10 +26,10 @@
 //   runs above 16,383 split) and one CHECKPOINT per 64 records (output position, literal position, records valid).  A
 //   block starts with an unknown offset history: the few repeat codes it cannot resolve stay in the records as they are,
 //   and one wave replays those prefixes in frame order at the end.
-// zstd_execute -- ONE WORKGROUP OF EIGHT WAVES PER FRAME (two per SIMD: a CU holds two frames; with ten waves it held one,
+// zstd_execute -- ONE WORKGROUP OF EIGHT WAVES PER FRAME (two per SIMD, 47 KB of LDS: a CU holds three frames; with ten waves it held one,
 //   flagstat_zstd_kernels.h), the pipeline of the LZ4 kernel (flagstat_wgpipe.h) behind a new
 //   front end: four EMIT waves take batches of 64 records (a DPP prefix sum places them; markers and literal bytes go into
-//   the 64 KiB + 4 KiB output ring; a match from farther back than the ring -- 6-30 % of the sequences of a flag stream --
+//   the 32 KiB + 4 KiB output ring; a match from farther back than the ring keeps -- 11-38 % of the sequences of a flag stream --
 //   is read from the output already flushed to global memory and becomes literal bytes), three SCAN waves turn markers into
 //   one final source per byte, one COPY wave gathers, writes and flushes.
 //
@@ -1556,7 +1556,7 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
                     uint32_t src_end = (now & far) ? src + ml : 0u;
                     src_end = wave_scan_max(src_end);
                     src_end = __builtin_amdgcn_readlane(src_end, 63);
-                    // (the copier's "flushed and landed" mark, as last seen: a far source lies 64 KiB back, the mark 2 KiB)
+                    // (the copier's "flushed and landed" mark, as last seen: a far source lies 32 KiB back, the mark 2 KiB)
                     if (__builtin_expect(src_end > f_seen, 0)) {
                         if (!wg_wait_timed<PROF>(L, t_wait, [&] {
                                 f_seen = wg_ld(&L.f_op);
