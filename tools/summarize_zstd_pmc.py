@@ -25,7 +25,8 @@ for sub in ("zs_pmc_sq", "zs_pmc_sq2"):
         if sub == "zs_pmc_sq" and key not in seen:
             seen.add(key)
             wg = int(r["Grid_Size"]) // int(r["Workgroup_Size"])
-            frames[k] = frames.get(k, 0) + (2 * wg if k == "chain" else wg)   # (a chain wave walks two frames)
+            waves = int(r["Grid_Size"]) // 64
+            frames[k] = frames.get(k, 0) + (2 * waves if k == "chain" else wg)   # (a chain WAVE walks two frames; three waves a workgroup)
 lines = ["# rocprofv3 --pmc, two passes, tests/perf/trace_lz4_gpu.py 2147483648 zstd:1 (five GPU-decoded passes over one image of 4195 frames);",
          "# sums over the launches of each kernel, per frame (1,024,000 bytes, 123 k sequences)"]
 for k in ("prepare", "chain", "records", "execute"):
