@@ -9,11 +9,12 @@ n=2**28; per=512000
 def gen(kind,i):
     if kind=="constant": return np.full(per, 99, dtype=np.uint16)
     if kind=="period7": return np.tile(np.array([99,147,83,163,1187,1107,0],dtype=np.uint16), per//7+1)[:per].copy()
-    r=np.random.default_rng(i); a=r.integers(0,4096,2000,dtype=np.uint16); return np.tile(a, per//2000+1)[:per].copy()
+    period=int(kind[6:])   # "period2000": 2000 random flags repeated (periods of 20,000 / 40,000 flags = 40 / 80 KB lie beyond the
+    r=np.random.default_rng(i); a=r.integers(0,4096,period,dtype=np.uint16); return np.tile(a, per//period+1)[:per].copy()   # 32 KiB the Zstandard kernel's ring keeps)
 for codec,mode,level in (("zstd","zstd",1),("lz4","fast",2)):
     knob=b"zstd_decoder" if codec=="zstd" else b"lz4_decoder"
     entry=lib.FLAGSTATS_hip_blockimage_zstd if codec=="zstd" else lib.FLAGSTATS_hip_blockimage_lz4
-    for kind in ("constant","period7","period2000"):
+    for kind in ("constant","period7","period2000","period10000","period20000","period40000"):
         def make(i):
             f=gen(kind,i); c=bt.compress_block(f.tobytes(),mode,level); return struct.pack("<ii",f.nbytes,len(c))+c
         with ThreadPoolExecutor(16) as ex: img=b"".join(ex.map(make,range(n//per)))
