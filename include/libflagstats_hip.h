@@ -294,7 +294,7 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
  * report of `bench decompress -s` (block file) / `-S` (raw file) needs, benchmark/flagstats.cpp:577-588 */
 int FLAGSTATS_hip_blockfile_superset(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 int FLAGSTATS_hip_file_raw_superset(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
-/* The GPU LZ4 decoder called directly, with its own statistics (flagstat_lz4_gpu.hip): the compressed image goes over PCIe
+/* The GPU LZ4 decoder called directly, with its own statistics (flagstat_gpu_decode.hip): the compressed image goes over PCIe
  * in pieces, one wave decodes one block through LDS as soon as its piece has landed, K1 counts the decoded buffer.
  * Synchronous; out[32] += counters.  This is what FLAGSTATS_hip_blockfile* / blockimage_lz4 run for large LZ4 files
  * (knob "lz4_decoder"); measurements: profiles/r03/gpu_lz4_4GiB.log, lz4_decoder_sweep.log. */

@@ -183,7 +183,7 @@ uint64_t chunk_bytes();
 // CPUs of host NUMA node `node` inside the calling process's own affinity mask (flagstat_blocks.hip); false: unknown / none
 bool node_cpuset(int node, cpu_set_t* set);
 
-// LZ4 block file decoded on the GPU (flagstat_lz4_gpu.hip).  img != nullptr: whole file image in memory; else fd: file mode.
+// LZ4 block file decoded on the GPU (flagstat_gpu_decode.hip).  img != nullptr: whole file image in memory; else fd: file mode.
 struct Lz4GpuSource {
     const uint8_t* img = nullptr;
     int fd = -1;

@@ -696,19 +696,32 @@ int count_host_shared(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, i
         if (lk.owns_lock()) return count_host_locked(e, h, n, out, op);
     }
     for (int i = 0; i < Engine::kSideEngines; ++i) {
-        Engine* side = e.side[i].load(std::memory_order_acquire);
-        if (!side) {
+        // The pointer is read AND retained under side_mu: retire_engine (FLAGSTATS_hip_shutdown from another thread) empties the
+        // slots under the same lock and destroys the side engines, whose object must outlive a caller that has picked it up
+        // but not yet locked it -- the reference keeps the (then dead) object, engine_alive refuses the call.
+        Engine* side = nullptr;
+        {
             std::lock_guard<std::mutex> mk(e.side_mu);
+            if (e.dead.load()) break;
             side = e.side[i].load(std::memory_order_relaxed);
             if (!side) {
-                if (e.dead.load()) break;
                 side = engine_create(e.device);
                 if (!side) break;  // (out of memory for another set of buffers: wait for the default engine instead)
                 e.side[i].store(side, std::memory_order_release);
             }
+            engine_retain(side);
         }
-        std::unique_lock<std::mutex> lk(side->mu, std::try_to_lock);
-        if (lk.owns_lock()) return count_host_locked(*side, h, n, out, op);
+        int rc = 0;
+        bool ran = false;
+        {
+            std::unique_lock<std::mutex> lk(side->mu, std::try_to_lock);
+            if (lk.owns_lock()) {
+                rc = count_host_locked(*side, h, n, out, op);
+                ran = true;
+            }
+        }
+        engine_release(side);
+        if (ran) return rc;
     }
     std::lock_guard<std::mutex> lk(e.mu);
     return count_host_locked(e, h, n, out, op);

@@ -1,4 +1,4 @@
-// flagstat_lz4_gpu.hip -- host side of the LZ4 block decode ON the GPU (row f1; the kernels are flagstat_lz4_kernels.hip,
+// flagstat_gpu_decode.hip -- host side of the LZ4 block decode ON the GPU (row f1; the kernels are flagstat_lz4_kernels.hip,
 // behind the block-file entries for large files, knob "lz4_decoder").  Plain host code: no device code in this file, so
 // it also builds against the test-only HIP stand-in (tests/hoststub) and runs under ThreadSanitizer.
 //

@@ -1,6 +1,6 @@
 // flagstat_lz4_kernels.hip -- LZ4 block decode ON the GPU (row f1: the reference decodes every block with liblz4's
 // LZ4_decompress_safe on the host, benchmark/flagstats.cpp:311-316).  Device code only; the host orchestration is
-// flagstat_lz4_gpu.hip.
+// flagstat_gpu_decode.hip.
 //
 // Two kernels:
 //

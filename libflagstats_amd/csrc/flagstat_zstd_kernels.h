@@ -1,5 +1,5 @@
 // flagstat_zstd_kernels.h -- device side of the GPU Zstandard frame decoder (flagstat_zstd_kernels.hip), as the host
-// orchestration (flagstat_lz4_gpu.hip) sees it: plain C++, no device code, so the orchestration also builds against the
+// orchestration (flagstat_gpu_decode.hip) sees it: plain C++, no device code, so the orchestration also builds against the
 // test-only HIP stand-in (tests/hoststub) and runs under ThreadSanitizer.
 #ifndef FLAGSTAT_ZSTD_KERNELS_H_
 #define FLAGSTAT_ZSTD_KERNELS_H_

@@ -1,6 +1,6 @@
 // flagstat_zstd_kernels.hip -- Zstandard frame decode ON the GPU (row f1: the reference decodes every .zst block payload
 // with libzstd's ZSTD_decompress on the host, benchmark/flagstats.cpp:636-682).  Device code only; the host orchestration
-// is flagstat_lz4_gpu.hip (shared with the LZ4 decoder).  Written from RFC 8878; tests/zstd_model.py restates the format
+// is flagstat_gpu_decode.hip (shared with the LZ4 decoder).  Written from RFC 8878; tests/zstd_model.py restates the format
 // and tests/zstd_gpu_model.py the record / checkpoint layout, both pinned against libzstd on the CPU.
 //
 // A frame of the reference's writer is 1,024,000 decoded bytes in eight blocks of 128 KiB; a block is a Huffman-coded

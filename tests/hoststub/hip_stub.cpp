@@ -484,7 +484,7 @@ void fsk_set_epoch_stagger(int) {}
 
 }  // extern "C"
 
-// The GPU LZ4 decoder's KERNEL is device code; its host side (flagstat_lz4_gpu.hip: pieces, reader pool, span recycling,
+// The GPU LZ4 decoder's KERNEL is device code; its host side (flagstat_gpu_decode.hip: pieces, reader pool, span recycling,
 // cached buffers) is part of this build.  The stand-in "kernel" decodes the launch's blocks on the stream's worker thread with
 // the PRODUCT's own host decoder (lz4_block_decode.h), so copies, decode and counting touch the same buffers in the same
 // order as on the device.

@@ -74,7 +74,7 @@ static void block_pipeline(const std::vector<uint16_t>& flags, const uint64_t* w
     }
 }
 
-// the GPU LZ4 decoder's host side (flagstat_lz4_gpu.hip): pieces on four decode streams with a count behind each, the
+// the GPU LZ4 decoder's host side (flagstat_gpu_decode.hip): pieces on four decode streams with a count behind each, the
 // reader pool of file mode with its pinned spans recycled by events, segments, the kept buffers and their release --
 // image and file mode, 1 / 5 / 16 readers, a truncated file, a damaged block.  The stand-in kernel is the product's
 // host decoder.

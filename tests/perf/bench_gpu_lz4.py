@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""LZ4 block decode ON the GPU (flagstat_lz4_gpu.hip: compressed image over PCIe, one wave per block)
+"""LZ4 block decode ON the GPU (flagstat_gpu_decode.hip: compressed image over PCIe, one wave per block)
 against the product's host pipeline (threaded host decode into pinned chunks, decoded bytes over PCIe) on the same
 NA12878-like block image, LZ4-fast and LZ4-HC-9.  Counters of both are checked against the oracle."""
 import argparse

@@ -1,6 +1,8 @@
 #!/usr/bin/env python3
 """Differential fuzz of the GPU LZ4 decoder: many seeds of the synthetic edge streams of tests/test_gpu_blockfile.py
-(plus byte flips that must fail cleanly or decode like the host decoder does), GPU against generator / host decoder."""
+(plus byte flips that must fail cleanly or decode like the host decoder does).  Two levels: the product entries (counters
+against the oracle, accept / reject against the product's host decoder) and, per batch of 50 seeds, BOTH decode kernels
+launched directly with the decoded bytes compared byte for byte against liblz4 (tests/test_gpu_decode_bytes.py)."""
 import argparse
 import os
 import struct
@@ -13,6 +15,7 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import numpy as np  # noqa: E402
 
 import test_gpu_blockfile as tb  # noqa: E402
+import test_gpu_decode_bytes as tdb  # noqa: E402
 from libflagstats_amd import _lib, blockfile  # noqa: E402
 
 
@@ -25,6 +28,7 @@ def main():
     _lib.check(lib.FLAGSTATS_hip_init(0), "init")
     _lib.check(lib.FLAGSTATS_hip_set(b"lz4_decoder", 1), "set")
     blocks = damaged_ok = damaged_rejected = 0
+    bytes_level = [[0, 0, 0, 0], [0, 0, 0, 0]]   # per kernel: blocks byte-exact, damaged: both accept / both reject / GPU stricter than liblz4
     for seed in range(1000, 1000 + args.seeds):
         rs = np.random.RandomState(seed)
         style = ("bare", "edges", "mixed")[seed % 3]
@@ -59,11 +63,19 @@ def main():
         else:
             assert not ok, ("seed", seed, "host rejects, GPU accepts")
             damaged_rejected += 1
-        if seed % 100 == 99:
+        if seed % 50 == 49:
+            for kernel in (0, 1):
+                r = tdb.lz4_fuzz_slice(lib, kernel, seed - 49, 50)
+                for k in range(4):
+                    bytes_level[kernel][k] += r[k]
             print("seed %d done" % seed, flush=True)    # (a GPU run that prints nothing for minutes is taken to be hung)
     _lib.check(lib.FLAGSTATS_hip_set(b"lz4_decoder", 2), "set")
     print("fuzz: %d seeds, %d synthetic blocks exact on the GPU; damaged blocks: %d still valid (same counters as the host decoder), "
           "%d rejected by both" % (args.seeds, blocks, damaged_ok, damaged_rejected))
+    for kernel, name in ((0, "workgroup kernel"), (1, "wave-per-block kernel")):
+        b = bytes_level[kernel]
+        print("bytes, %s: %d blocks byte-exact against liblz4; damaged payloads: %d decode to liblz4's bytes, %d rejected by both, %d refused "
+              "by the GPU decoder only, none accepted that liblz4 rejects" % (name, b[0], b[1], b[2], b[3]))
 
 
 if __name__ == "__main__":

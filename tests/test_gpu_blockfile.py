@@ -348,8 +348,11 @@ def _synthetic_lz4_block(rs, target, style):
         comp += bytes((off & 255, off >> 8))
         if ml - 4 >= 15:
             put_len(ml - 4 - 15)
-        for _ in range(ml):            # byte by byte: overlapping matches repeat with period off
-            out.append(out[-off])
+        if off >= ml:                  # (what a byte-by-byte copy gives, without the Python loop)
+            out += out[len(out) - off:len(out) - off + ml]
+        else:                          # an overlapping match repeats with period off
+            pat = bytes(out[len(out) - off:])
+            out += (pat * (ml // off + 1))[:ml]
     # the block ends with a literals-only sequence; the last match must start at least 12 bytes before the end of the
     # block (LZ4 block format, "parsing restrictions": liblz4 rejects anything else)
     ll = int(rs.choice([12, 13, 14, 15, 16, 40]))

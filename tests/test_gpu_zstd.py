@@ -313,39 +313,13 @@ def test_gpu_zstd_decoder_takes_frames_of_many_small_blocks(zgpu):
     import ctypes
     import oracle
     from libflagstats_amd import _lib, blockfile
+    from zstd_fuzz_gen import flushed_frame
     hip = zgpu
     z = bt.zstd()
-    z.ZSTD_createCCtx.restype = ctypes.c_void_p
-    z.ZSTD_freeCCtx.argtypes = [ctypes.c_void_p]
-    z.ZSTD_compressStream2.restype = ctypes.c_size_t
-
-    class Buf(ctypes.Structure):
-        _fields_ = [("p", ctypes.c_void_p), ("size", ctypes.c_size_t), ("pos", ctypes.c_size_t)]
-
-    z.ZSTD_compressStream2.argtypes = [ctypes.c_void_p, ctypes.POINTER(Buf), ctypes.POINTER(Buf), ctypes.c_int]
-
-    def flushed_frame(raw, every):
-        cctx = z.ZSTD_createCCtx()
-        dst = ctypes.create_string_buffer(len(raw) + len(raw) // every * 32 + 1024)
-        src = ctypes.create_string_buffer(raw, len(raw))
-        ob = Buf(ctypes.cast(dst, ctypes.c_void_p), len(dst), 0)
-        at = 0
-        while at < len(raw):
-            n = min(every, len(raw) - at)
-            ib = Buf(ctypes.cast(src, ctypes.c_void_p).value + at, n, 0)
-            last = at + n == len(raw)
-            while True:
-                left = z.ZSTD_compressStream2(cctx, ctypes.byref(ob), ctypes.byref(ib), 2 if last else 1)   # ZSTD_e_end / ZSTD_e_flush
-                assert not z.ZSTD_isError(left)
-                if left == 0 and ib.pos == ib.size:
-                    break
-            at += n
-        z.ZSTD_freeCCtx(cctx)
-        return dst.raw[:ob.pos]
 
     raw = oracle.generate(oracle.GEN_NA12878, 77, 1, 0, 512000).tobytes()
     for every, takes in ((30000, True), (20000, False)):      # 35 blocks: within the 40 the scratch holds tables for; 52: beyond
-        frame = flushed_frame(raw, every)
+        frame = flushed_frame(z, raw, every)
         back = ctypes.create_string_buffer(len(raw))
         assert z.ZSTD_decompress(back, len(raw), frame, len(frame)) == len(raw) and back.raw == raw
         img = struct.pack("<ii", len(raw), len(frame)) + frame
