@@ -228,8 +228,9 @@ def spawn_ranks(nproc):
             codes = [pr.poll() for pr in procs]
             bad = [r for r, c in enumerate(codes) if c not in (None, 0)]
             if bad:
+                # (several ranks may have died inside one poll interval: all are named, the lowest one's stderr tail is shown)
                 culprit, rc = bad[0], codes[bad[0]]
-                why = "rank %d exited with code %d" % (culprit, rc)
+                why = ", ".join("rank %d exited with code %d" % (r, codes[r]) for r in bad)
                 break
             if all(c == 0 for c in codes):
                 break
@@ -264,13 +265,13 @@ def spawn_ranks(nproc):
 
 
 def injected_fault(stage, rank):
-    """TEST ONLY (tests/test_bench_spawn.py, tests/test_gpu_bench_contract.py): env FLAGSTATS_BENCH_FAULT = "<rank>:<stage>[:hang]"
-    makes that rank exit with code 3 (or hang) when it reaches the stage: start | init | comm | warmup."""
-    spec = os.environ.get("FLAGSTATS_BENCH_FAULT", "")
-    if not spec:
-        return
-    parts = spec.split(":")
-    if len(parts) >= 2 and parts[0] == str(rank) and parts[1] == stage:
+    """TEST ONLY (tests/test_bench_spawn.py, tests/test_gpu_bench_contract.py): env FLAGSTATS_BENCH_FAULT =
+    "<rank>:<stage>[:hang][,<rank>:<stage>[:hang]...]" makes each named rank exit with code 3 (or hang) when it reaches the
+    stage: start | init | comm | warmup."""
+    for spec in os.environ.get("FLAGSTATS_BENCH_FAULT", "").split(","):
+        parts = spec.split(":")
+        if not (len(parts) >= 2 and parts[0] == str(rank) and parts[1] == stage):
+            continue
         if len(parts) > 2 and parts[2] == "hang":
             print("bench.py: injected fault: rank %d hangs at stage %s" % (rank, stage), file=sys.stderr, flush=True)
             while True:

@@ -112,7 +112,7 @@ double now_s()
 // slot in a chunk buffer; the gap up to the next slot is zero-filled, and a zero flag counts
 // nothing, so a whole chunk is counted as ONE array.
 int index_blocks(const uint8_t* img, int fd, uint64_t bytes, uint64_t chunk_cap, std::vector<BlockRef>& blocks,
-                 std::vector<ChunkRef>& chunks, uint64_t& uncompressed)
+                 std::vector<ChunkRef>& chunks, uint64_t& uncompressed, int codec)
 {
     uint64_t pos = 0;
     uncompressed = 0;
@@ -131,6 +131,8 @@ int index_blocks(const uint8_t* img, int fd, uint64_t bytes, uint64_t chunk_cap,
         pos += 8;
         if (us < 0 || cs < 0) return fsint::fail_text("block file: negative size in block header");
         if (static_cast<uint64_t>(cs) > bytes - pos) return fsint::fail_text("block file: block payload runs past end of file");
+        if (!fsint::block_sizes_plausible(codec, static_cast<uint64_t>(us), static_cast<uint64_t>(cs)))
+            return fsint::fail_text("block file: a block header declares more decoded bytes than a payload of its size can hold");
         const uint64_t padded = (static_cast<uint64_t>(us) + 15) & ~15ull;
         if (padded > chunk_cap) return fsint::fail_text("block file: block larger than the chunk buffer");
         if (cur.bytes + padded > chunk_cap) {
@@ -278,7 +280,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
         if (cur.b1 > cur.b0) chunks.push_back(cur);
         uncompressed = bytes;
     } else {
-        rc = index_blocks(img, fd, bytes, chunk_cap, blocks, chunks, uncompressed);
+        rc = index_blocks(img, fd, bytes, chunk_cap, blocks, chunks, uncompressed, in.decode == lz4_block_decode ? 0 : 1);
     }
     if (rc) return rc;
     if (map)  // file mode with a mapping: headers were pread (no fault per block), payloads are decoded in place

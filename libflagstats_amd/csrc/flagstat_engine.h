@@ -99,8 +99,11 @@ struct Engine {
 #endif
     static constexpr int kLz4Streams = FLAGSTAT_DECODE_STREAMS, kLz4MaxPieces = 64, kLz4IdleCalls = 8;
     hipStream_t lz4_stream[kLz4Streams] = {};      // ... its decode streams, events and small device buffers, made on first use
-    hipEvent_t lz4_ev[4] = {};                     // start, copies queued, decoded + counted (timed); index on the device
-    hipEvent_t lz4_landed[kLz4MaxPieces] = {}, lz4_joined[kLz4Streams] = {}, lz4_pin_free[3] = {};
+    hipEvent_t lz4_ev[5] = {};                     // start, copies queued, decoded + counted (timed); index on the device; decoded, before K1 (timed)
+    static constexpr int kLz4MaxSpans = 8;          // file mode: pinned spans the readers fill ahead of the copies (a ring)
+    hipEvent_t lz4_landed[kLz4MaxPieces] = {}, lz4_joined[kLz4Streams] = {}, lz4_pin_free[kLz4MaxSpans] = {};
+    uint8_t* lz4_pin = nullptr;                    // ... ONE page-locked allocation holding the ring (on the GPU's NUMA node)
+    uint64_t lz4_pin_bytes = 0;
     uint8_t* zstd_scratch[kLz4Streams] = {};       // GPU Zstandard decoder: records / literals / checkpoints of a piece, per decode stream
     uint64_t zstd_scratch_cap[kLz4Streams] = {};   // (kept and released with the two large buffers)
     void* lz4_index = nullptr;                     // blocks + status + tally of a segment
@@ -182,6 +185,16 @@ void* host_alloc_on_node(size_t bytes, int numa_node);   // pinned, pages placed
 uint64_t chunk_bytes();
 // CPUs of host NUMA node `node` inside the calling process's own affinity mask (flagstat_blocks.hip); false: unknown / none
 bool node_cpuset(int node, cpu_set_t* set);
+
+// A block header that declares more decoded bytes than ANY payload of its size can decode to is refused by both index passes
+// before a buffer is sized from it (a damaged 60-byte file must not make the reader allocate and zero-fill 2 GiB): an LZ4
+// block grows by at most 255 output bytes per input byte (a match-length byte), a Zstandard frame by at most 128 KiB per
+// 4-byte RLE block.  (The reference decodes such a block into its fixed 1,089,536-byte buffer with the DECLARED size as the
+// capacity, benchmark/flagstats.cpp:296-316: undefined behaviour there, a loud error here.)
+inline bool block_sizes_plausible(int codec, uint64_t decoded, uint64_t payload)
+{
+    return codec == 0 ? decoded <= payload * 255u + 64u : decoded <= (payload / 4u + 1u) * 131072u;
+}
 
 // LZ4 block file decoded on the GPU (flagstat_gpu_decode.hip).  img != nullptr: whole file image in memory; else fd: file mode.
 struct Lz4GpuSource {

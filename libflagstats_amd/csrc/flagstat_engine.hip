@@ -11,6 +11,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <memory>
 #include <string>
@@ -157,21 +158,37 @@ void release_engine_resources(Engine& e)
 // build an engine on `device`; the caller holds no engine lock (the engine is not published yet)
 int engine_setup(Engine& e, int device)
 {
+    // env FLAGSTATS_HIP_INIT_TIMES=1: where the creation of an engine spends its time (tests/perf/cold_start.py: what a one-shot
+    // process pays before its first call -- the first HIP call of a process initialises the runtime)
+    const char* tk = std::getenv("FLAGSTATS_HIP_INIT_TIMES");
+    const bool timed = tk && std::atoi(tk) != 0;
+    using clk = std::chrono::steady_clock;
+    clk::time_point t_last = clk::now();
+    double t_phase[6] = {0, 0, 0, 0, 0, 0};
+    auto lap = [&](int k) {
+        if (!timed) return;
+        const clk::time_point now = clk::now();
+        t_phase[k] += std::chrono::duration<double, std::milli>(now - t_last).count();
+        t_last = now;
+    };
     int count = 0;
     hipError_t err = hipGetDeviceCount(&count);
+    lap(0);
     if (err != hipSuccess || count <= 0)
         return fail_hip("hipGetDeviceCount (no usable GPU)", err == hipSuccess ? hipErrorNoDevice : err);
     if (device < 0 || device >= count) return fail_text("device index out of range");
     hipDeviceProp_t prop;
     HIP_TRY(hipGetDeviceProperties(&prop, device));
     if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-        char buf[256];
+        char buf[384];
         std::snprintf(buf, sizeof buf, "device %d is %s; this library carries gfx950 (MI355X) code only", device,
                       prop.gcnArchName);
         return fail_text(buf);
     }
+    lap(1);
     DeviceGuard guard(device);
     if (!guard.ok()) return -1;
+    lap(2);
     e.device = device;
     e.cus = prop.multiProcessorCount;
     e.numa_node = numa_node_of_device(device);
@@ -180,6 +197,7 @@ int engine_setup(Engine& e, int device)
         HIP_TRY(hipMalloc(&e.d_out[i], 4096));  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
         HIP_TRY(hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming));
     }
+    lap(3);
     HIP_TRY(hipHostMalloc(&e.h_out, kHostOutBytes, hipHostMallocDefault));
     std::memset(e.h_out, 0, kHostOutBytes);
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e.h_out_dev), e.h_out, 0));
@@ -194,9 +212,15 @@ int engine_setup(Engine& e, int device)
         if (hipExtMallocWithFlags(&p, kSmallInBytes, hipDeviceMallocFinegrained) == hipSuccess) e.small_bar_in = static_cast<uint16_t*>(p);
     }
     (void)hipGetLastError();
+    lap(4);
     e.small_pinned_bytes = e.small_bar_in ? kSmallPinnedFlags * sizeof(uint16_t) : kSmallInBytes;
     HIP_TRY(hipHostMalloc(&e.small_in, e.small_pinned_bytes, hipHostMallocDefault));
     HIP_TRY(hipHostGetDevicePointer(reinterpret_cast<void**>(&e.small_in_dev), e.small_in, 0));
+    lap(5);
+    if (timed)
+        std::fprintf(stderr, "engine creation (ms): hipGetDeviceCount = runtime initialisation %.2f | device properties %.2f | hipSetDevice %.2f | two streams, counters, "
+                             "events, NUMA node %.2f | pinned result buffer + fine-grained BAR input %.2f | pinned small-call input %.2f\n",
+                     t_phase[0], t_phase[1], t_phase[2], t_phase[3], t_phase[4], t_phase[5]);
     return 0;
 }
 

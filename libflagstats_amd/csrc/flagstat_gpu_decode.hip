@@ -1,6 +1,8 @@
-// flagstat_gpu_decode.hip -- host side of the LZ4 block decode ON the GPU (row f1; the kernels are flagstat_lz4_kernels.hip,
-// behind the block-file entries for large files, knob "lz4_decoder").  Plain host code: no device code in this file, so
-// it also builds against the test-only HIP stand-in (tests/hoststub) and runs under ThreadSanitizer.
+// flagstat_gpu_decode.hip -- host side of the block decode ON the GPU for both codecs of the reference's block files (row f1;
+// kernels: flagstat_lz4_kernels.hip for raw LZ4 blocks, flagstat_zstd_kernels.hip for Zstandard frames; behind the block-file
+// entries for large files, knobs "lz4_decoder" / "zstd_decoder").  Plain host code: no device code in this file, so it also
+// builds against the test-only HIP stand-in (tests/hoststub) and runs under ThreadSanitizer and Address/UB sanitizers.
+// (Until r04 this file was flagstat_lz4_gpu.hip; the internal names lz4_gpu_* stayed.)
 //
 // The reference's block reader decodes every block with liblz4's LZ4_decompress_safe on the host
 // (benchmark/flagstats.cpp:311-316); the host pipeline of this repo (flagstat_blocks.hip) does the same on N host threads
@@ -28,6 +30,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <string>
 #include <vector>
 #include <atomic>
 #include <condition_variable>
@@ -44,6 +47,30 @@
 #include "flagstat_zstd_kernels.h"
 
 namespace fsint {
+
+// Host-side phases of a call (env FLAGSTATS_HIP_GPU_DECODE_TIMES=1 prints them on stderr: tests/perf/cold_start.py reads
+// what the FIRST call of a process spends where)
+namespace {
+struct PhaseClock {
+    using clk = std::chrono::steady_clock;
+    bool on = false;
+    clk::time_point last;
+    double index = 0, meminfo = 0, streams = 0, alloc_comp = 0, alloc_out = 0, alloc_small = 0, alloc_scratch = 0, pinned = 0, queue = 0, wait = 0;
+    void start()
+    {
+        const char* k = std::getenv("FLAGSTATS_HIP_GPU_DECODE_TIMES");
+        on = k && std::atoi(k) != 0;
+        if (on) last = clk::now();
+    }
+    void lap(double& into)
+    {
+        if (!on) return;
+        const clk::time_point now = clk::now();
+        into += std::chrono::duration<double, std::milli>(now - last).count();
+        last = now;
+    }
+};
+}  // namespace
 
 void lz4_gpu_release(Engine& e, bool all)
 {
@@ -75,6 +102,9 @@ void lz4_gpu_release(Engine& e, bool all)
     if (e.lz4_index) (void)hipFree(e.lz4_index);
     e.lz4_index = nullptr;
     e.lz4_index_cap = 0;
+    if (e.lz4_pin) (void)hipHostFree(e.lz4_pin);
+    e.lz4_pin = nullptr;
+    e.lz4_pin_bytes = 0;
     e.lz4_ready = false;
 }
 
@@ -84,13 +114,13 @@ void lz4_gpu_other_use(Engine& e)
     if (++e.lz4_idle >= static_cast<uint32_t>(Engine::kLz4IdleCalls)) lz4_gpu_release(e, false);
 }
 
-// streams, events: once per engine
-static int lz4_gpu_prepare(Engine& e)
+// Streams and events: once per engine.  The 75 events take 0.03 ms; the two decode streams 15-20 ms (a hardware queue each:
+// tests/perf/micro/file_h2d.hip, profiles/r05/file_h2d.log), which the FIRST call of a process would wait for -- so the streams
+// are made on a helper thread beside the buffers' allocation, the pinned ring and the first reads, and the thread is joined
+// before the first decode launch (lz4_gpu_segment).
+static int lz4_gpu_events(Engine& e)
 {
-    if (e.lz4_ready) return 0;
     hipError_t err = hipSuccess;
-    for (hipStream_t& x : e.lz4_stream)
-        if (err == hipSuccess && !x) err = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
     for (hipEvent_t& x : e.lz4_ev)
         if (err == hipSuccess && !x) err = hipEventCreate(&x);
     for (hipEvent_t& x : e.lz4_landed)
@@ -101,26 +131,76 @@ static int lz4_gpu_prepare(Engine& e)
         if (err == hipSuccess && !x) err = hipEventCreateWithFlags(&x, hipEventDisableTiming | hipEventBlockingSync);
     if (err != hipSuccess) {
         lz4_gpu_release(e, true);
-        return fail_hip("GPU LZ4 decoder: streams / events", err);
+        return fail_hip("GPU block decoder: events", err);
     }
-    e.lz4_ready = true;
+    return 0;
+}
+
+static int lz4_gpu_streams(Engine& e)   // (may run on a helper thread: makes the engine's device current itself)
+{
+    DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    hipError_t err = hipSuccess;
+    for (hipStream_t& x : e.lz4_stream)
+        if (err == hipSuccess && !x) err = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
+    if (err != hipSuccess) return fail_hip("GPU block decoder: streams", err);
     return 0;
 }
 
 // One segment: file bytes [file_lo, file_lo + bytes) hold `blocks` (offsets relative to the segment), dpos decoded bytes.
 // e.mu must be held.  Returns kLz4GpuNoMemory when the device cannot hold the buffers (nothing has been queued then).
 static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, const std::vector<fsk::GpuBlock>& blocks,
-                           uint64_t bytes, uint64_t dpos, uint64_t n_flags, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
+                           uint64_t bytes, uint64_t dpos, uint64_t n_flags, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats, PhaseClock& pc_,
+                           bool wave_kernel)
 {
     const uint8_t* img = in.img ? in.img + file_lo : nullptr;
-    int rc = lz4_gpu_prepare(e);
+    int rc = lz4_gpu_events(e);
     if (rc) return rc;
     hipStream_t s = e.stream[0];
     constexpr uint32_t nstreams = Engine::kLz4Streams;
+    // first use on this engine: the decode streams are made beside everything up to the first decode launch
+    std::thread maker;
+    int maker_rc = 0;
+    std::string maker_err;
+    struct Joiner {
+        std::thread& t;
+        ~Joiner()
+        {
+            if (t.joinable()) t.join();
+        }
+    } joiner{maker};
+    if (!e.lz4_ready)
+        maker = std::thread([&] {
+            maker_rc = lz4_gpu_streams(e);
+            if (maker_rc) maker_err = last_error_text();
+        });
+    bool streams_wait_index = false;   // the decode streams still have to be told to wait for the index (event 3)
+    auto join_streams = [&]() -> int {
+        if (maker.joinable()) {
+            pc_.lap(pc_.queue);
+            maker.join();
+            pc_.lap(pc_.streams);   // (only what the call WAITED for the helper thread)
+            if (maker_rc) {
+                lz4_gpu_release(e, true);
+                return fail_again(maker_err.c_str(), maker_rc);
+            }
+            e.lz4_ready = true;
+        }
+        if (streams_wait_index) {
+            streams_wait_index = false;
+            for (uint32_t i = 0; i < nstreams; ++i) {
+                const hipError_t e_ = hipStreamWaitEvent(e.lz4_stream[i], e.lz4_ev[3], 0);
+                if (e_ != hipSuccess) return fail_hip("hipStreamWaitEvent(index on the device)", e_);
+            }
+        }
+        return 0;
+    };
     // everything queued so far must be over before an error leaves (the buffers may be released by the caller)
     auto settle = [&] {
+        if (maker.joinable()) maker.join();
         (void)hipStreamSynchronize(s);
-        for (hipStream_t x : e.lz4_stream) (void)hipStreamSynchronize(x);
+        for (hipStream_t x : e.lz4_stream)
+            if (x) (void)hipStreamSynchronize(x);
     };
 #define LZG_TRY(expr)                            \
     do {                                         \
@@ -133,13 +213,18 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     } while (0)
     // the two large buffers belong to the engine and are reused by the next segment / file (knob "lz4_gpu_keep_bytes")
     const uint64_t want[2] = {bytes + 64, dpos + 16};
+    // (capacities grow in steps of 64 MiB; env FLAGSTATS_HIP_GPU_BUFFER_GRAIN: the sanitizer builds ask for exact sizes, so that
+    // an access behind what a segment needs is a report instead of a hit in the slack)
+    uint64_t grain = 64ull << 20;
+    if (const char* gk = std::getenv("FLAGSTATS_HIP_GPU_BUFFER_GRAIN"))
+        if (std::strtoull(gk, nullptr, 0) >= 16) grain = std::strtoull(gk, nullptr, 0);
     for (int i = 0; i < 2; ++i)
         if (e.lz4_cap[i] < want[i]) {
             uint8_t* old = e.lz4_buf[i];
             e.lz4_buf[i] = nullptr;
             e.lz4_cap[i] = 0;
             if (old) LZG_TRY(hipFree(old));
-            const uint64_t cap = (want[i] + (64ull << 20) - 1) & ~((64ull << 20) - 1);
+            const uint64_t cap = (want[i] + grain - 1) / grain * grain;
             const hipError_t e_ = hipMalloc(&e.lz4_buf[i], cap);
             if (e_ != hipSuccess) {
                 (void)hipGetLastError();
@@ -147,6 +232,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
                 return kLz4GpuNoMemory;
             }
             e.lz4_cap[i] = cap;
+            pc_.lap(i ? pc_.alloc_out : pc_.alloc_comp);
         }
     uint8_t* const d_comp = e.lz4_buf[0];
     uint8_t* const d_out = e.lz4_buf[1];
@@ -167,6 +253,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             return kLz4GpuNoMemory;
         }
         e.lz4_index_cap = cap;
+        pc_.lap(pc_.alloc_small);
     }
     fsk::GpuBlock* const d_blocks = static_cast<fsk::GpuBlock*>(e.lz4_index);
     uint32_t* const d_status = reinterpret_cast<uint32_t*>(static_cast<uint8_t*>(e.lz4_index) + off_status);
@@ -186,7 +273,9 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     const bool big_ring = rk && std::atoi(rk) == 16;
     // knob "lz4_gpu_kernel": 0 = the workgroup pipeline (eight waves per block, 64 KiB window in LDS), 1 = r03's wave per block
     const bool zstd = in.codec == 1;
-    const int kernel = zstd || knobs().lz4_gpu_kernel.load() == 0 ? fsk::LZ4K_WORKGROUP : (big_ring ? fsk::LZ4K_WAVE_RING16 : fsk::LZ4K_WAVE);
+    // (wave_kernel: a block beyond what the workgroup kernel's records can address -- 16 MiB of payload, 256 MiB decoded; the
+    // reference's writer makes 1,024,000-byte blocks -- sends the whole file to the wave-per-block kernel, which has no such limit)
+    const int kernel = zstd || (knobs().lz4_gpu_kernel.load() == 0 && !wave_kernel) ? fsk::LZ4K_WORKGROUP : (big_ring ? fsk::LZ4K_WAVE_RING16 : fsk::LZ4K_WAVE);
     const char* pk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");  // tuning: per-phase wave cycles on stderr
     const bool prof = pk && std::atoi(pk) != 0;
     // Pieces.  The workgroup kernel holds 512 blocks at a time, a block takes 2.5-3.5 ms whatever else runs, and TWO
@@ -216,27 +305,48 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     if (npieces < 1) npieces = 1;
     if (npieces > static_cast<uint32_t>(Engine::kLz4MaxPieces)) npieces = Engine::kLz4MaxPieces;
     if (npieces > blocks.size()) npieces = static_cast<uint32_t>(blocks.size());
-    // file mode: the engine's pinned chunk buffers, filled by parallel preads
-    uint8_t* pinned[3] = {nullptr, nullptr, nullptr};
+    // File mode: a ring of page-locked spans, filled by parallel preads ahead of the copies.  ONE allocation on the GPU's NUMA
+    // node, made on first use and kept with the engine: 4 spans of 16 MiB -- r04 took the host pipeline's three 64 MiB chunk
+    // buffers, whose page-locking cost the first call of a process 40-53 ms (0.2-0.25 ms per MiB; 48 MiB in one call: 7.6 ms;
+    // profiles/r05/file_h2d.log, cold_start_before.log); small spans also shorten what nothing overlaps: the first span's
+    // read and the last span's copy.  env FLAGSTATS_HIP_GPU_SPAN_MIB / FLAGSTATS_HIP_GPU_SPANS override (A/B, tests); a chunk
+    // size below 16 MiB (knob "chunk_flags") makes the spans that small (tests: many spans in a small file).
+    uint8_t* pinned[Engine::kLz4MaxSpans] = {};
     hipEvent_t* const pin_free = e.lz4_pin_free;
     uint64_t span_cap = 0;
-    int readers = 0;
+    int readers = 0, nspans_ring = 0;
     if (!img) {
-        span_cap = (chunk_bytes() + 15) & ~15ull;
-        if (span_cap < (4ull << 20)) span_cap = 4ull << 20;
-        void* bufs[3];
-        rc = pinned_reserve(e, span_cap, bufs);
-        if (rc) {
-            settle();
-            return rc;
+        const char* sk = std::getenv("FLAGSTATS_HIP_GPU_SPAN_MIB");
+        span_cap = sk && std::atoi(sk) > 0 ? static_cast<uint64_t>(std::atoi(sk)) << 20 : 16ull << 20;
+        if (!sk && chunk_bytes() < span_cap) span_cap = (chunk_bytes() + 4095) & ~4095ull;
+        if (span_cap < (1ull << 20)) span_cap = 1ull << 20;
+        const char* nk = std::getenv("FLAGSTATS_HIP_GPU_SPANS");
+        nspans_ring = nk ? std::atoi(nk) : 4;
+        if (nspans_ring < 2) nspans_ring = 2;
+        if (nspans_ring > Engine::kLz4MaxSpans) nspans_ring = Engine::kLz4MaxSpans;
+        const uint64_t ring_bytes = span_cap * static_cast<uint64_t>(nspans_ring);
+        if (e.lz4_pin_bytes < ring_bytes) {
+            if (e.lz4_pin) {
+                LZG_TRY(hipStreamSynchronize(s));
+                (void)hipHostFree(e.lz4_pin);
+            }
+            e.lz4_pin = nullptr;
+            e.lz4_pin_bytes = 0;
+            e.lz4_pin = static_cast<uint8_t*>(host_alloc_on_node(ring_bytes, e.numa_node));
+            if (!e.lz4_pin) {
+                settle();
+                return -1;
+            }
+            e.lz4_pin_bytes = ring_bytes;
         }
-        for (int i = 0; i < 3; ++i) pinned[i] = static_cast<uint8_t*>(bufs[i]);
+        for (int i = 0; i < nspans_ring; ++i) pinned[i] = e.lz4_pin + span_cap * static_cast<uint64_t>(i);
+        pc_.lap(pc_.pinned);
         readers = in.threads > 0 ? in.threads : static_cast<int>(std::thread::hardware_concurrency());
         if (readers > 16) readers = 16;
         if (readers < 1) readers = 1;
     }
     LZG_TRY(hipEventRecord(e.lz4_ev[3], s));  // index on the device, status and counters preset
-    for (uint32_t i = 0; i < nstreams; ++i) LZG_TRY(hipStreamWaitEvent(e.lz4_stream[i], e.lz4_ev[3], 0));
+    streams_wait_index = true;                // (told to the decode streams when they exist: join_streams)
     // pieces: blocks [first, last) = segment bytes [lo, hi), split by compressed bytes
     struct Piece {
         uint64_t first, last, lo, hi;
@@ -249,51 +359,72 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     const char* fpk = std::getenv("FLAGSTATS_HIP_GPU_FIRST_PIECE");
     int first_pct = fpk ? std::atoi(fpk) : (zstd ? 50 : 0);
     if (first_pct < 0 || first_pct >= 100) first_pct = 0;
-    for (uint64_t first = 0; pieces.size() < npieces && first < blocks.size();) {
-        const uint64_t c = pieces.size();
-        uint64_t target = bytes / npieces * (c + 1);
-        if (first_pct > 0 && npieces > 1) {
-            const uint64_t t0 = bytes / npieces * static_cast<uint64_t>(first_pct) / 100u;
-            target = t0 + (bytes - t0) / (npieces - 1) * c;
+    auto cut_pieces = [&] {
+        pieces.clear();
+        for (uint64_t first = 0; pieces.size() < npieces && first < blocks.size();) {
+            const uint64_t c = pieces.size();
+            uint64_t target = bytes / npieces * (c + 1);
+            if (first_pct > 0 && npieces > 1) {
+                const uint64_t t0 = bytes / npieces * static_cast<uint64_t>(first_pct) / 100u;
+                target = t0 + (bytes - t0) / (npieces - 1) * c;
+            }
+            uint64_t last = first + 1;
+            while (last < blocks.size() && (c + 1 == npieces || blocks[last].src_off + blocks[last].src_len <= target)) ++last;
+            pieces.push_back(Piece{first, last, blocks[first].src_off - 8, blocks[last - 1].src_off + blocks[last - 1].src_len});
+            first = last;
         }
-        uint64_t last = first + 1;
-        while (last < blocks.size() && (c + 1 == npieces || blocks[last].src_off + blocks[last].src_len <= target)) ++last;
-        pieces.push_back(Piece{first, last, blocks[first].src_off - 8, blocks[last - 1].src_off + blocks[last - 1].src_len});
-        first = last;
-    }
-    const uint32_t pieces_done = static_cast<uint32_t>(pieces.size());
-    // Zstandard: scratch between the entropy and the execution kernel, one per decode stream, sized for the largest piece
+    };
+    cut_pieces();
+    // Zstandard: scratch between the four kernels (8.5 MB per 1,024,000-byte frame in flight), one per decode stream, sized for the
+    // largest piece.  A device that cannot hold it gets more and smaller pieces (half the frames per launch each time) before the
+    // call gives up: the scratch is what a busy device runs out of first, and smaller launches only cost some overlap.
     uint32_t z_max_dst = 0;
     if (zstd) {
-        uint64_t most = 0;
-        for (const Piece& pc : pieces) most = pc.last - pc.first > most ? pc.last - pc.first : most;
         for (const fsk::GpuBlock& b : blocks) z_max_dst = b.dst_len > z_max_dst ? b.dst_len : z_max_dst;
         if (z_max_dst > fsk::kZstdMaxFrameBytes) {
             settle();
             if (knobs().zstd_decoder.load() == 1) fail_text("GPU Zstandard decoder: a block decodes to more than it takes (64 MiB)");
             return kGpuDecodeRejected;
         }
-        const uint64_t need = fsk_zstd_scratch_bytes(z_max_dst, static_cast<uint32_t>(most));
-        const uint32_t used = pieces.size() < nstreams ? static_cast<uint32_t>(pieces.size()) : nstreams;
-        for (uint32_t i = 0; i < used; ++i)
-            if (e.zstd_scratch_cap[i] < need) {
-                uint8_t* old = e.zstd_scratch[i];
-                e.zstd_scratch[i] = nullptr;
-                e.zstd_scratch_cap[i] = 0;
-                if (old) LZG_TRY(hipFree(old));
-                const uint64_t cap = (need + (16ull << 20) - 1) & ~((16ull << 20) - 1);
-                const hipError_t e_ = hipMalloc(&e.zstd_scratch[i], cap);
-                if (e_ != hipSuccess) {
-                    (void)hipGetLastError();
+        for (;;) {
+            uint64_t most = 0;
+            for (const Piece& pc : pieces) most = pc.last - pc.first > most ? pc.last - pc.first : most;
+            const uint64_t need = fsk_zstd_scratch_bytes(z_max_dst, static_cast<uint32_t>(most));
+            const uint32_t used = pieces.size() < nstreams ? static_cast<uint32_t>(pieces.size()) : nstreams;
+            bool ok = true;
+            for (uint32_t i = 0; i < used && ok; ++i)
+                if (e.zstd_scratch_cap[i] < need) {
+                    uint8_t* old = e.zstd_scratch[i];
                     e.zstd_scratch[i] = nullptr;
-                    settle();
-                    return kLz4GpuNoMemory;
+                    e.zstd_scratch_cap[i] = 0;
+                    if (old) LZG_TRY(hipFree(old));
+                    const uint64_t sgrain = grain < (16ull << 20) ? grain : (16ull << 20);
+                    const uint64_t cap = (need + sgrain - 1) / sgrain * sgrain;
+                    const hipError_t e_ = hipMalloc(&e.zstd_scratch[i], cap);
+                    if (e_ != hipSuccess) {
+                        (void)hipGetLastError();
+                        e.zstd_scratch[i] = nullptr;
+                        ok = false;
+                    } else {
+                        e.zstd_scratch_cap[i] = cap;
+                    }
                 }
-                e.zstd_scratch_cap[i] = cap;
+            if (ok) break;
+            if (most <= 1 || npieces >= static_cast<uint32_t>(Engine::kLz4MaxPieces) || npieces >= blocks.size()) {
+                settle();
+                return kLz4GpuNoMemory;
             }
+            npieces = npieces * 2 > static_cast<uint32_t>(Engine::kLz4MaxPieces) ? static_cast<uint32_t>(Engine::kLz4MaxPieces) : npieces * 2;
+            if (npieces > blocks.size()) npieces = static_cast<uint32_t>(blocks.size());
+            cut_pieces();
+        }
+        pc_.lap(pc_.alloc_scratch);
     }
+    const uint32_t pieces_done = static_cast<uint32_t>(pieces.size());
     // piece c has been queued on the copy stream: decode its blocks behind it
     auto launch_piece = [&](uint32_t c) -> int {
+        const int jrc = join_streams();
+        if (jrc) return jrc;
         hipError_t e_ = hipEventRecord(e.lz4_landed[c], s);
         hipStream_t ds = e.lz4_stream[c % nstreams];
         if (e_ == hipSuccess) e_ = hipStreamWaitEvent(ds, e.lz4_landed[c], 0);
@@ -313,9 +444,10 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             rc = e_ == hipSuccess ? launch_piece(c) : fail_hip("hipMemcpyAsync(block image piece)", e_);
         }
     } else {
-        // File mode.  The pieces are cut into spans of one pinned buffer; a pool of `readers` threads preads span i + 1
-        // (every thread its share) while this thread queues the copy of span i; a buffer is refilled once the copy that
-        // last used it has left the host.  (Threads started per span cost a third of the read time: r03, 83 -> 7x ms.)
+        // File mode.  The pieces are cut into spans of one ring slot; a pool of `readers` threads preads the released spans
+        // (every thread its share of each) while this thread queues the copies behind them: span i may be read as soon as the
+        // copy that last used its slot (span i - ring) has left the host, so the readers run up to ring - 1 spans ahead of the
+        // copy queue.  (Threads started per span cost a third of the read time: r03, 83 -> 7x ms.)
         struct Span {
             uint64_t at, len;
             int ends_piece;  // piece that is complete once this span is queued, or -1
@@ -326,6 +458,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
                 const uint64_t len = pieces[c].hi - at < span_cap ? pieces[c].hi - at : span_cap;
                 spans.push_back(Span{at, len, at + len == pieces[c].hi ? static_cast<int>(c) : -1});
             }
+        const size_t ring = static_cast<size_t>(nspans_ring);
         std::mutex m;
         std::condition_variable cv_work, cv_done;
         size_t released = 0;                       // spans [0, released) may be read
@@ -347,7 +480,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
                 uint64_t o = share * static_cast<uint64_t>(t);
                 const uint64_t end = o + share < sp.len ? o + share : sp.len;
                 bool ok = true;
-                uint8_t* base = pinned[i % 3];
+                uint8_t* base = pinned[i % ring];
                 while (o < end) {
                     const ssize_t r = pread(in.fd, base + o, end - o, static_cast<off_t>(file_lo + sp.at + o));
                     if (r <= 0) {
@@ -369,26 +502,33 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
                 cv_done.wait(ul, [&] { return done[i] == readers; });
                 if (failed) return fail_text("block file: short read");
             }
-            hipError_t e_ = hipMemcpyAsync(d_comp + spans[i].at, pinned[i % 3], spans[i].len, hipMemcpyHostToDevice, s);
-            if (e_ == hipSuccess) e_ = hipEventRecord(pin_free[i % 3], s);
+            hipError_t e_ = hipMemcpyAsync(d_comp + spans[i].at, pinned[i % ring], spans[i].len, hipMemcpyHostToDevice, s);
+            if (e_ == hipSuccess) e_ = hipEventRecord(pin_free[i % ring], s);
             if (e_ != hipSuccess) return fail_hip("hipMemcpyAsync(block file span)", e_);
             return spans[i].ends_piece >= 0 ? launch_piece(static_cast<uint32_t>(spans[i].ends_piece)) : 0;
         };
-        for (size_t i = 0; i < spans.size() && !rc; ++i) {
-            if (i >= 3) {
-                hipError_t e_ = hipEventSynchronize(pin_free[i % 3]);  // the copy of span i - 3 has left this buffer
-                if (e_ != hipSuccess) rc = fail_hip("hipEventSynchronize(pinned span)", e_);
-            }
-            if (!rc) {
-                {
-                    std::lock_guard<std::mutex> g(m);
-                    released = i + 1;
+        size_t next_release = 0;
+        for (size_t q = 0; q < spans.size() && !rc; ++q) {
+            // Release what the ring allows before waiting for span q's readers: spans up to q + ring - 2 -- the slot of span
+            // q + ring - 1 is span q - 1's, whose copy has only just been queued: waiting for THAT here would leave the copy
+            // engine idle until span q is queued; waiting for span q - 2's copy leaves it one copy to work on.
+            const size_t ahead = ring > 2 ? q + ring - 1 : q + 1;
+            while (!rc && next_release < spans.size() && next_release < ahead) {
+                if (next_release >= ring) {
+                    // (the copy of span next_release - ring, queued at an earlier q, has left this slot)
+                    const hipError_t e_ = hipEventSynchronize(pin_free[next_release % ring]);
+                    if (e_ != hipSuccess) rc = fail_hip("hipEventSynchronize(pinned span)", e_);
                 }
-                cv_work.notify_all();
-                if (i >= 1) rc = queue_span(i - 1);
+                if (!rc) {
+                    {
+                        std::lock_guard<std::mutex> g(m);
+                        released = ++next_release;
+                    }
+                    cv_work.notify_all();
+                }
             }
+            if (!rc) rc = queue_span(q);
         }
-        if (!rc && !spans.empty()) rc = queue_span(spans.size() - 1);
         {
             std::lock_guard<std::mutex> g(m);
             stop = true;
@@ -400,12 +540,19 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         settle();
         return rc;
     }
+    rc = join_streams();
+    if (rc) {
+        settle();
+        return rc;
+    }
+    pc_.lap(pc_.queue);
     LZG_TRY(hipEventRecord(e.lz4_ev[1], s));  // every piece has landed
     for (uint32_t i = 0; i < nstreams; ++i) {
         LZG_TRY(hipEventRecord(e.lz4_joined[i], e.lz4_stream[i]));
         LZG_TRY(hipStreamWaitEvent(s, e.lz4_joined[i], 0));
     }
     // One K1 pass over the whole decoded buffer (0.15 ms per GiB).
+    LZG_TRY(hipEventRecord(e.lz4_ev[4], s));  // ... and is decoded
     rc = count_device_async(e, reinterpret_cast<const uint16_t*>(d_out), dpos / 2, e.d_out[0], s, e.ws[0],
                             OP_FLAGSTAT | (in.superset ? OP_SUPERSET : 0));
     if (rc) {
@@ -419,6 +566,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     std::vector<uint32_t> st(blocks.size());
     LZG_TRY(hipMemcpyAsync(st.data(), d_status, st.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, s));
     LZG_TRY(hipStreamSynchronize(s));
+    pc_.lap(pc_.wait);
     uint64_t bad = 0, first_bad = 0;
     uint32_t first_code = 0;
     for (size_t i = 0; i < st.size(); ++i)
@@ -429,9 +577,10 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             }
             ++bad;
         }
-    float h2d = 0, dec = 0, pipe = 0;
+    float h2d = 0, dec = 0, cnt = 0, pipe = 0;
     LZG_TRY(hipEventElapsedTime(&h2d, e.lz4_ev[0], e.lz4_ev[1]));
-    LZG_TRY(hipEventElapsedTime(&dec, e.lz4_ev[1], e.lz4_ev[2]));
+    LZG_TRY(hipEventElapsedTime(&dec, e.lz4_ev[1], e.lz4_ev[4]));
+    LZG_TRY(hipEventElapsedTime(&cnt, e.lz4_ev[4], e.lz4_ev[2]));
     LZG_TRY(hipEventElapsedTime(&pipe, e.lz4_ev[0], e.lz4_ev[2]));
     if (prof && zstd) {
         const double nb = static_cast<double>(blocks.size());
@@ -471,7 +620,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     stats->bad_blocks += bad;
     stats->h2d_ms += h2d;
     stats->decode_ms += dec;
-    stats->count_ms += 0;  // (a piece is counted behind its decode: part of decode_ms)
+    stats->count_ms += cnt;  // the ONE K1 pass over the decoded buffer that ends the pipeline (0.15 ms per GiB)
     stats->sequences += tally[0];
     stats->far_matches += tally[1];
     stats->ring_kib = zstd ? (fsk::kZstdWindow + 4096u) / 1024u : (kernel == fsk::LZ4K_WORKGROUP ? 66 : (kernel == fsk::LZ4K_WAVE ? 8 : 16));
@@ -483,7 +632,8 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         for (int k = 0; k < 32; ++k) out[k] += e.h_out[k];
     }
     if (bad) {
-        // (Zstandard with the decoder chosen by size: the caller decodes the file with libzstd, whose verdict counts)
+        // (Zstandard with the decoder chosen by size: the caller decodes the file with libzstd, whose verdict -- and message --
+        // counts; nothing of this run has reached the caller's counters)
         if (zstd && knobs().zstd_decoder.load() != 1) return kGpuDecodeRejected;
         char buf[192];
         std::snprintf(buf, sizeof buf, "block file: %llu block(s) failed to decode to their declared size (GPU %s decoder; first: block %llu, code %u)",
@@ -498,11 +648,14 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
 int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
 {
     const auto t_start = std::chrono::steady_clock::now();
+    PhaseClock pc;
+    pc.start();
     const uint8_t* img = in.img;
     const uint64_t bytes = in.bytes;
     // index: int32 uncompressed size, int32 compressed size, payload (benchmark/flagstats.cpp:119-138)
     std::vector<fsk::GpuBlock> blocks;
     uint64_t pos = 0, dpos = 0, n_flags = 0, usum = 0;
+    uint32_t max_src = 0, max_dst = 0;
     while (pos < bytes) {
         if (bytes - pos < 8) return fail_text("block file: truncated block header");
         int32_t us, cs;
@@ -516,15 +669,17 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         std::memcpy(&cs, hdr + 4, 4);
         if (us < 0 || cs < 0) return fail_text("block file: negative size in block header");
         if (static_cast<uint64_t>(cs) > bytes - pos - 8) return fail_text("block file: block payload runs past end of file");
+        if (!block_sizes_plausible(in.codec, static_cast<uint64_t>(us), static_cast<uint64_t>(cs)))
+            return fail_text("block file: a block header declares more decoded bytes than a payload of its size can hold");
         blocks.push_back(fsk::GpuBlock{pos + 8, dpos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us)});
         n_flags += static_cast<uint64_t>(us) >> 1;  // as benchmark/flagstats.cpp:323
         usum += static_cast<uint64_t>(us);
         dpos += (static_cast<uint64_t>(us) + 15) & ~15ull;
         pos += 8 + static_cast<uint64_t>(cs);
+        max_src = static_cast<uint32_t>(cs) > max_src ? static_cast<uint32_t>(cs) : max_src;
+        max_dst = static_cast<uint32_t>(us) > max_dst ? static_cast<uint32_t>(us) : max_dst;
     }
-    const char* pk_ = std::getenv("FLAGSTATS_HIP_GPU_LZ4_PROFILE");
-    const bool prof_host = pk_ && std::atoi(pk_) != 0;
-    const auto t_index = std::chrono::steady_clock::now();
+    pc.lap(pc.index);
     FLAGSTATS_gpu_lz4_stats local;
     if (!stats) stats = &local;
     {
@@ -545,18 +700,41 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         const uint64_t pct = in.codec == 1 ? 190 : 125;
         if (in.by_size && usum * 100 < bytes * pct) return kGpuDecodeRejected;
     }
+    // What the kernels cannot address is known from the index -- a capability limit, not damage.  LZ4: the workgroup kernel's
+    // records carry 24-bit input and 28-bit output positions (status 10 if it met such a block); a file with a block of 16 MiB of
+    // payload or 256 MiB decoded goes to the wave-per-block kernel, which has no such limit.
+    const bool wave_kernel = in.codec == 0 && (max_src >= (1u << 24) || max_dst >= (1u << 28));
     // Segments: compressed and decoded bytes of a segment are resident on the device together, so a file larger than the
     // card can hold goes through in several of them, one after the other (each with its own pieces, decode launches and
-    // counting pass).  Default: a third of the free device memory, at most 16 GiB of decoded bytes; env
-    // FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES overrides (tests).
+    // counting pass).  Default: a third of the free device memory -- for Zstandard, of what is free beside the scratch of
+    // two launches (8.5 MB per frame in flight; when that alone is more than half the device's free memory the pieces shrink
+    // instead, see lz4_gpu_segment) -- and at most 16 GiB of decoded bytes; env FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES overrides (tests).
     uint64_t seg_cap = 16ull << 30;
     {
         size_t free_b = 0, total_b = 0;
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 3 < seg_cap) seg_cap = free_b / 3;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) {
+            uint64_t avail = free_b;
+            // (what the engine already holds for the decoder is reused, not needed on top)
+            avail += e.lz4_cap[0] + e.lz4_cap[1];
+            for (uint64_t c : e.zstd_scratch_cap) avail += c;
+            if (in.codec == 1 && max_dst <= fsk::kZstdMaxFrameBytes) {
+                const uint64_t frames = blocks.size() < 1536 ? blocks.size() : 1536;
+                uint64_t scratch = static_cast<uint64_t>(Engine::kLz4Streams) * fsk_zstd_scratch_bytes(max_dst, static_cast<uint32_t>(frames));
+                if (scratch > avail / 2) scratch = avail / 2;
+                avail -= scratch;
+            }
+            if (avail / 3 < seg_cap) seg_cap = avail / 3;
+        } else {
+            (void)hipGetLastError();
+        }
         const char* sb = std::getenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES");
         if (sb && *sb) seg_cap = std::strtoull(sb, nullptr, 0);
     }
-    const auto t_meminfo = std::chrono::steady_clock::now();
+    pc.lap(pc.meminfo);
+    // The counters of all segments are collected here and reach the caller's out[] only when the last segment has succeeded: a
+    // segment the decoder does not take (a Zstandard frame with a checksum in the middle of a large file) or cannot hold then
+    // still hands the WHOLE file to the host-thread pipeline, and a failed call never leaves partial sums behind.
+    uint64_t acc[32] = {0};
     std::vector<fsk::GpuBlock> seg;
     for (size_t b0 = 0; b0 < blocks.size();) {
         size_t b1 = b0;
@@ -576,19 +754,17 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
             g.dst_off -= d0;
             seg_flags += static_cast<uint64_t>(g.dst_len) >> 1;
         }
-        const int rc = lz4_gpu_segment(e, in, file_lo, seg, file_hi - file_lo, dsz, seg_flags, out, stats);
+        const int rc = lz4_gpu_segment(e, in, file_lo, seg, file_hi - file_lo, dsz, seg_flags, acc, stats, pc, wave_kernel);
         if (rc) {
-            // nothing of a failed run stays on the device; a file the device cannot hold may still go through the host pipeline
-            // (only if nothing has been added to out[] yet)
+            // nothing of a failed run stays on the device, nothing of it has reached out[]: the two "not taken" codes mean the same
+            // in the first segment and in a later one
             lz4_gpu_release(e, false);
-            if (rc == kLz4GpuNoMemory && b0 != 0) return fail_text("GPU block decoder: out of device memory in a later segment");
-            if (rc == kGpuDecodeRejected && b0 != 0) return -1;  // (earlier segments are in out[] already: the message stands)
             return rc;
         }
         ++stats->segments;
         b0 = b1;
     }
-    const auto t_segments = std::chrono::steady_clock::now();
+    for (int k = 0; k < 32; ++k) out[k] += acc[k];
     // what stays with the engine for the next call: knob "lz4_gpu_keep_bytes" (~0 = automatic: at most a quarter of the device)
     e.lz4_idle = 0;
     {
@@ -602,10 +778,14 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         if (held > keep) lz4_gpu_release(e, false);
     }
     stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
-    if (prof_host) {
-        auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-        std::fprintf(stderr, "lz4 gpu profile, host side: index %.2f ms, device memory query %.2f ms, segments %.2f ms (of which the GPU pipeline %.2f ms), keep rule %.2f ms\n",
-                     ms(t_start, t_index), ms(t_index, t_meminfo), ms(t_meminfo, t_segments), stats->pipeline_ms, ms(t_segments, std::chrono::steady_clock::now()));
+    if (pc.on) {
+        double keep_rule = 0;
+        pc.lap(keep_rule);
+        std::fprintf(stderr, "gpu decode, host side (ms): index %.2f | device memory query %.2f | streams + events %.2f | hipMalloc compressed %.2f, decoded %.2f, "
+                             "index %.2f, scratch %.2f | pinned spans %.2f | reading + queueing the pieces %.2f | waiting for the device %.2f | keep rule %.2f | "
+                             "call %.2f (stream events: copies %.2f, decode behind the last copy %.2f, K1 %.2f)\n",
+                     pc.index, pc.meminfo, pc.streams, pc.alloc_comp, pc.alloc_out, pc.alloc_small, pc.alloc_scratch, pc.pinned, pc.queue, pc.wait, keep_rule,
+                     stats->wall_s * 1e3, stats->h2d_ms, stats->decode_ms, stats->count_ms);
     }
     return 0;
 }
@@ -627,5 +807,9 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     fsint::Lz4GpuSource src;
     src.img = image ? static_cast<const uint8_t*>(image) : &empty;
     src.bytes = bytes;
-    return fsint::lz4_gpu_run(e, src, out, stats);
+    const int rc = fsint::lz4_gpu_run(e, src, out, stats);
+    // (this entry has no host pipeline behind it: the "not taken" codes are errors here)
+    if (rc == fsint::kLz4GpuNoMemory) return fsint::fail_text("GPU block decoder: the device cannot hold the file's compressed and decoded bytes");
+    if (rc == fsint::kGpuDecodeRejected) return fsint::fail_text("GPU block decoder: the file is not one the decoder takes");
+    return rc;
 }

@@ -58,6 +58,22 @@ __global__ void checksum(const uint32_t* p, uint64_t n, unsigned long long* out)
     atomicAdd(out, s);
 }
 
+// the job's CPU quota at work: periods in which the cgroup was throttled, and for how long (cgroup v2 cpu.stat)
+static void throttle(const char* when)
+{
+    FILE* f = std::fopen("/sys/fs/cgroup/cpu.stat", "r");
+    if (!f) return;
+    char line[256];
+    unsigned long long nr = 0, us = 0, periods = 0;
+    while (std::fgets(line, sizeof line, f)) {
+        (void)std::sscanf(line, "nr_throttled %llu", &nr);
+        (void)std::sscanf(line, "throttled_usec %llu", &us);
+        (void)std::sscanf(line, "nr_periods %llu", &periods);
+    }
+    std::fclose(f);
+    std::printf("cgroup %s: %llu periods, %llu throttled, %.1f ms throttled in all\n", when, periods, nr, us / 1e3);
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return std::fprintf(stderr, "usage: %s FILE [threads] [span MiB] [reps]\n", argv[0]), 2;
@@ -85,6 +101,7 @@ int main(int argc, char** argv)
     };
     std::printf("file %s: %.1f MiB, %d threads, spans of %llu MiB\n", argv[1], bytes / 1048576.0, nthr, (unsigned long long)(span >> 20));
     unsigned long long want = 0;
+    throttle("at start");
 
     // ---- pread into three pinned spans (what r04 ships)
     {
@@ -125,7 +142,7 @@ int main(int argc, char** argv)
     }
     // ---- mmap, the runtime pins what it copies; with and without populating the page tables first
     for (int populate = 0; populate < 2; ++populate) {
-        for (int r = 0; r < reps; ++r) {
+        for (int r = 0; r < 1; ++r) {
             CK(hipMemsetAsync(d, 0, bytes, s));
             CK(hipStreamSynchronize(s));
             auto t0 = clk::now();
@@ -180,7 +197,10 @@ int main(int argc, char** argv)
             });
             t_reg += ms(p0, clk::now());
             if (bad.load()) break;
-            CK(hipMemcpyAsync(d + at, m + at, len, hipMemcpyHostToDevice, s));
+            {   // one copy per registered share: a copy may not span two registrations
+                const uint64_t share = ((len + nthr - 1) / nthr + 4095) & ~4095ull;
+                for (uint64_t o = 0; o < len; o += share) CK(hipMemcpyAsync(d + at + o, m + at + o, std::min(share, len - o), hipMemcpyHostToDevice, s));
+            }
         }
         if (bad.load()) {
             std::printf("register: hipHostRegister refuses the file mapping (%s)\n", hipGetErrorString(hipGetLastError()));
@@ -203,6 +223,75 @@ int main(int argc, char** argv)
         const bool ok = device_sum() == want;
         std::printf("register: %.2f ms = %.1f GB/s to the last byte on the device (registering %.2f ms of it, queued after %.2f); unregister %.2f ms, munmap %.2f%s\n", ms(t0, t2),
                     bytes / ms(t0, t2) / 1e6, t_reg, ms(t0, t1), ms(t2, t3), ms(t3, clk::now()), ok ? "" : "  WRONG BYTES");
+    }
+    // ---- pread STRAIGHT into device memory through the PCIe BAR (fine-grained device memory the host can address): the kernel's
+    //      copy_to_user is the only copy, no pinned spans, no DMA
+    {
+        int large_bar = 0;
+        (void)hipDeviceGetAttribute(&large_bar, hipDeviceAttributeIsLargeBar, 0);
+        void* fg = nullptr;
+        auto t0 = clk::now();
+        if (large_bar && hipExtMallocWithFlags(&fg, bytes + 4096, hipDeviceMallocFinegrained) == hipSuccess) {
+            std::printf("bar:      hipExtMallocWithFlags(fine-grained, %.0f MiB): %.2f ms\n", bytes / 1048576.0, ms(t0, clk::now()));
+            uint8_t* b = static_cast<uint8_t*>(fg);
+            for (int r = 0; r < reps; ++r) {
+                CK(hipMemsetAsync(fg, 0, bytes, s));
+                CK(hipStreamSynchronize(s));
+                t0 = clk::now();
+                std::atomic<int> short_reads{0};
+                parallel(nthr, [&](int t) {
+                    // every thread walks the file in 1 MiB slices, round robin: early parts of the file are complete early
+                    const uint64_t slice = 1ull << 20;
+                    for (uint64_t at = slice * t; at < bytes; at += slice * nthr) {
+                        uint64_t o = at;
+                        const uint64_t end = std::min(bytes, at + slice);
+                        while (o < end) {
+                            ssize_t got = pread(fd, b + o, end - o, o);
+                            if (got <= 0) { ++short_reads; return; }
+                            o += got;
+                        }
+                    }
+                    __builtin_ia32_sfence();
+                });
+                const double t = ms(t0, clk::now());
+                CK(hipMemcpyAsync(d, fg, bytes, hipMemcpyDeviceToDevice, s));  // (only so that the checksum kernel reads the same buffer)
+                const bool ok = device_sum() == want && !short_reads.load();
+                std::printf("bar:      %.2f ms = %.1f GB/s (pread into the BAR mapping, %d threads)%s\n", t, bytes / t / 1e6, nthr, ok ? "" : "  WRONG BYTES / pread refused");
+            }
+            CK(hipFree(fg));
+        } else {
+            (void)hipGetLastError();
+            std::printf("bar:      no large BAR / no fine-grained allocation\n");
+        }
+    }
+    // ---- what the first call of a process pays: pinned spans one after the other and three at a time, streams
+    {
+        uint8_t* pin[3] = {nullptr, nullptr, nullptr};
+        auto t0 = clk::now();
+        parallel(3, [&](int t) { (void)hipHostMalloc(&pin[t], span, hipHostMallocDefault); });
+        std::printf("alloc:    3 x %llu MiB pinned on three threads at once: %.1f ms\n", (unsigned long long)(span >> 20), ms(t0, clk::now()));
+        for (auto& p : pin) if (p) CK(hipHostFree(p));
+        t0 = clk::now();
+        uint8_t* one = nullptr;
+        CK(hipHostMalloc(&one, 3 * span, hipHostMallocDefault));
+        std::printf("alloc:    one pinned allocation of %llu MiB: %.1f ms\n", (unsigned long long)(3 * span >> 20), ms(t0, clk::now()));
+        CK(hipHostFree(one));
+        t0 = clk::now();
+        hipStream_t x[2];
+        for (auto& q : x) CK(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
+        const double t_create = ms(t0, clk::now());
+        t0 = clk::now();
+        for (auto& q : x) {
+            CK(hipMemsetAsync(d_sum, 0, 8, q));
+            CK(hipStreamSynchronize(q));
+        }
+        std::printf("alloc:    two streams created in %.2f ms, first use of both %.2f ms\n", t_create, ms(t0, clk::now()));
+        t0 = clk::now();
+        hipEvent_t ev[75];
+        for (auto& q : ev) CK(hipEventCreateWithFlags(&q, hipEventDisableTiming));
+        std::printf("alloc:    75 events created in %.2f ms\n", ms(t0, clk::now()));
+        for (auto& q : ev) CK(hipEventDestroy(q));
+        for (auto& q : x) CK(hipStreamDestroy(q));
     }
     // ---- for scale: the same bytes out of anonymous memory (image mode) and out of pinned memory
     {
@@ -236,6 +325,7 @@ int main(int argc, char** argv)
             CK(hipHostFree(pin));
         }
     }
+    throttle("at end");
     close(fd);
     return 0;
 }

@@ -22,11 +22,12 @@ def spawn(fault, *extra, timeout_env=None):
 
 
 def test_a_rank_that_dies_at_start_ends_the_run():
-    # rank 1 dies before it does anything; rank 0 is made to hang at the same point (on a GPU box it would sit in the
-    # rendezvous): the parent must stop it
-    r, took = spawn("1:start")
+    # rank 1 dies before it does anything; rank 0 is MADE to hang at the same point (on a GPU box it would sit in the
+    # rendezvous; here, without a GPU, it might otherwise die of its own in the same poll interval): the parent must stop it
+    r, took = spawn("1:start,0:start:hang")
     assert r.returncode != 0 and took < 30, (r.returncode, took, r.stderr[-2000:])
     assert "rank 1 exited with code 3" in r.stderr and "injected fault: rank 1 dies at stage start" in r.stderr
+    assert "injected fault: rank 0 hangs at stage start" in r.stderr
     assert not [ln for ln in r.stdout.splitlines() if ln.startswith("{")]      # no result line from a failed run
 
 
