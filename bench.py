@@ -361,6 +361,7 @@ def main():
     comm = None
     ar_impl = None
     rccl_nranks = None
+    rccl_library = None   # {path, version} of the RCCL the C-ABI all-reduce is bound to (N > 1)
     if multi:
         injected_fault("init", rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -411,6 +412,9 @@ def main():
                     raise _lib.FlagstatsHipError(box.get("err", "communicator creation failed"))
                 ar_impl = "FLAGSTATS_hip_allreduce_counters (C ABI, ncclAllReduce uint64[32])"
                 rccl_nranks = int(lib.FLAGSTATS_hip_comm_count(comm))
+                buf, ver = ctypes.create_string_buffer(1024), ctypes.c_int(-1)
+                if lib.FLAGSTATS_hip_comm_library(buf, len(buf), ctypes.byref(ver)) == 0:
+                    rccl_library = {"path": buf.value.decode(errors="replace"), "version": int(ver.value)}
                 if rccl_nranks != world:
                     raise _lib.FlagstatsHipError("ncclCommCount says %d ranks, the launcher %d" % (rccl_nranks, world))
             except Exception as e:  # noqa: BLE001 -- a scaling run must not die on the communicator; say so instead
@@ -420,6 +424,7 @@ def main():
                     lib.FLAGSTATS_hip_comm_destroy(comm)
                 comm = None
                 rccl_nranks = None
+                rccl_library = None
                 ar_impl = "torch.distributed (%s)" % args.backend
             # every rank must take the same path
             flag = torch.tensor([1 if comm else 0], dtype=torch.int32, device=dev if args.backend == "nccl" else "cpu")
@@ -703,6 +708,7 @@ def main():
                        "allreduce": (("overlapped" if state["overlap"] else "in-line") + calib_note) if multi else None,
                        "allreduce_impl": ar_impl,
                        "rccl_nranks": rccl_nranks,
+                       "rccl_library": rccl_library if comm else None,
                        "per_rank_ms": per_rank_ms,
                        "slowest_rank": (max(range(world), key=lambda r: per_rank_ms[r]) if per_rank_ms else None),
                        "allreduce_us": allreduce_us,

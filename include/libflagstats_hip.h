@@ -136,6 +136,9 @@ int FLAGSTATS_hip_comm_unique_id(void* id128);
 void* FLAGSTATS_hip_comm_init_rank(const void* id128, int nranks, int rank, int device); /* NULL on failure */
 int FLAGSTATS_hip_comm_destroy(void* comm);
 int FLAGSTATS_hip_comm_count(void* comm);   /* ranks RCCL sees in the communicator (ncclCommCount); < 0 on failure */
+/* which RCCL is bound: path of the shared object that holds ncclAllReduce (dladdr; "" if unknown) and ncclGetVersion's
+ * number (-1 if unknown); binds RCCL if nothing has yet; non-zero when RCCL cannot be loaded */
+int FLAGSTATS_hip_comm_library(char* path, uint64_t cap, int* version);
 int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* stream);
 int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream);
 /* the same query with the collective OFF the launch stream: K1 + K2 (store) on `stream`, the all-reduce on

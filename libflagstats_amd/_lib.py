@@ -66,6 +66,7 @@ SIGNATURES = {
     "FLAGSTATS_hip_comm_init_rank": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int]),
     "FLAGSTATS_hip_comm_destroy": (ctypes.c_int, [ctypes.c_void_p]),
     "FLAGSTATS_hip_comm_count": (ctypes.c_int, [ctypes.c_void_p]),
+    "FLAGSTATS_hip_comm_library": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64, ctypes.POINTER(ctypes.c_int)]),
     "FLAGSTATS_hip_allreduce_counters": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]),
     "FLAGSTATS_hip_device_u16_allreduce_overlapped": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
                                                                      ctypes.c_void_p, ctypes.c_void_p]),

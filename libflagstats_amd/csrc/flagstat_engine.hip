@@ -15,6 +15,7 @@
 #include <cstring>
 #include <memory>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "flagstat_kernels.h"
@@ -192,10 +193,23 @@ int engine_setup(Engine& e, int device)
     e.device = device;
     e.cus = prop.multiProcessorCount;
     e.numa_node = numa_node_of_device(device);
-    for (int i = 0; i < 2; ++i) {
-        HIP_TRY(hipStreamCreateWithFlags(&e.stream[i], hipStreamNonBlocking));
-        HIP_TRY(hipMalloc(&e.d_out[i], 4096));  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
-        HIP_TRY(hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming));
+    {
+        // A stream costs 7-10 ms to make (a hardware queue; profiles/r05/file_h2d.log: two in 14.5-21 ms) and a one-shot process
+        // pays for both before its first call: the second one is made on a helper thread beside the first and the small
+        // allocations.
+        hipError_t err1 = hipSuccess;
+        std::thread second([&] {
+            err1 = hipSetDevice(device);
+            if (err1 == hipSuccess) err1 = hipStreamCreateWithFlags(&e.stream[1], hipStreamNonBlocking);
+        });
+        hipError_t err0 = hipStreamCreateWithFlags(&e.stream[0], hipStreamNonBlocking);
+        for (int i = 0; i < 2 && err0 == hipSuccess; ++i) {
+            err0 = hipMalloc(&e.d_out[i], 4096);  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
+            if (err0 == hipSuccess) err0 = hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming);
+        }
+        second.join();
+        if (err0 != hipSuccess) return fail_hip("engine creation: stream / counters / events", err0);
+        if (err1 != hipSuccess) return fail_hip("engine creation: second stream", err1);
     }
     lap(3);
     HIP_TRY(hipHostMalloc(&e.h_out, kHostOutBytes, hipHostMallocDefault));

@@ -43,6 +43,7 @@
 
 #include "../../include/libflagstats_hip.h"
 #include "flagstat_engine.h"
+#include "flagstat_kernels.h"
 #include "flagstat_lz4_kernels.h"
 #include "flagstat_zstd_kernels.h"
 
@@ -136,7 +137,7 @@ static int lz4_gpu_events(Engine& e)
     return 0;
 }
 
-static int lz4_gpu_streams(Engine& e)   // (may run on a helper thread: makes the engine's device current itself)
+static int lz4_gpu_streams(Engine& e, int codec)   // (runs on a helper thread: makes the engine's device current itself)
 {
     DeviceGuard guard(e.device);
     if (!guard.ok()) return -1;
@@ -144,6 +145,17 @@ static int lz4_gpu_streams(Engine& e)   // (may run on a helper thread: makes th
     for (hipStream_t& x : e.lz4_stream)
         if (err == hipSuccess && !x) err = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
     if (err != hipSuccess) return fail_hip("GPU block decoder: streams", err);
+    // ... and the code objects the call is about to launch from are loaded here instead of inside the first launches (the
+    // occupancy queries load the decode kernels' translation unit, fsk_warm K1's)
+    const char* wk = std::getenv("FLAGSTATS_HIP_GPU_WARM");   // (A/B: 0 = leave the loads to the first launches)
+    const int warm = wk ? std::atoi(wk) : 3;
+    if (warm & 1) {
+        if (codec == 1)
+            (void)fsk_zstd_frames_per_cu();
+        else
+            (void)fsk_lz4_blocks_per_cu(knobs().lz4_gpu_kernel.load() == 0 ? fsk::LZ4K_WORKGROUP : fsk::LZ4K_WAVE);
+    }
+    if (warm & 2) fsk_warm();
     return 0;
 }
 
@@ -171,7 +183,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     } joiner{maker};
     if (!e.lz4_ready)
         maker = std::thread([&] {
-            maker_rc = lz4_gpu_streams(e);
+            maker_rc = lz4_gpu_streams(e, in.codec);
             if (maker_rc) maker_err = last_error_text();
         });
     bool streams_wait_index = false;   // the decode streams still have to be told to wait for the index (event 3)
@@ -332,10 +344,33 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             }
             e.lz4_pin = nullptr;
             e.lz4_pin_bytes = 0;
-            e.lz4_pin = static_cast<uint8_t*>(host_alloc_on_node(ring_bytes, e.numa_node));
-            if (!e.lz4_pin) {
+            // Page-locking costs 0.2 ms per MiB when the thread that asks runs on the node the pages are placed on, and 0.5 when
+            // it does not (it zeroes them across the sockets: 31 ms for 64 MiB, profiles/r05/cold_start_mid.log): the allocation
+            // runs on a thread bound to the GPU's node, like the readers that fill the ring afterwards.
+            int arc = 0;
+            std::string aerr;
+            std::thread alloc([&] {
+                cpu_set_t cpus;
+                if (knobs().numa.load() && node_cpuset(e.numa_node, &cpus)) (void)pthread_setaffinity_np(pthread_self(), sizeof cpus, &cpus);
+                DeviceGuard g2(e.device);
+                const char* rk = std::getenv("FLAGSTATS_HIP_GPU_RING_ALLOC");   // (A/B: plain = hipHostMalloc without a memory policy)
+                if (rk && !std::strcmp(rk, "plain")) {
+                    void* p = nullptr;
+                    const hipError_t e_ = g2.ok() ? hipHostMalloc(&p, ring_bytes, hipHostMallocDefault) : hipErrorInvalidDevice;
+                    if (e_ != hipSuccess) fail_hip("hipHostMalloc(pinned ring)", e_);
+                    e.lz4_pin = e_ == hipSuccess ? static_cast<uint8_t*>(p) : nullptr;
+                } else {
+                    e.lz4_pin = g2.ok() ? static_cast<uint8_t*>(host_alloc_on_node(ring_bytes, e.numa_node)) : nullptr;
+                }
+                if (!e.lz4_pin) {
+                    arc = -1;
+                    aerr = last_error_text();
+                }
+            });
+            alloc.join();
+            if (arc) {
                 settle();
-                return -1;
+                return fail_again(aerr.c_str(), arc);
             }
             e.lz4_pin_bytes = ring_bytes;
         }
@@ -387,30 +422,39 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             return kGpuDecodeRejected;
         }
         for (;;) {
-            uint64_t most = 0;
-            for (const Piece& pc : pieces) most = pc.last - pc.first > most ? pc.last - pc.first : most;
-            const uint64_t need = fsk_zstd_scratch_bytes(z_max_dst, static_cast<uint32_t>(most));
-            const uint32_t used = pieces.size() < nstreams ? static_cast<uint32_t>(pieces.size()) : nstreams;
+            // every decode stream's scratch holds the largest piece THAT stream gets (piece c runs on stream c % nstreams): with the
+            // first piece half a share, the two differ by a third
+            uint64_t most[nstreams] = {};
+            uint64_t most_all = 0;
+            for (size_t c = 0; c < pieces.size(); ++c) {
+                const uint64_t k = pieces[c].last - pieces[c].first;
+                most[c % nstreams] = k > most[c % nstreams] ? k : most[c % nstreams];
+                most_all = k > most_all ? k : most_all;
+            }
             bool ok = true;
-            for (uint32_t i = 0; i < used && ok; ++i)
-                if (e.zstd_scratch_cap[i] < need) {
-                    uint8_t* old = e.zstd_scratch[i];
+            for (uint32_t i = 0; i < nstreams && ok; ++i) {
+                if (!most[i]) continue;
+                const uint64_t need = fsk_zstd_scratch_bytes(z_max_dst, static_cast<uint32_t>(most[i]));
+                if (e.zstd_scratch_cap[i] >= need) continue;
+                uint8_t* old = e.zstd_scratch[i];
+                e.zstd_scratch[i] = nullptr;
+                e.zstd_scratch_cap[i] = 0;
+                if (old) LZG_TRY(hipFree(old));
+                const uint64_t sgrain = grain < (16ull << 20) ? grain : (16ull << 20);
+                const uint64_t cap = (need + sgrain - 1) / sgrain * sgrain;
+                // (env FLAGSTATS_HIP_GPU_SCRATCH_CAP: tests make requests above it fail, as a busy device would)
+                const char* sck = std::getenv("FLAGSTATS_HIP_GPU_SCRATCH_CAP");
+                const hipError_t e_ = sck && cap > std::strtoull(sck, nullptr, 0) ? hipErrorOutOfMemory : hipMalloc(&e.zstd_scratch[i], cap);
+                if (e_ != hipSuccess) {
+                    (void)hipGetLastError();
                     e.zstd_scratch[i] = nullptr;
-                    e.zstd_scratch_cap[i] = 0;
-                    if (old) LZG_TRY(hipFree(old));
-                    const uint64_t sgrain = grain < (16ull << 20) ? grain : (16ull << 20);
-                    const uint64_t cap = (need + sgrain - 1) / sgrain * sgrain;
-                    const hipError_t e_ = hipMalloc(&e.zstd_scratch[i], cap);
-                    if (e_ != hipSuccess) {
-                        (void)hipGetLastError();
-                        e.zstd_scratch[i] = nullptr;
-                        ok = false;
-                    } else {
-                        e.zstd_scratch_cap[i] = cap;
-                    }
+                    ok = false;
+                } else {
+                    e.zstd_scratch_cap[i] = cap;
                 }
+            }
             if (ok) break;
-            if (most <= 1 || npieces >= static_cast<uint32_t>(Engine::kLz4MaxPieces) || npieces >= blocks.size()) {
+            if (most_all <= 1 || npieces >= static_cast<uint32_t>(Engine::kLz4MaxPieces) || npieces >= blocks.size()) {
                 settle();
                 return kLz4GpuNoMemory;
             }

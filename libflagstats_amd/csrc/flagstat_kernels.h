@@ -59,6 +59,7 @@ struct CountArgs {
 extern "C" {
 // bytes of workspace K1 needs for `grid` workgroups
 size_t fsk_partials_bytes(uint32_t grid);
+void fsk_warm(void);                      // loads K1 / K2's code object without a launch (a process's first call, off its critical path)
 // K1 + K2 on `stream`: d_out32[32] += counters of d_array[0..n).  Asynchronous.
 // variant bits 0-7: K1 schedule; bit 8: store instead of accumulate; bit 9: fused finalise (needs d_ticket);
 // bit 10: superset slots; bit 11: direct atomic epilogue (accumulate form only; K1 alone, no K2)

@@ -1028,6 +1028,14 @@ __global__ __launch_bounds__(kFinalizeThreads) void flagstat_finalize(const uint
 // finalise, 8 the dynamic schedule's "retired workgroups" word, 16 * (i + 1) the counter of its queue i (up to 16, one
 // cache line each), kGroupTicketWord + 16 * g the ticket of epilogue group g, kGroupCopyWord + 32 * g that group's
 // copy of the 32 slots.  The block must be zero before the first launch and is left zero by every launch.
+// Loads this translation unit's code object (K1, K2) without launching anything: the first launch of a process otherwise pays
+// for it in line.  The GPU decoders' first call runs it on its helper thread (flagstat_gpu_decode.hip).
+extern "C" void fsk_warm(void)
+{
+    hipFuncAttributes attr;
+    if (hipFuncGetAttributes(&attr, reinterpret_cast<const void*>(&fsk::flagstat_finalize)) != hipSuccess) (void)hipGetLastError();
+}
+
 extern "C" size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 8192; }
 
 static std::atomic<int> g_epoch_stagger{1};          // K1 mode bit 4: waves of a workgroup end their epochs at different steps

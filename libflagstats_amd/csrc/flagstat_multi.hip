@@ -268,6 +268,30 @@ int FLAGSTATS_hip_comm_count(void* comm)
     return n;
 }
 
+// Which RCCL carried the collective: the path of the shared object that holds the bound ncclAllReduce (dladdr -- torch's
+// bundled copy or /opt/rocm's) and its version (ncclGetVersion).  Goes into the N > 1 bench line, so that a scaling curve says
+// what it was measured with.
+int FLAGSTATS_hip_comm_library(char* path, uint64_t cap, int* version)
+{
+    const Rccl* r = rccl();
+    if (!r) return -1;
+    if (path && cap) {
+        path[0] = 0;
+        Dl_info info;
+        std::memset(&info, 0, sizeof info);
+        if (dladdr(reinterpret_cast<const void*>(r->AllReduce), &info) && info.dli_fname) std::snprintf(path, cap, "%s", info.dli_fname);
+    }
+    if (version) {
+        *version = -1;
+        typedef ncclResult_t (*getversion_fn)(int*);
+        if (getversion_fn gv = reinterpret_cast<getversion_fn>(dlsym(r->handle, "ncclGetVersion"))) {
+            int v = -1;
+            if (gv(&v) == ncclSuccess) *version = v;
+        }
+    }
+    return 0;
+}
+
 int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* stream)
 {
     if (!d_counters || !comm) return fail_text("NULL counters or communicator");

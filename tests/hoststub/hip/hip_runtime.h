@@ -10,7 +10,7 @@
 #include <stdint.h>
 
 typedef int hipError_t;
-enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorNoDevice = 100, hipErrorNotReady = 600, hipErrorStreamCaptureUnsupported = 900 };
+enum { hipSuccess = 0, hipErrorInvalidValue = 1, hipErrorOutOfMemory = 2, hipErrorNoDevice = 100, hipErrorInvalidDevice = 101, hipErrorNotReady = 600, hipErrorStreamCaptureUnsupported = 900 };
 
 struct StubStream;
 struct StubEvent;

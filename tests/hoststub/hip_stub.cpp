@@ -16,6 +16,7 @@
 #include <functional>
 #include <map>
 #include <mutex>
+#include <shared_mutex>
 #include <thread>
 #include <vector>
 
@@ -69,6 +70,9 @@ namespace {
 
 thread_local int t_device = 0;
 std::mutex g_mu;                       // stream registry + allocation map
+std::shared_mutex g_life;              // a device-wide sync walks the streams (shared); a stream is deleted under it (exclusive):
+                                       // without it a hipFree on one thread touched a stream another thread was destroying
+                                       // (two sessions closing at once: one ThreadSanitizer report in ~20 runs)
 std::vector<StubStream*> g_streams;
 std::map<int, StubStream*> g_null;     // per-device NULL stream
 
@@ -166,6 +170,7 @@ hipError_t hipDeviceGetPCIBusId(char* buf, int len, int d)
 }
 hipError_t hipDeviceSynchronize(void)
 {
+    std::shared_lock<std::shared_mutex> life(g_life);
     std::vector<StubStream*> all;
     {
         std::lock_guard<std::mutex> lk(g_mu);
@@ -297,6 +302,7 @@ hipError_t hipStreamDestroy(hipStream_t s)
     }
     s->cv.notify_all();
     s->th.join();
+    std::unique_lock<std::shared_mutex> life(g_life);
     {
         std::lock_guard<std::mutex> lk(g_mu);
         for (size_t i = 0; i < g_streams.size(); ++i)
@@ -394,6 +400,7 @@ hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b)
 // ------------------------------------------------------------------ the kernels' launchers, computed by the oracle
 extern "C" {
 
+void fsk_warm(void) {}
 size_t fsk_partials_bytes(uint32_t grid) { return static_cast<size_t>(grid) * fsk::kInternal * sizeof(uint64_t) + 8192; }
 
 hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int variant, uint64_t* d_partials, uint32_t*,

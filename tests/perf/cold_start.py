@@ -69,12 +69,17 @@ def report(name, samples, n_flags, ref_note=""):
         line += " | the same call again in that process %.1f ms: first / warm = %.2fx" % (med(warm), med(first) / med(warm))
     line += " | whole process %.1f ms | %.2f Gflags/s one-shot" % (med([s["process_ms"] for s in samples]), n_flags / med(ready) / 1e6)
     print(line + ref_note, flush=True)
-    if samples[0].get("init_phases"):
-        print("    " + samples[0]["init_phases"][0], flush=True)
-    if samples[0]["phases"]:
-        print("    first call, " + samples[0]["phases"][0], flush=True)
-        if len(samples[0]["phases"]) > 1:
-            print("    second call, " + samples[0]["phases"][1], flush=True)
+    print("    every sample: start -> counters %s ms; first call %s ms" % (" ".join("%.0f" % x for x in ready), " ".join("%.0f" % x for x in first)), flush=True)
+    typical = min(samples, key=lambda s: abs(s["calls_ms"][0] - med(first)))
+    slowest = max(samples, key=lambda s: s["calls_ms"][0])
+    if typical.get("init_phases"):
+        print("    " + typical["init_phases"][0], flush=True)
+    if typical["phases"]:
+        print("    first call (the median sample), " + typical["phases"][0], flush=True)
+        if len(typical["phases"]) > 1:
+            print("    second call, " + typical["phases"][1], flush=True)
+    if slowest is not typical and slowest["calls_ms"][0] > 1.5 * med(first) and slowest["phases"]:
+        print("    first call (the SLOWEST sample), " + slowest["phases"][0], flush=True)
 
 
 def reference_program(path, raw):
@@ -139,6 +144,7 @@ def main():
             with tempfile.NamedTemporaryFile(suffix=suffix, dir=tmp) as f:
                 f.write(img)
                 f.flush()
+                os.fsync(f.fileno())   # written back before the timed reads: a file in the page cache, clean
                 size = len(img)
                 del img
                 samples = [spawn_oneshot("blockfile", f.name, env_extra=env_extra) for _ in range(args.samples)]
@@ -154,6 +160,7 @@ def main():
                 for at in range(0, args.flags, per):
                     f.write(oracle.generate(oracle.GEN_NA12878, 7, 1, at, min(per, args.flags - at)).tobytes())
                 f.flush()
+                os.fsync(f.fileno())   # written back before the timed reads: a file in the page cache, clean
                 samples = [spawn_oneshot("raw", f.name, env_extra=env_extra) for _ in range(args.samples)]
                 assert all(s["n_flags"] == args.flags for s in samples)
                 ref = reference_program(f.name, raw=True)

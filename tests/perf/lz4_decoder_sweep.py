@@ -78,6 +78,7 @@ def main():
                 with tempfile.NamedTemporaryFile(suffix=".zst" if zstd else ".lz4", dir=os.environ.get("TMPDIR", "/tmp")) as f:
                     f.write(img)
                     f.flush()
+                    os.fsync(f.fileno())   # written back before the timed reads: a file in the page cache, clean
                     line = "      the same as a FILE (page cache):"
                     for dec in (0, 1):
                         _lib.check(lib.FLAGSTATS_hip_set(knob, dec), "set")

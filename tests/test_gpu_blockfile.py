@@ -531,3 +531,50 @@ def test_size_rule_leaves_incompressible_files_to_the_host_threads(hip):
     finally:
         assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 2) == 0
         assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 64 << 20) == 0
+
+
+def test_blocks_beyond_the_workgroup_kernels_limits_go_to_the_wave_kernel(gpu_decoder):
+    """ADVICE r04: the workgroup kernel's records address 16 MiB of payload and 256 MiB of output per block (status 10 beyond);
+    the reference's writer never makes such blocks, but they are valid files: known from the index, they send the file to the
+    wave-per-block kernel instead of failing the call."""
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_UNIFORM, 81, 0xFFFF, 0, (17 << 20) // 2 + 1000)         # incompressible: payload > 16 MiB
+    img = bt.block_file_image(flags, block_bytes=17 << 20)
+    assert max(cs for _, cs in _headers(img)) >= 1 << 24
+    want = expect(flags, 17 << 20)[0]
+    got, st = blockfile.flagstat_lz4_image(img, 2)
+    assert st["gpu_decode"] == 1 and np.array_equal(got, want)
+    rc, got2, gst = gpu_decode(gpu_decoder, img)
+    assert rc == 0 and np.array_equal(got2, want) and gst.ring_kib == 8        # (8 KiB ring: the wave kernel ran)
+
+
+def _headers(img):
+    import struct
+    pos = 0
+    while pos < len(img):
+        us, cs = struct.unpack_from("<ii", img, pos)
+        yield us, cs
+        pos += 8 + cs
+
+
+def test_a_header_that_declares_more_than_its_payload_can_decode_to_is_refused(hip):
+    """A damaged 60-byte file must not make the reader size buffers from a 2 GiB header: an LZ4 block grows by at most 255
+    bytes per payload byte, a Zstandard frame by at most 128 KiB per 4 bytes -- both index passes refuse what lies beyond,
+    loudly, on the host-thread path and on the GPU path."""
+    import struct
+    from libflagstats_amd import _lib, blockfile
+    raw = bytes(200)
+    for codec, entry, knob in (("fast", blockfile.flagstat_lz4_image, b"lz4_decoder"), ("zstd", blockfile.flagstat_zstd_image, b"zstd_decoder")):
+        comp = bt.compress_block(raw, codec if codec == "zstd" else "fast", 1)
+        good = struct.pack("<ii", len(raw), len(comp)) + comp
+        bad = struct.pack("<ii", 0x7FFFFFF0, len(comp)) + comp
+        for dec in (0, 1):
+            assert hip.FLAGSTATS_hip_set(knob, dec) == 0
+            try:
+                got, _ = entry(good, 1)
+                assert not got.any()                 # 100 zero flags count nothing
+                with pytest.raises(_lib.FlagstatsHipError, match="declares more decoded bytes"):
+                    entry(bad, 1)
+            finally:
+                assert hip.FLAGSTATS_hip_set(knob, 2) == 0

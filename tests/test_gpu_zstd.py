@@ -2,6 +2,7 @@
 product entries against the oracle and against the libzstd host pipeline, on the reference-written .zst goldens, on
 synthetic streams of every compressor level, on damaged and on unsupported-but-valid frames.
 The reference decodes every payload with ZSTD_decompress (benchmark/flagstats.cpp:636-682)."""
+import ctypes
 import json
 import os
 import random
@@ -385,3 +386,62 @@ def test_gpu_zstd_decoder_is_the_default_for_large_files(hip, tmp_path):
         finally:
             assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 2) == 0
         assert st["gpu_decode"] == 1 and np.array_equal(got, want)
+
+
+def test_a_frame_the_gpu_decoder_does_not_take_in_a_later_segment_sends_the_whole_file_to_libzstd(hip, monkeypatch):
+    """with the decoder chosen by size, a file that goes through in several segments and meets a frame the GPU
+    decoder does not take (here: two concatenated frames in one payload) in a LATER segment must still fall back to the host
+    pipeline -- the segments before it must not have reached the caller's counters (they are collected and added only after
+    the last segment) -- and forced, the call fails with a message and leaves the counters untouched."""
+    import oracle
+    from libflagstats_amd import _lib, blockfile
+    raws = [oracle.generate(oracle.GEN_NA12878, 90 + i, 1, 0, 150000).tobytes() for i in range(6)]
+    parts = [bt.compress_block(r, "zstd", 1) for r in raws]
+    two = bt.compress_block(raws[4][:100000], "zstd", 1) + bt.compress_block(raws[4][100000:], "zstd", 1)
+    parts[4] = two                                  # valid Zstandard (libzstd decodes both frames), not taken by the GPU decoder
+    img = b"".join(struct.pack("<ii", len(r), len(p)) + p for r, p in zip(raws, parts))
+    want = expect_blocks(raws)
+    monkeypatch.setenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES", "400000")      # two frames per segment: the odd one is in the third
+    assert hip.FLAGSTATS_hip_get(b"zstd_decoder") == 2
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 1) == 0
+    try:
+        got, st = blockfile.flagstat_zstd_image(img, 2)
+        assert st["gpu_decode"] == 0 and np.array_equal(got, want)
+        assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+        out = np.full(32, 7, dtype=np.uint64)
+        buf = (ctypes.c_char * len(img)).from_buffer_copy(img)
+        rc = hip.FLAGSTATS_hip_blockimage_zstd(buf, len(img), 2, out.ctypes.data, None)
+        assert rc != 0 and b"Zstandard" in hip.FLAGSTATS_hip_last_error()
+        assert (out == 7).all()                      # nothing of the first two segments was added
+    finally:
+        assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 2) == 0
+        assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 64 << 20) == 0
+
+
+def test_zstd_scratch_that_does_not_fit_makes_smaller_pieces(zgpu, monkeypatch):
+    """the scratch between the kernels (8.5 MB per frame in flight and decode stream) is what a busy device runs out
+    of first; a failed scratch allocation halves the frames per launch instead of giving the file up.  Forced here with a
+    piece count of one on a file whose one-piece scratch is above the test's cap."""
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_NA12878, 97, 1, 0, 512000 * 12)
+    img = bt.block_file_image(flags, mode="zstd", level=1)
+    want = expect(flags, bt.BLOCK_BYTES)[0]
+    auto = (1 << 64) - 1
+    assert zgpu.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", 0) == 0             # nothing kept from earlier files: the scratch is asked for anew
+    try:
+        blockfile.flagstat_zstd_image(bt.block_file_image(flags[:1000], mode="zstd", level=1), 2)
+        assert zgpu.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
+        monkeypatch.setenv("FLAGSTATS_HIP_GPU_SCRATCH_CAP", str(40 << 20))  # test knob: a scratch request above this "fails"
+        got, st = blockfile.flagstat_zstd_image(img, 2)
+        assert st["gpu_decode"] == 1 and np.array_equal(got, want)
+        assert st["chunks"] >= 4                    # 13 frames at ~8.5 MB each: at most four fit under 40 MB
+        monkeypatch.setenv("FLAGSTATS_HIP_GPU_SCRATCH_CAP", str(4 << 20))   # not even one frame's: the file goes to the host threads ...
+        assert zgpu.FLAGSTATS_hip_set(b"zstd_decoder", 2) == 0
+        assert zgpu.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 1) == 0
+        got, st = blockfile.flagstat_zstd_image(img, 2)
+        assert st["gpu_decode"] == 0 and np.array_equal(got, want)
+    finally:
+        assert zgpu.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 64 << 20) == 0
+        assert zgpu.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
+        assert zgpu.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", auto) == 0
