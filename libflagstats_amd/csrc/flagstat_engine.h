@@ -64,6 +64,13 @@ Knobs& knobs();
 // | OP_HOST_OUT (d_out is pinned-host or managed memory: counters are written by K2, never by device atomics)
 enum { OP_FLAGSTAT = 0, OP_POSPOPCNT = 1, OP_FLAGSTAT_STORE = 2, OP_BASE_MASK = 3, OP_SUPERSET = 4, OP_HOST_OUT = 8 };
 
+// page-locked host memory from host_alloc_registered (below)
+struct RegisteredHost {
+    void* ptr = nullptr;       // what the caller uses (2 MiB aligned when mapped here)
+    void* map = nullptr;       // the mapping behind it (nullptr: `ptr` came from hipHostMalloc)
+    size_t map_bytes = 0;
+};
+
 struct Engine {
     // Handles that outlive a FLAGSTATS_hip_shutdown (sessions, explicit contexts) keep the OBJECT alive through `refs`; the
     // shutdown releases the engine's GPU resources and marks it `dead`, after which every operation on it fails loudly
@@ -92,6 +99,7 @@ struct Engine {
     uint64_t host_chunks = 0;                      // last multi-chunk host call: chunks submitted ...
     uint64_t host_overlapped = 0;                  // ... and how many were submitted while the previous one was still in flight
     void* pinned[3] = {nullptr, nullptr, nullptr}; // block-file chunk buffers, kept across calls
+    RegisteredHost pinned_reg[3];                  // ... and what they are made of (host_alloc_registered)
     uint8_t* lz4_buf[2] = {nullptr, nullptr};      // GPU LZ4 decoder: compressed / decoded bytes of a segment, kept across calls
     uint64_t lz4_cap[2] = {0, 0};                  // (knob "lz4_gpu_keep_bytes"; released after kLz4IdleCalls other calls)
 #ifndef FLAGSTAT_DECODE_STREAMS   // (measurement builds: more decode streams)
@@ -104,6 +112,8 @@ struct Engine {
     hipEvent_t lz4_landed[kLz4MaxPieces] = {}, lz4_joined[kLz4Streams] = {}, lz4_pin_free[kLz4MaxSpans] = {};
     uint8_t* lz4_pin = nullptr;                    // ... ONE page-locked allocation holding the ring (on the GPU's NUMA node)
     uint64_t lz4_pin_bytes = 0;
+    void* lz4_pin_map = nullptr;                   // (the mapping behind it when it is registered anonymous memory: host_alloc_registered)
+    size_t lz4_pin_map_bytes = 0;
     uint8_t* zstd_scratch[kLz4Streams] = {};       // GPU Zstandard decoder: records / literals / checkpoints of a piece, per decode stream
     uint64_t zstd_scratch_cap[kLz4Streams] = {};   // (kept and released with the two large buffers)
     void* lz4_index = nullptr;                     // blocks + status + tally of a segment
@@ -182,6 +192,12 @@ int count_host_shared(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, i
 int stage_reserve(Engine& e, int slot, uint64_t flags);   // e.mu held
 int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3]);  // e.mu held
 void* host_alloc_on_node(size_t bytes, int numa_node);   // pinned, pages placed on `numa_node` when >= 0
+// Page-locked memory the quick way: anonymous memory backed by transparent huge pages, first touched by threads bound to
+// `numa_node`'s CPUs (so it lies there), then hipHostRegister-ed -- 48 MiB in 0.8 ms where hipHostMalloc takes 6-40 ms (it locks
+// and maps 4 KiB pages one by one: 0.2-0.5 ms per MiB; profiles/r05/file_h2d.log), copies out of it at the link's rate.
+// Falls back to host_alloc_on_node.  Release with host_free_registered (the pair keeps no table: the owner remembers `bytes`).
+RegisteredHost host_alloc_registered(size_t bytes, int numa_node);   // ptr == nullptr on failure (error recorded)
+void host_free_registered(RegisteredHost& r);
 uint64_t chunk_bytes();
 // CPUs of host NUMA node `node` inside the calling process's own affinity mask (flagstat_blocks.hip); false: unknown / none
 bool node_cpuset(int node, cpu_set_t* set);

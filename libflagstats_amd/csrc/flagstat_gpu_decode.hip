@@ -73,6 +73,19 @@ struct PhaseClock {
 };
 }  // namespace
 
+static void lz4_gpu_free_ring(Engine& e)
+{
+    RegisteredHost r;
+    r.ptr = e.lz4_pin;
+    r.map = e.lz4_pin_map;
+    r.map_bytes = e.lz4_pin_map_bytes;
+    host_free_registered(r);
+    e.lz4_pin = nullptr;
+    e.lz4_pin_bytes = 0;
+    e.lz4_pin_map = nullptr;
+    e.lz4_pin_map_bytes = 0;
+}
+
 void lz4_gpu_release(Engine& e, bool all)
 {
     for (int i = 0; i < 2; ++i) {
@@ -103,9 +116,7 @@ void lz4_gpu_release(Engine& e, bool all)
     if (e.lz4_index) (void)hipFree(e.lz4_index);
     e.lz4_index = nullptr;
     e.lz4_index_cap = 0;
-    if (e.lz4_pin) (void)hipHostFree(e.lz4_pin);
-    e.lz4_pin = nullptr;
-    e.lz4_pin_bytes = 0;
+    lz4_gpu_free_ring(e);
     e.lz4_ready = false;
 }
 
@@ -340,38 +351,19 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         if (e.lz4_pin_bytes < ring_bytes) {
             if (e.lz4_pin) {
                 LZG_TRY(hipStreamSynchronize(s));
-                (void)hipHostFree(e.lz4_pin);
+                lz4_gpu_free_ring(e);
             }
-            e.lz4_pin = nullptr;
-            e.lz4_pin_bytes = 0;
-            // Page-locking costs 0.2 ms per MiB when the thread that asks runs on the node the pages are placed on, and 0.5 when
-            // it does not (it zeroes them across the sockets: 31 ms for 64 MiB, profiles/r05/cold_start_mid.log): the allocation
-            // runs on a thread bound to the GPU's node, like the readers that fill the ring afterwards.
-            int arc = 0;
-            std::string aerr;
-            std::thread alloc([&] {
-                cpu_set_t cpus;
-                if (knobs().numa.load() && node_cpuset(e.numa_node, &cpus)) (void)pthread_setaffinity_np(pthread_self(), sizeof cpus, &cpus);
-                DeviceGuard g2(e.device);
-                const char* rk = std::getenv("FLAGSTATS_HIP_GPU_RING_ALLOC");   // (A/B: plain = hipHostMalloc without a memory policy)
-                if (rk && !std::strcmp(rk, "plain")) {
-                    void* p = nullptr;
-                    const hipError_t e_ = g2.ok() ? hipHostMalloc(&p, ring_bytes, hipHostMallocDefault) : hipErrorInvalidDevice;
-                    if (e_ != hipSuccess) fail_hip("hipHostMalloc(pinned ring)", e_);
-                    e.lz4_pin = e_ == hipSuccess ? static_cast<uint8_t*>(p) : nullptr;
-                } else {
-                    e.lz4_pin = g2.ok() ? static_cast<uint8_t*>(host_alloc_on_node(ring_bytes, e.numa_node)) : nullptr;
-                }
-                if (!e.lz4_pin) {
-                    arc = -1;
-                    aerr = last_error_text();
-                }
-            });
-            alloc.join();
-            if (arc) {
+            // Page-locked the quick way (host_alloc_registered: huge pages touched on the GPU's node, then registered): r04's three
+            // hipHostMalloc-ed 64 MiB buffers cost the first call of a process 40-53 ms, this ring 1 ms.
+            DeviceGuard g2(e.device);
+            RegisteredHost r = g2.ok() ? host_alloc_registered(ring_bytes, e.numa_node) : RegisteredHost{};
+            if (!r.ptr) {
                 settle();
-                return fail_again(aerr.c_str(), arc);
+                return -1;
             }
+            e.lz4_pin = static_cast<uint8_t*>(r.ptr);
+            e.lz4_pin_map = r.map;
+            e.lz4_pin_map_bytes = r.map_bytes;
             e.lz4_pin_bytes = ring_bytes;
         }
         for (int i = 0; i < nspans_ring; ++i) pinned[i] = e.lz4_pin + span_cap * static_cast<uint64_t>(i);

@@ -25,6 +25,7 @@ struct FLAGSTATS_hip_stream {
     hipStream_t st[2] = {nullptr, nullptr};
     fsint::Workspace ws[2];
     uint8_t* pinned[3] = {nullptr, nullptr, nullptr};
+    fsint::RegisteredHost pinned_reg[3];   // what they are made of (registered huge pages: opening a session does not wait for hipHostMalloc)
     hipEvent_t copied[3];
     bool have_event[3] = {false, false, false};
     bool in_flight[3] = {false, false, false};
@@ -80,7 +81,8 @@ FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void)
     if (s->cap < (1ull << 20)) s->cap = 1ull << 20;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 3 && e == hipSuccess; ++i) {
-        s->pinned[i] = static_cast<uint8_t*>(fsint::host_alloc_on_node(s->cap, eng->numa_node));
+        s->pinned_reg[i] = fsint::host_alloc_registered(s->cap, eng->numa_node);
+        s->pinned[i] = static_cast<uint8_t*>(s->pinned_reg[i].ptr);
         if (!s->pinned[i]) {
             FLAGSTATS_hip_stream_close(s);
             return nullptr;
@@ -185,7 +187,7 @@ void FLAGSTATS_hip_stream_close(FLAGSTATS_hip_stream* s)
         for (int i = 0; i < 2; ++i)
             if (s->st[i]) (void)hipStreamSynchronize(s->st[i]);
         for (int i = 0; i < 3; ++i) {
-            if (s->pinned[i]) (void)hipHostFree(s->pinned[i]);
+            if (s->pinned[i]) fsint::host_free_registered(s->pinned_reg[i]);
             if (s->have_event[i]) (void)hipEventDestroy(s->copied[i]);
         }
         for (int i = 0; i < 2; ++i) {

@@ -66,6 +66,9 @@ hipError_t hipHostMalloc(void** p, size_t bytes, unsigned flags);
 template <class T>
 static inline hipError_t hipHostMalloc(T** p, size_t bytes, unsigned flags) { return hipHostMalloc(reinterpret_cast<void**>(p), bytes, flags); }
 hipError_t hipHostFree(void* p);
+enum { hipHostRegisterDefault = 0 };
+hipError_t hipHostRegister(void* p, size_t bytes, unsigned flags);
+hipError_t hipHostUnregister(void* p);
 hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes);
 hipError_t hipHostGetDevicePointer(void** dp, void* hp, unsigned flags);
 hipError_t hipPointerGetAttributes(hipPointerAttribute_t* a, const void* p);

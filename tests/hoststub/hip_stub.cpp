@@ -215,6 +215,17 @@ hipError_t hipHostMalloc(void** p, size_t bytes, unsigned)
     remember(*p, bytes, hipMemoryTypeHost);
     return hipSuccess;
 }
+hipError_t hipHostRegister(void* p, size_t bytes, unsigned)
+{
+    if (!p || !bytes) return hipErrorInvalidValue;
+    remember(p, bytes, hipMemoryTypeHost);
+    return hipSuccess;
+}
+hipError_t hipHostUnregister(void* p)
+{
+    std::lock_guard<std::mutex> lk(g_mu);
+    return g_allocs.erase(reinterpret_cast<uintptr_t>(p)) ? hipSuccess : hipErrorInvalidValue;
+}
 hipError_t hipMemGetInfo(size_t* free_bytes, size_t* total_bytes)
 {
     if (free_bytes) *free_bytes = 8ull << 30;
