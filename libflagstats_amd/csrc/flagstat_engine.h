@@ -198,6 +198,7 @@ void* host_alloc_on_node(size_t bytes, int numa_node);   // pinned, pages placed
 // Falls back to host_alloc_on_node.  Release with host_free_registered (the pair keeps no table: the owner remembers `bytes`).
 RegisteredHost host_alloc_registered(size_t bytes, int numa_node);   // ptr == nullptr on failure (error recorded)
 void host_free_registered(RegisteredHost& r);
+extern thread_local double g_reg_times[4];   // the last host_alloc_registered's phases in ms (diagnostics)
 uint64_t chunk_bytes();
 // CPUs of host NUMA node `node` inside the calling process's own affinity mask (flagstat_blocks.hip); false: unknown / none
 bool node_cpuset(int node, cpu_set_t* set);

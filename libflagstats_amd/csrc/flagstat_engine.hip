@@ -199,16 +199,22 @@ int engine_setup(Engine& e, int device)
         // A stream costs 7-10 ms to make (a hardware queue; profiles/r05/file_h2d.log: two in 14.5-21 ms) and a one-shot process
         // pays for both before its first call: the second one is made on a helper thread beside the first and the small
         // allocations.
+        // The same thread then uses its stream once for a fill and a small copy from pageable memory: the runtime loads its own
+        // fill / copy kernels at their first use (~12 ms, which the first call of a process otherwise pays in line:
+        // profiles/r05/cold_start.log).
         hipError_t err1 = hipSuccess;
         std::thread second([&] {
             err1 = hipSetDevice(device);
             if (err1 == hipSuccess) err1 = hipStreamCreateWithFlags(&e.stream[1], hipStreamNonBlocking);
+            if (err1 == hipSuccess) err1 = hipMalloc(&e.d_out[1], 4096);
+            uint64_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (err1 == hipSuccess) err1 = hipMemsetAsync(e.d_out[1], 0, 4096, e.stream[1]);
+            if (err1 == hipSuccess) err1 = hipMemcpyAsync(e.d_out[1], zeros, sizeof zeros, hipMemcpyHostToDevice, e.stream[1]);
+            if (err1 == hipSuccess) err1 = hipStreamSynchronize(e.stream[1]);
         });
         hipError_t err0 = hipStreamCreateWithFlags(&e.stream[0], hipStreamNonBlocking);
-        for (int i = 0; i < 2 && err0 == hipSuccess; ++i) {
-            err0 = hipMalloc(&e.d_out[i], 4096);  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
-            if (err0 == hipSuccess) err0 = hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming);
-        }
+        if (err0 == hipSuccess) err0 = hipMalloc(&e.d_out[0], 4096);  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
+        for (int i = 0; i < 2 && err0 == hipSuccess; ++i) err0 = hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming);
         second.join();
         if (err0 != hipSuccess) return fail_hip("engine creation: stream / counters / events", err0);
         if (err1 != hipSuccess) return fail_hip("engine creation: second stream", err1);
@@ -703,9 +709,15 @@ void* host_alloc_on_node(size_t bytes, int numa_node)
     return p;
 }
 
+thread_local double g_reg_times[4] = {0, 0, 0, 0};   // last host_alloc_registered: mmap + madvise, first touch, hipHostRegister, fallback (ms; tests/perf)
+
 RegisteredHost host_alloc_registered(size_t bytes, int numa_node)
 {
     RegisteredHost r;
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t0 = clk::now();
+    auto since = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+    g_reg_times[0] = g_reg_times[1] = g_reg_times[2] = g_reg_times[3] = 0;
     if (!bytes) bytes = 1;
     const char* k = std::getenv("FLAGSTATS_HIP_HOST_ALLOC");   // (A/B: "malloc" = always hipHostMalloc)
     const size_t huge = 2u << 20;
@@ -716,6 +728,8 @@ RegisteredHost host_alloc_registered(size_t bytes, int numa_node)
 #ifdef MADV_HUGEPAGE
         (void)madvise(base, len, MADV_HUGEPAGE);   // (refused where huge pages are off: 4 KiB pages then, still 5x quicker than hipHostMalloc)
 #endif
+        g_reg_times[0] = since(t0);
+        const clk::time_point t1 = clk::now();
         // first touch = placement: by threads on the node's CPUs, a slice each
         cpu_set_t cpus;
         const bool bind = g_knobs.numa.load() && node_cpuset(numa_node, &cpus);
@@ -729,7 +743,11 @@ RegisteredHost host_alloc_registered(size_t bytes, int numa_node)
         std::vector<std::thread> pool;
         for (int t = 0; t < nthr; ++t) pool.emplace_back(touch, t);   // (also for one thread: the CALLER's affinity stays as it is)
         for (std::thread& t : pool) t.join();
-        if (hipHostRegister(base, len, hipHostRegisterDefault) == hipSuccess) {
+        g_reg_times[1] = since(t1);
+        const clk::time_point t2 = clk::now();
+        const hipError_t reg = hipHostRegister(base, len, hipHostRegisterDefault);
+        g_reg_times[2] = since(t2);
+        if (reg == hipSuccess) {
             r.ptr = base;
             r.map = map;
             r.map_bytes = len + huge;
@@ -738,7 +756,9 @@ RegisteredHost host_alloc_registered(size_t bytes, int numa_node)
         (void)hipGetLastError();
         munmap(map, len + huge);
     }
+    const clk::time_point t3 = clk::now();
     r.ptr = host_alloc_on_node(bytes, numa_node);
+    g_reg_times[3] = since(t3);
     return r;
 }
 

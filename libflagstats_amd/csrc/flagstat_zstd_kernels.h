@@ -12,7 +12,8 @@
 
 namespace fsk {
 
-constexpr uint32_t kZstdMaxBlocks = 256;        // Zstandard blocks per frame the GPU decoder takes (more: status kZstdTooManyBlocks)
+constexpr uint32_t kZstdMaxBlocks = 256;        // Zstandard blocks per frame the scratch of a first pass holds at most (more: status kZstdTooManyBlocks)
+constexpr uint32_t kZstdMaxBlocksRetry = 4096;  // ... and of the second pass the host makes over frames that ran out (fsk_zstd_decode_ex)
 constexpr uint32_t kZstdMaxFrameBytes = 1u << 26;  // decoded bytes per frame it takes
 constexpr int kZstdTallyWords = 32;             // unsigned long long words of the tally the kernels add to
 // Waves per role of the execution kernel: 4 emit + 3 scan + 1 copy = EIGHT waves, two per SIMD, so that a CU holds as many
@@ -78,6 +79,12 @@ uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes);
 hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
                            unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int prof,
                            hipStream_t stream);
+// The same with room for at least `min_blocks` Zstandard blocks per frame (capped at kZstdMaxBlocksRetry): the second pass over
+// the frames a first pass answered with kZstdTooManyBlocks (windows of a few KiB, streaming compressors that flush often).
+uint64_t fsk_zstd_scratch_bytes_ex(uint32_t max_dst_len, uint32_t nframes, uint32_t min_blocks);
+hipError_t fsk_zstd_decode_ex(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
+                              unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, uint32_t min_blocks, int prof,
+                              hipStream_t stream);
 // waves per role of the execution kernel in this build
 void fsk_zstd_role_waves(int* emitters, int* scanners);
 // workgroups of the execution kernel one CU holds at once (the runtime's occupancy query, which counts registers and LDS per CU

@@ -61,14 +61,16 @@ struct ZBlk {  // one Zstandard block, between the kernels
     uint32_t chain_err;                // zstd_chain: 0 or a status code
     uint32_t nrec, out_len, out_at, n_sym, hist_known, hist[3];   // zstd_records
 };
-static inline ZLayout zstd_layout(uint32_t max_dst_len, uint32_t nframes)
+static inline ZLayout zstd_layout(uint32_t max_dst_len, uint32_t nframes, uint32_t min_blocks = 0)
 {
     ZLayout y;
     y.nframes = nframes;
     // blocks per frame the scratch holds tables for: four times what 128 KiB blocks need (compressors that split blocks), and
-    // some (more: kZstdTooManyBlocks)
+    // some (more: kZstdTooManyBlocks; the host then decodes those frames once more with `min_blocks` = what a frame of 1 KiB
+    // blocks -- the smallest window the format allows -- needs: 3.5 KB of tables a block are not reserved for every frame)
     y.blk_cap = 4u * ((max_dst_len + 131071u) / 131072u) + 8u;
     if (y.blk_cap > kZstdMaxBlocks) y.blk_cap = kZstdMaxBlocks;
+    if (min_blocks > y.blk_cap) y.blk_cap = min_blocks < kZstdMaxBlocksRetry ? min_blocks : kZstdMaxBlocksRetry;
     // records: a sequence makes at least three bytes; per block up to 95 more (split runs, the literals behind the last
     // sequence, rounding to whole batches of 64)
     y.rec_stride = ((max_dst_len / 3u + 64u) & ~63u) + 96u * y.blk_cap;
@@ -247,26 +249,103 @@ __device__ bool fse_build(uint32_t* table, int16_t* counts, uint32_t nsym, uint3
     return true;
 }
 
-// One of the three sequence tables of a block from its source (mode << 28 | position).  Returns the accuracy log, or ~0.
-template <class XB>
-__device__ uint32_t seq_table(const uint8_t* frame, uint32_t limit, uint32_t src, uint32_t* table, int16_t* counts, const int8_t* dflt, uint32_t dflt_n,
-                              uint32_t dflt_log, uint32_t max_symbol, uint32_t max_log, XB xbits)
+// One of the three sequence tables of a block, first half: its symbol counts from the table's source (mode << 28 | position)
+// into `counts` (LDS, 64 entries).  One lane, serial (a description is a chain of variable-length fields).  Returns
+// log | nsym << 8, for an RLE table 0x10000 | symbol << 24, or ~0 for a damaged description.
+__device__ uint32_t seq_counts(const uint8_t* frame, uint32_t limit, uint32_t src, int16_t* counts, const int8_t* dflt, uint32_t dflt_n, uint32_t dflt_log,
+                               uint32_t max_symbol, uint32_t max_log)
 {
     const uint32_t mode = src >> 28, at = src & 0xFFFFFFFu;
     if (mode == 0u) {
         _Pragma("unroll 1") for (uint32_t s = 0; s < dflt_n; ++s) counts[s] = dflt[s];
-        return fse_build(table, counts, dflt_n, dflt_log, xbits) ? dflt_log : ~0u;
+        return dflt_log | (dflt_n << 8);
     }
     if (mode == 1u) {
         if (at >= limit) return ~0u;
         const uint32_t sym = frame[at];
         if (sym > max_symbol) return ~0u;
-        table[0] = sym | (xbits(sym) << 10);
-        return 0u;
+        return 0x10000u | (sym << 24);
     }
     uint32_t log, after;
     if (!fse_read_counts(frame, at, limit, max_symbol, max_log, counts, log, after)) return ~0u;
-    return fse_build(table, counts, max_symbol + 1u, log, xbits) ? log : ~0u;
+    return log | ((max_symbol + 1u) << 8);
+}
+
+// ... second half: counts -> the table as the other kernels read it, by the WHOLE WAVE (RFC 8878 4.1.1, restated so that no cell
+// waits for another).  r04 built the tables a lane per block (8 of 64 lanes busy, three serial passes of dependent LDS round trips
+// per table: 0.96 M of the kernel's 1.66 M cycles).  Here, for a table of S = 2^log cells:
+//   * the "less than one" symbols take the top cells, in symbol order downwards; `high` is the last cell below them;
+//   * the spread visits cell (k * step) mod S at step k and skips the top cells, so cell u is visited at k(u) = u * step^-1 mod S
+//     (step is odd: the inverse exists) and receives slot i = k - (number of skipped visits before k); slot i belongs to the symbol
+//     whose run of `count` slots covers it: run starts as markers, a max-scan over the slots fills the runs;
+//   * a symbol's cells get the state numbers count, count + 1, ... in order of u: cells are taken 64 at a time in order of u, a cell's
+//     number is its symbol's running count (kept in the symbol's own lane) plus its rank among the group's cells of that symbol.
+// Written straight out: out16[u] = number | extra bits << 10 (the bits a state reads are log - highbit(number), its base
+// (number << bits) - S), outsym[u] = symbol.  `scratch` = 640 bytes of LDS.  `xb` = extra bits of the symbol whose number is the
+// lane's.  Returns false for counts that do not fill the table.
+__device__ bool fse_build_wave(const int16_t* counts, uint32_t nsym, uint32_t log, uint32_t lane, uint32_t xb, uint16_t* __restrict__ out16,
+                               uint8_t* __restrict__ outsym, uint8_t* scratch)
+{
+    const uint32_t S = 1u << log, mask = S - 1u;
+    uint8_t* const slotsym = scratch;          // [S <= 512]
+    uint8_t* const lowlist = scratch + 512;    // [<= 64]
+    const int32_t c = lane < nsym ? counts[lane] : 0;
+    const bool is_low = c == -1;
+    const uint32_t n_s = c > 0 ? static_cast<uint32_t>(c) : 0u;
+    const unsigned long long lowmask = __builtin_amdgcn_ballot_w64(is_low);
+    const uint32_t nlow = static_cast<uint32_t>(__builtin_popcountll(lowmask));
+    if (nlow >= S) return false;
+    const uint32_t high = S - 1u - nlow;
+    const uint32_t incl = wave_scan_add(n_s), cum = incl - n_s;
+    if (__builtin_amdgcn_readlane(incl, 63) != high + 1u) return false;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t i = lane; i < S; i += 64u) slotsym[i] = 0u;
+    __syncthreads();   // (one wave: orders the LDS stores above before the ones below)
+    if (n_s) slotsym[cum] = static_cast<uint8_t>(lane + 1u);
+    if (is_low) lowlist[__builtin_popcountll(lowmask & below)] = static_cast<uint8_t>(lane);
+    __syncthreads();
+    uint32_t carry = 0;
+    for (uint32_t base = 0; base < S; base += 64u) {
+        uint32_t v = base + lane < S ? slotsym[base + lane] : 0u;
+        v = wave_scan_max(v);
+        v = v > carry ? v : carry;
+        carry = __builtin_amdgcn_readlane(v, 63);
+        if (base + lane < S) slotsym[base + lane] = static_cast<uint8_t>(v);
+    }
+    __syncthreads();
+    const uint32_t step = (S >> 1) + (S >> 3) + 3u;
+    uint32_t inv = step;   // Newton: the number of correct low bits doubles every round (3 -> 6 -> 12)
+    inv *= 2u - step * inv;
+    inv *= 2u - step * inv;
+    inv *= 2u - step * inv;
+    const uint32_t skipk = ((S - 1u - lane) * inv) & mask;   // lane r < nlow: the visit that would have hit the r-th top cell
+    uint32_t run = n_s;                                        // lane s: the next state number of symbol s
+    for (uint32_t base = 0; base < S; base += 64u) {
+        const uint32_t u = base + lane;
+        const bool valid = u < S, normal = valid && u <= high;
+        uint32_t sym = 0, x = 1u;
+        if (valid && !normal) sym = lowlist[S - 1u - u];
+        const uint32_t k = (u * inv) & mask;
+        uint32_t skipped = 0;
+        _Pragma("unroll 1") for (uint32_t r = 0; r < nlow; ++r) skipped += __builtin_amdgcn_readlane(skipk, r) < k ? 1u : 0u;
+        if (normal) sym = static_cast<uint32_t>(slotsym[(k - skipped) & mask]) - 1u;
+        unsigned long long todo = __builtin_amdgcn_ballot_w64(normal);
+        _Pragma("unroll 1") while (todo) {
+            const uint32_t s0 = __builtin_amdgcn_readlane(sym, static_cast<uint32_t>(__builtin_ctzll(todo)));
+            const unsigned long long m = __builtin_amdgcn_ballot_w64(normal && sym == s0);
+            const uint32_t first = __builtin_amdgcn_readlane(run, s0 & 63u);
+            if (normal && sym == s0) x = first + static_cast<uint32_t>(__builtin_popcountll(m & below));
+            if (lane == s0) run += static_cast<uint32_t>(__builtin_popcountll(m));
+            todo &= ~m;
+        }
+        const uint32_t xbs = __shfl(xb, static_cast<int>(sym & 63u));
+        if (valid) {
+            out16[u] = static_cast<uint16_t>(x | (xbs << 10));
+            if (outsym) outsym[u] = static_cast<uint8_t>(sym);
+        }
+    }
+    __syncthreads();   // (the scratch may be reused at once)
+    return true;
 }
 
 // Huffman tree description at `at` (RFC 8878 4.2.1) -> table in LDS; returns max bits (0 on failure), position behind it.
@@ -720,34 +799,59 @@ __global__ __launch_bounds__(64) void zstd_prepare(const uint8_t* __restrict__ c
         const unsigned long long t1 = PROF ? __builtin_readcyclecounter() : 0ull;
         uint32_t logl = 0, logo = 0, logm = 0;
         bool seq_act = mine && my_type == 2u && nseq > 0u && !lerr;
-        // One table at a time, built in the lane's LDS area and sent off at once: to the chain kernel as next-state number | extra
-        // bits << 10 (the bits of the next state are log - highbit(number), its base (number << bits) - size), to the records
-        // kernel the symbols.
+        // (1) a lane per block: the symbol counts of its three tables into the lane's own LDS area (the Huffman table that lay there
+        // has done its work); (2) the whole wave builds table after table, block after block (fse_build_wave), and sends them off
+        // at once: to the chain kernel next-state number | extra bits << 10, to the records kernel the symbols.
+        uint32_t info[3] = {~0u, ~0u, ~0u};
         if (seq_act) {
-            uint32_t* const work = L.tab[lane].fse;
-            uint8_t* const tg = tabs + static_cast<uint64_t>(nblk - nb + lane) * kTabBytes;
-            uint16_t* const t16 = reinterpret_cast<uint16_t*>(tg);
-            auto emit = [&](uint32_t log, uint32_t at16, uint32_t sym_at) {
-                const uint32_t size = 1u << log;
-                _Pragma("unroll 1") for (uint32_t u = 0; u < size; ++u) {
-                    const uint32_t e = work[u];
-                    const uint32_t nbits = (e >> 6) & 15u;
-                    t16[at16 + u] = static_cast<uint16_t>((((e >> 16) + size) >> nbits) | (((e >> 10) & 31u) << 10));
-                    if (sym_at) tg[sym_at + u] = static_cast<uint8_t>(e & 63u);
-                }
-            };
-            logl = seq_table(frame, n, tab_src[0], work, L.counts[lane], kLLDefault, 36u, 6u, 35u, 9u, [](uint32_t s) { return s < 36u ? static_cast<uint32_t>(kLLBits[s]) : 0u; });
-            if (logl != ~0u) emit(logl, 0u, kTabSymLL);
-            logo = seq_table(frame, n, tab_src[1], work, L.counts[lane], kOFDefault, 29u, 5u, 31u, 8u, [](uint32_t s) { return s; });
-            if (logo != ~0u) emit(logo, kTabOF / 2u, 0u);
-            logm = seq_table(frame, n, tab_src[2], work, L.counts[lane], kMLDefault, 53u, 6u, 52u, 9u, [](uint32_t s) { return s < 53u ? static_cast<uint32_t>(kMLBits[s]) : 0u; });
-            if (logm != ~0u) emit(logm, kTabML / 2u, kTabSymML);
-            if (logl == ~0u || logo == ~0u || logm == ~0u) {
+            int16_t* const cnt = reinterpret_cast<int16_t*>(L.tab[lane].huf);
+            info[0] = seq_counts(frame, n, tab_src[0], cnt, kLLDefault, 36u, 6u, 35u, 9u);
+            info[1] = seq_counts(frame, n, tab_src[1], cnt + 64, kOFDefault, 29u, 5u, 31u, 8u);
+            info[2] = seq_counts(frame, n, tab_src[2], cnt + 128, kMLDefault, 53u, 6u, 52u, 9u);
+            if (info[0] == ~0u || info[1] == ~0u || info[2] == ~0u) {
                 lerr = kZstdBadSequences;
                 seq_act = false;
             } else if (bend <= bits_at || frame[bend - 1u] == 0u) {
                 lerr = kZstdBadBitstream;
                 seq_act = false;
+            }
+        }
+        __syncthreads();
+        {
+            // extra bits of the symbol whose number is the lane's, per table
+            const uint32_t xb_t[3] = {lane < 36u ? static_cast<uint32_t>(kLLBits[lane]) : 0u, lane, lane < 53u ? static_cast<uint32_t>(kMLBits[lane]) : 0u};
+            const uint32_t at16[3] = {0u, kTabOF / 2u, kTabML / 2u}, sym_at[3] = {kTabSymLL, 0u, kTabSymML};
+            const unsigned long long act = __builtin_amdgcn_ballot_w64(seq_act);
+            bool built = true;
+            for (uint32_t j = 0; j < nb; ++j) {
+                if (!((act >> j) & 1ull)) continue;
+                uint8_t* const tg = tabs + static_cast<uint64_t>(nblk - nb + j) * kTabBytes;
+                uint16_t* const t16 = reinterpret_cast<uint16_t*>(tg);
+                uint8_t* const area = reinterpret_cast<uint8_t*>(L.tab[j].huf);
+                for (uint32_t t = 0; t < 3u; ++t) {
+                    const uint32_t inf = __builtin_amdgcn_readlane(info[t], j);
+                    if (inf & 0x10000u) {   // one symbol: a table of one cell
+                        const uint32_t sym = inf >> 24;
+                        const uint32_t xbs = t == 0u ? (sym < 36u ? kLLBits[sym] : 0u) : (t == 1u ? sym : (sym < 53u ? kMLBits[sym] : 0u));
+                        if (lane == 0u) {
+                            t16[at16[t]] = static_cast<uint16_t>(1u | (xbs << 10));
+                            if (sym_at[t]) tg[sym_at[t]] = static_cast<uint8_t>(sym);
+                        }
+                        if (lane == j) info[t] = 0u;   // (its accuracy log)
+                        continue;
+                    }
+                    const bool ok = fse_build_wave(reinterpret_cast<const int16_t*>(area) + 64u * t, (inf >> 8) & 255u, inf & 255u, lane, xb_t[t], t16 + at16[t],
+                                                   sym_at[t] ? tg + sym_at[t] : nullptr, area + 512u);
+                    built = built && ok;
+                    if (lane == j) info[t] &= 255u;
+                }
+            }
+            if (!built && !lerr && seq_act) lerr = kZstdBadSequences;   // (`built` is uniform: every active lane of a pass reports)
+            if (!built) seq_act = false;
+            if (seq_act) {
+                logl = info[0];
+                logo = info[1];
+                logm = info[2];
             }
         }
         if (PROF) t_tab += __builtin_readcyclecounter() - t1;
@@ -1669,14 +1773,25 @@ __global__ __launch_bounds__(kZxThreads, FLAGSTAT_ZSTD_EXEC_WAVES_PER_SIMD) void
 }  // namespace fsk
 
 extern "C" uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes) { return fsk::zstd_layout(max_dst_len, nframes).total; }
+extern "C" uint64_t fsk_zstd_scratch_bytes_ex(uint32_t max_dst_len, uint32_t nframes, uint32_t min_blocks)
+{
+    return fsk::zstd_layout(max_dst_len, nframes, min_blocks).total;
+}
 
 extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
                                       unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int prof, hipStream_t stream)
 {
+    return fsk_zstd_decode_ex(comp, blocks, nblocks, out, status, tally, scratch, scratch_bytes, max_dst_len, 0u, prof, stream);
+}
+
+extern "C" hipError_t fsk_zstd_decode_ex(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
+                                         unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, uint32_t min_blocks, int prof,
+                                         hipStream_t stream)
+{
     if (nblocks == 0) return hipSuccess;
     if (!comp || !blocks || !out || !status || !tally || !scratch) return hipErrorInvalidValue;
     if ((reinterpret_cast<uintptr_t>(comp) & 7u) || (reinterpret_cast<uintptr_t>(scratch) & 255u)) return hipErrorInvalidValue;
-    const fsk::ZLayout lay = fsk::zstd_layout(max_dst_len, nblocks);
+    const fsk::ZLayout lay = fsk::zstd_layout(max_dst_len, nblocks, min_blocks);
     if (lay.total > scratch_bytes) return hipErrorInvalidValue;
     uint8_t* const sc = static_cast<uint8_t*>(scratch);
     const dim3 grid(nblocks);

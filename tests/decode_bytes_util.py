@@ -33,15 +33,21 @@ def _protos(lib):
     lib.fsk_zstd_decode.restype = ctypes.c_int
     lib.fsk_zstd_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
                                     ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    lib.fsk_zstd_scratch_bytes_ex.restype = ctypes.c_uint64
+    lib.fsk_zstd_scratch_bytes_ex.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
+    lib.fsk_zstd_decode_ex.restype = ctypes.c_int
+    lib.fsk_zstd_decode_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
     lib._fsk_protos = True
 
 
 class DeviceDecode:
     """One launch of a decode kernel over `payloads` (compressed bytes) with declared decoded `sizes`; the decoded buffer
     stays on the device until free() so that further device entries (pospopcnt, K1) can run on what the decoder wrote.
-    codec: "lz4" (kernel 0 = the workgroup pipeline, 1 = one wave per block) or "zstd"."""
+    codec: "lz4" (kernel 0 = the workgroup pipeline, 1 = one wave per block) or "zstd" (min_blocks > 0: the second-pass entry
+    fsk_zstd_decode_ex, with room for that many Zstandard blocks per frame)."""
 
-    def __init__(self, lib, codec, payloads, sizes, kernel=0):
+    def __init__(self, lib, codec, payloads, sizes, kernel=0, min_blocks=0):
         from libflagstats_amd import _lib
         _protos(lib)
         self.lib, self._check = lib, _lib.check
@@ -65,9 +71,12 @@ class DeviceDecode:
         self.d_tally = self._up(bytes(8 * 32))
         if codec == "zstd":
             mx = max(self.sizes) if n else 0
-            need = lib.fsk_zstd_scratch_bytes(mx, n)
+            need = lib.fsk_zstd_scratch_bytes_ex(mx, n, min_blocks)
             d_scratch = self._alloc(need + 256)
-            rc = lib.fsk_zstd_decode(self.d_comp, self.d_blocks, n, self.d_out, self.d_status, self.d_tally, (d_scratch + 255) & ~255, need, mx, 0, None)
+            if min_blocks:
+                rc = lib.fsk_zstd_decode_ex(self.d_comp, self.d_blocks, n, self.d_out, self.d_status, self.d_tally, (d_scratch + 255) & ~255, need, mx, min_blocks, 0, None)
+            else:
+                rc = lib.fsk_zstd_decode(self.d_comp, self.d_blocks, n, self.d_out, self.d_status, self.d_tally, (d_scratch + 255) & ~255, need, mx, 0, None)
         else:
             rc = lib.fsk_lz4_decode(kernel, self.d_comp, self.d_blocks, n, self.d_out, self.d_status, self.d_tally, 0, None)
         if rc:

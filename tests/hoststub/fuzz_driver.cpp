@@ -125,6 +125,42 @@ static Block make_zstd_block(size_t target)
     return b;
 }
 
+// ... and frames of MANY small blocks: a streaming compressor flushing every `every` bytes (>= 1024: a block per KiB is what the
+// GPU decoder's second pass has room for; the first pass answers kZstdTooManyBlocks)
+struct ZBuf {
+    void* p;
+    size_t size, pos;
+};
+typedef void* (*zcreate_fn)(void);
+typedef size_t (*zfree_fn)(void*);
+typedef size_t (*zstream2_fn)(void*, ZBuf*, ZBuf*, int);
+static zcreate_fn z_create = nullptr;
+static zfree_fn z_free = nullptr;
+static zstream2_fn z_stream2 = nullptr;
+
+static Block make_zstd_block_flushed(size_t target, size_t every)
+{
+    Block b = make_zstd_block(target);
+    if (!z_create || !z_free || !z_stream2 || target == 0) return b;
+    void* cctx = z_create();
+    b.payload.assign(target + target / every * 32 + 1024, 0);
+    ZBuf ob{b.payload.data(), b.payload.size(), 0};
+    for (size_t at = 0; at < target;) {
+        const size_t n = every < target - at ? every : target - at;
+        ZBuf ib{b.decoded.data() + at, n, 0};
+        const bool last = at + n == target;
+        for (;;) {
+            const size_t left = z_stream2(cctx, &ob, &ib, last ? 2 : 1);   // ZSTD_e_end / ZSTD_e_flush
+            if (z_iserr(left)) std::exit(4);
+            if (left == 0 && ib.pos == ib.size) break;
+        }
+        at += n;
+    }
+    z_free(cctx);
+    b.payload.resize(ob.pos);
+    return b;
+}
+
 static void put32(Bytes& img, int32_t v)
 {
     const unsigned char* p = reinterpret_cast<const unsigned char*>(&v);
@@ -370,6 +406,9 @@ int main(int argc, char** argv)
         z_compress = reinterpret_cast<zcompress_fn>(dlsym(h, "ZSTD_compress"));
         z_bound = reinterpret_cast<zbound_fn>(dlsym(h, "ZSTD_compressBound"));
         z_iserr = reinterpret_cast<ziserr_fn>(dlsym(h, "ZSTD_isError"));
+        z_create = reinterpret_cast<zcreate_fn>(dlsym(h, "ZSTD_createCCtx"));
+        z_free = reinterpret_cast<zfree_fn>(dlsym(h, "ZSTD_freeCCtx"));
+        z_stream2 = reinterpret_cast<zstream2_fn>(dlsym(h, "ZSTD_compressStream2"));
     }
     const bool have_zstd = z_compress && z_bound && z_iserr && FLAGSTATS_hip_zstd_available();
     setenv("FLAGSTATS_HIP_GPU_BUFFER_GRAIN", "16", 1);   // exact-size "device" buffers: an access behind them is a report
@@ -386,7 +425,12 @@ int main(int argc, char** argv)
     static const size_t sizes[] = {0, 1, 2, 15, 16, 17, 100, 1000, 4097, 30000};
     std::vector<Block> zpool;   // Zstandard frames are made once (compression is what costs here): inputs differ by which they take and by the damage
     if (have_zstd)
-        for (int i = 0; i < 400; ++i) zpool.push_back(make_zstd_block(i % 40 == 0 ? 70000 + below(80000) : sizes[below(sizeof sizes / sizeof sizes[0])] + below(40)));
+        for (int i = 0; i < 400; ++i) {
+            if (i % 25 == 7)
+                zpool.push_back(make_zstd_block_flushed(20000 + below(60000), 1024 + below(1500)));   // 10-80 blocks a frame: the second pass
+            else
+                zpool.push_back(make_zstd_block(i % 40 == 0 ? 70000 + below(80000) : sizes[below(sizeof sizes / sizeof sizes[0])] + below(40)));
+        }
     long calls = 0, n_valid = 0, n_lz4 = 0, n_zstd = 0, n_text = 0, n_raw = 0, n_golden = 0;
     for (long i = 0; i < inputs; ++i) {
         uint64_t what = below(100);

@@ -538,12 +538,46 @@ extern "C" int fsk_lz4_blocks_per_cu(int) { return 2; }
 
 #include "../../libflagstats_amd/csrc/flagstat_zstd_kernels.h"
 
-extern "C" uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes) { return 4096 + (static_cast<uint64_t>(max_dst_len) / 64 + 64) * nframes; }
-extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
-                                      unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int, hipStream_t stream)
+// (like the kernels: a first pass has table slots for 4 blocks per 128 KiB + 8, a second pass -- _ex with min_blocks -- for more;
+// a frame with more Zstandard blocks than that answers kZstdTooManyBlocks, so the host's second pass runs in the sanitizer builds)
+static uint32_t stub_blk_cap(uint32_t max_dst_len, uint32_t min_blocks)
 {
+    uint32_t cap = 4u * ((max_dst_len + 131071u) / 131072u) + 8u;
+    if (cap > fsk::kZstdMaxBlocks) cap = fsk::kZstdMaxBlocks;
+    if (min_blocks > cap) cap = min_blocks < fsk::kZstdMaxBlocksRetry ? min_blocks : fsk::kZstdMaxBlocksRetry;
+    return cap;
+}
+static uint32_t stub_count_zstd_blocks(const uint8_t* f, uint32_t n)
+{
+    if (n < 6 || f[0] != 0x28 || f[1] != 0xB5 || f[2] != 0x2F || f[3] != 0xFD) return 0;
+    const uint32_t fhd = f[4], single = (fhd >> 5) & 1u, fcs_flag = fhd >> 6, did = fhd & 3u;
+    uint32_t p = 5u + (single ? 0u : 1u) + (did == 3u ? 4u : did) + (fcs_flag == 0u ? single : (1u << fcs_flag));
+    uint32_t count = 0;
+    while (p + 3u <= n) {
+        const uint32_t bh = f[p] | (f[p + 1] << 8) | (static_cast<uint32_t>(f[p + 2]) << 16);
+        ++count;
+        p += 3u + (((bh >> 1) & 3u) == 1u ? 1u : (bh >> 3));
+        if (bh & 1u) break;
+    }
+    return count;
+}
+extern "C" uint64_t fsk_zstd_scratch_bytes_ex(uint32_t max_dst_len, uint32_t nframes, uint32_t min_blocks)
+{
+    return 4096 + (static_cast<uint64_t>(max_dst_len) / 64 + 64 + stub_blk_cap(max_dst_len, min_blocks)) * nframes;
+}
+extern "C" uint64_t fsk_zstd_scratch_bytes(uint32_t max_dst_len, uint32_t nframes) { return fsk_zstd_scratch_bytes_ex(max_dst_len, nframes, 0u); }
+extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
+                                      unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, int prof, hipStream_t stream)
+{
+    return fsk_zstd_decode_ex(comp, blocks, nblocks, out, status, tally, scratch, scratch_bytes, max_dst_len, 0u, prof, stream);
+}
+extern "C" hipError_t fsk_zstd_decode_ex(const uint8_t* comp, const fsk::GpuBlock* blocks, uint32_t nblocks, uint8_t* out, uint32_t* status,
+                                         unsigned long long* tally, void* scratch, uint64_t scratch_bytes, uint32_t max_dst_len, uint32_t min_blocks, int,
+                                         hipStream_t stream)
+{
+    const uint32_t blk_cap = stub_blk_cap(max_dst_len, min_blocks);
     if (nblocks == 0) return hipSuccess;
-    if (!comp || !blocks || !out || !status || !tally || !scratch || scratch_bytes < fsk_zstd_scratch_bytes(max_dst_len, nblocks)) return hipErrorInvalidValue;
+    if (!comp || !blocks || !out || !status || !tally || !scratch || scratch_bytes < fsk_zstd_scratch_bytes_ex(max_dst_len, nblocks, min_blocks)) return hipErrorInvalidValue;
     typedef size_t (*decompress_fn)(void*, size_t, const void*, size_t);
     typedef unsigned (*is_error_fn)(size_t);
     static void* handle = dlopen("libzstd.so.1", RTLD_NOW | RTLD_LOCAL);
@@ -554,6 +588,10 @@ extern "C" hipError_t fsk_zstd_decode(const uint8_t* comp, const fsk::GpuBlock* 
         uint8_t* sc = static_cast<uint8_t*>(scratch);
         for (uint32_t i = 0; i < nblocks; ++i) {
             const fsk::GpuBlock b = blocks[i];
+            if (stub_count_zstd_blocks(comp + b.src_off, b.src_len) > blk_cap) {
+                status[i] = fsk::kZstdTooManyBlocks;
+                continue;
+            }
             std::vector<uint8_t> tmp(b.dst_len + 64);
             const size_t got = decompress(tmp.data(), b.dst_len, comp + b.src_off, b.src_len);
             sc[i & 4095u] = static_cast<uint8_t>(i);  // (the scratch is written by the launch: a use-after-release shows under TSan)

@@ -50,6 +50,7 @@ def spawn_oneshot(mode, arg, calls=3, env_extra=None):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     d["process_ms"] = (t_exit - t_spawn) * 1e-6
     d["phases"] = [ln for ln in r.stderr.splitlines() if ln.startswith("gpu decode, host side")]
+    d["ring"] = [ln for ln in r.stderr.splitlines() if ln.startswith("gpu decode, pinned ring")]
     d["init_phases"] = [ln for ln in r.stderr.splitlines() if ln.startswith("engine creation")]
     return d
 
@@ -76,6 +77,8 @@ def report(name, samples, n_flags, ref_note=""):
         print("    " + typical["init_phases"][0], flush=True)
     if typical["phases"]:
         print("    first call (the median sample), " + typical["phases"][0], flush=True)
+        if typical.get("ring"):
+            print("    " + typical["ring"][0], flush=True)
         if len(typical["phases"]) > 1:
             print("    second call, " + typical["phases"][1], flush=True)
     if slowest is not typical and slowest["calls_ms"][0] > 1.5 * med(first) and slowest["phases"]:

@@ -38,7 +38,7 @@ def main():
     lib = _lib.lib()
     _lib.check(lib.FLAGSTATS_hip_init(0), "init")
     z = bt.zstd()
-    exact = wrong = unsupported = 0
+    exact = wrong = unsupported = second_pass = 0
     both_ok = both_fail = strict = lenient = differ = 0
     batch = 50
     for s0 in range(args.first, args.first + args.seeds, batch):
@@ -60,6 +60,14 @@ def main():
                 bad_sizes.append(len(raw))
                 wants.append(ref_decode(z, bad, len(raw)))
         got, st, _, _ = decode_frames(lib, frames, sizes)
+        # the product's second pass: frames that ran out of block slots (status 67) once more with a slot per KiB
+        again = [i for i in range(len(frames)) if st[i] == 67]
+        if again:
+            st = st.copy()
+            g2, s2, _, _ = decode_frames(lib, [frames[i] for i in again], [sizes[i] for i in again], min_blocks=max(sizes[i] for i in again) // 1024 + 16)
+            for k, i in enumerate(again):
+                got[i], st[i] = g2[k], s2[k]
+            second_pass += len(again)
         for i, raw in enumerate(raws):
             even = len(raw) & ~1
             if st[i] == 0 and got[i][:even] == raw[:even]:
@@ -86,8 +94,8 @@ def main():
                 differ += 1
                 print("DIFFER: seed %d (damaged frame %d)" % (s0 + i // 3, i), flush=True)
         print("seeds %d..%d done: %d exact so far" % (s0, min(s0 + batch, args.first + args.seeds) - 1, exact), flush=True)
-    print("%d synthetic frames (a third of them from ZSTD_compress2 with random advanced parameters): %d exact, %d not taken (status >= 64), %d wrong | %d damaged frames: both reject %d, both accept with equal bytes %d, GPU stricter %d, GPU more lenient %d, different bytes %d" % (
-        exact + wrong + unsupported, exact, unsupported, wrong, both_ok + both_fail + strict + lenient + differ, both_fail, both_ok, strict, lenient, differ))
+    print("%d synthetic frames (a third of them from ZSTD_compress2 with random advanced parameters): %d exact (%d of them in the second pass over frames of many blocks), %d not taken (status >= 64), %d wrong | %d damaged frames: both reject %d, both accept with equal bytes %d, GPU stricter %d, GPU more lenient %d, different bytes %d" % (
+        exact + wrong + unsupported, exact, second_pass, unsupported, wrong, both_ok + both_fail + strict + lenient + differ, both_fail, both_ok, strict, lenient, differ))
     return 1 if wrong or lenient or differ else 0
 
 

@@ -22,8 +22,9 @@ class GpuBlock(ctypes.Structure):
     _fields_ = [("src_off", ctypes.c_uint64), ("dst_off", ctypes.c_uint64), ("src_len", ctypes.c_uint32), ("dst_len", ctypes.c_uint32)]
 
 
-def decode_frames(lib, frames, sizes, prof=0, reps=1):
-    """frames: list of bytes, sizes: decoded size of each -> (list of decoded bytes, status array, tally, best kernel ms)"""
+def decode_frames(lib, frames, sizes, prof=0, reps=1, min_blocks=0):
+    """frames: list of bytes, sizes: decoded size of each -> (list of decoded bytes, status array, tally, best kernel ms);
+    min_blocks > 0: the second-pass entry (fsk_zstd_decode_ex: room for that many Zstandard blocks per frame)"""
     n = len(frames)
     blocks = (GpuBlock * n)()
     comp = bytearray(8)
@@ -39,22 +40,22 @@ def decode_frames(lib, frames, sizes, prof=0, reps=1):
     d_out = torch.zeros(dpos + 64, dtype=torch.uint8, device="cuda")
     d_status = torch.full((n,), -1, dtype=torch.int32, device="cuda")
     d_tally = torch.zeros(32, dtype=torch.int64, device="cuda")
-    lib.fsk_zstd_scratch_bytes.restype = ctypes.c_uint64
-    lib.fsk_zstd_scratch_bytes.argtypes = [ctypes.c_uint32, ctypes.c_uint32]
+    lib.fsk_zstd_scratch_bytes_ex.restype = ctypes.c_uint64
+    lib.fsk_zstd_scratch_bytes_ex.argtypes = [ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32]
     mx = max(sizes) if sizes else 0
-    need = lib.fsk_zstd_scratch_bytes(mx, n)
+    need = lib.fsk_zstd_scratch_bytes_ex(mx, n, min_blocks)
     d_scratch = torch.zeros(need + 256, dtype=torch.uint8, device="cuda")
     sp = (d_scratch.data_ptr() + 255) & ~255
-    lib.fsk_zstd_decode.restype = ctypes.c_int
-    lib.fsk_zstd_decode.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
-                                    ctypes.c_uint64, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
+    lib.fsk_zstd_decode_ex.restype = ctypes.c_int
+    lib.fsk_zstd_decode_ex.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p,
+                                       ctypes.c_uint64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p]
     best = 1e9
     for _ in range(reps):
         d_status.fill_(-1)
         d_tally.zero_()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        rc = lib.fsk_zstd_decode(d_comp.data_ptr(), d_blocks.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), d_tally.data_ptr(), sp, need, mx, prof, None)
+        rc = lib.fsk_zstd_decode_ex(d_comp.data_ptr(), d_blocks.data_ptr(), n, d_out.data_ptr(), d_status.data_ptr(), d_tally.data_ptr(), sp, need, mx, min_blocks, prof, None)
         torch.cuda.synchronize()
         best = min(best, (time.perf_counter() - t0) * 1e3)
         if rc:

@@ -222,19 +222,40 @@ def test_zstd_decode_is_byte_exact_on_other_block_sizes(hip, block_bytes):
 
 
 def test_zstd_decode_is_byte_exact_on_frames_of_many_small_blocks(hip):
-    """35 blocks in a frame: taken, byte-exact; 52: refused with the "too many blocks" code, never decoded wrongly"""
+    """35 blocks in a frame: taken at once, byte-exact.  52 blocks, 391 blocks (a 1 KiB window), 1000 blocks: the first-pass entry
+    answers "too many blocks" (never a wrong byte), the second-pass entry (fsk_zstd_decode_ex: a block slot per KiB) decodes them
+    byte for byte."""
+    import ctypes
+
     import oracle
     from zstd_fuzz_gen import flushed_frame
     z = bt.zstd()
     raw = oracle.generate(oracle.GEN_NA12878, 77, 1, 0, 512000).tobytes()
     run_and_compare(hip, "zstd", [(flushed_frame(z, raw, 30000), len(raw)), (flushed_frame(z, raw[:300001], 9000), 300001)], "35 blocks")
-    frame = flushed_frame(z, raw, 20000)
-    assert du.ref_zstd(frame, len(raw)) == raw
-    with du.DeviceDecode(hip, "zstd", [frame], [len(raw)]) as dd:
-        if dd.status[0] == 0:
-            du.check_decoded(dd, 0, raw, "52 blocks")
-        else:
-            assert dd.status[0] == 67, int(dd.status[0])       # kZstdTooManyBlocks: the file goes to libzstd
+    # ZSTD_compress2 with windowLog 10: blocks of 1 KiB
+    z.ZSTD_createCCtx.restype = ctypes.c_void_p
+    z.ZSTD_freeCCtx.argtypes = [ctypes.c_void_p]
+    z.ZSTD_CCtx_setParameter.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int]
+    z.ZSTD_compress2.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t]
+    z.ZSTD_compress2.restype = ctypes.c_size_t
+    cctx = z.ZSTD_createCCtx()
+    z.ZSTD_CCtx_setParameter(cctx, 101, 10)          # ZSTD_c_windowLog
+    small = raw[:400000]
+    dst = ctypes.create_string_buffer(z.ZSTD_compressBound(len(small)))
+    n = z.ZSTD_compress2(cctx, dst, len(dst), small, len(small))
+    z.ZSTD_freeCCtx(cctx)
+    assert not z.ZSTD_isError(n)
+    cases = [("52 blocks", flushed_frame(z, raw, 20000), raw), ("1 KiB window", dst.raw[:n], small), ("1000 blocks", flushed_frame(z, raw, 1024), raw)]
+    for what, frame, want in cases:
+        assert du.ref_zstd(frame, len(want)) == want
+        with du.DeviceDecode(hip, "zstd", [frame], [len(want)]) as dd:
+            if dd.status[0] == 0:
+                du.check_decoded(dd, 0, want, what)
+            else:
+                assert dd.status[0] == 67, (what, int(dd.status[0]))       # kZstdTooManyBlocks
+        with du.DeviceDecode(hip, "zstd", [frame], [len(want)], min_blocks=len(want) // 1024 + 16) as dd:
+            du.check_decoded(dd, 0, want, what + ", second pass")
+            assert np.array_equal(dd.pospopcnt(0), du.pospopcnt_ref(want))
 
 
 def zstd_fuzz_slice(hip, first, count, batch=50):

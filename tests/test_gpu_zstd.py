@@ -308,9 +308,11 @@ def test_gpu_zstd_decoder_keeps_and_releases_its_device_memory(zgpu):
 
 
 def test_gpu_zstd_decoder_takes_frames_of_many_small_blocks(zgpu):
-    """Frames cut into more and smaller blocks than ZSTD_compress makes (a streaming compressor flushing every 20,000
-    bytes: 52 blocks in a 1,024,000-byte frame) are Zstandard like any other: up to the block capacity of the scratch the
-    GPU decoder takes them (several passes of the prepare and chain kernels), beyond it the file goes to libzstd."""
+    """Frames cut into more and smaller blocks than ZSTD_compress makes (a streaming compressor flushing every 30,000 / 20,000 /
+    1,024 bytes: 35 / 52 / 1000 blocks in a 1,024,000-byte frame) are Zstandard like any other.  Up to the block slots of a first
+    pass (40 for such a frame) the GPU decoder takes them at once; beyond, it decodes those frames once more with a slot per KiB
+    (orchestration: the second pass) -- next to ordinary frames in the same file; a frame of still smaller blocks (a flush every
+    300 bytes) is not taken: forced, an error; by size, the file goes to libzstd."""
     import ctypes
     import oracle
     from libflagstats_amd import _lib, blockfile
@@ -319,21 +321,23 @@ def test_gpu_zstd_decoder_takes_frames_of_many_small_blocks(zgpu):
     z = bt.zstd()
 
     raw = oracle.generate(oracle.GEN_NA12878, 77, 1, 0, 512000).tobytes()
-    for every, takes in ((30000, True), (20000, False)):      # 35 blocks: within the 40 the scratch holds tables for; 52: beyond
+    plain = oracle.generate(oracle.GEN_NA12878, 78, 1, 0, 300000).tobytes()
+    for every, takes in ((30000, True), (20000, True), (1024, True), (300, False)):
         frame = flushed_frame(z, raw, every)
         back = ctypes.create_string_buffer(len(raw))
         assert z.ZSTD_decompress(back, len(raw), frame, len(frame)) == len(raw) and back.raw == raw
-        img = struct.pack("<ii", len(raw), len(frame)) + frame
+        img = image_of([plain], 1) + struct.pack("<ii", len(raw), len(frame)) + frame + image_of([plain[:100001]], 3)
+        want = expect_blocks([plain, raw, plain[:100001]])
         if takes:
             got, st = blockfile.flagstat_zstd_image(img, 2)
-            assert st["gpu_decode"] == 1 and np.array_equal(got, expect_blocks([raw]))
+            assert st["gpu_decode"] == 1 and np.array_equal(got, want), every
         else:
             with pytest.raises(_lib.FlagstatsHipError):
                 blockfile.flagstat_zstd_image(img, 2)
             assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 2) == 0
             assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 1) == 0
             got, st = blockfile.flagstat_zstd_image(img, 2)
-            assert st["gpu_decode"] == 0 and np.array_equal(got, expect_blocks([raw]))
+            assert st["gpu_decode"] == 0 and np.array_equal(got, want)
             assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 64 << 20) == 0
             assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 1) == 0
 

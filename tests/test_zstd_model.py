@@ -117,3 +117,86 @@ def test_damaged_frames_never_decode_to_something_else():
                     else:
                         assert g == want
     assert strict < 40
+
+
+def test_fse_table_built_cell_by_cell_equals_the_serial_spread():
+    """zstd_prepare builds its FSE tables with the whole wave (fse_build_wave, flagstat_zstd_kernels.hip): cell u is visited by the
+    spread at k = u * step^-1 mod S, receives slot k - (skipped visits before k), the slot's symbol comes from a max-scan over run
+    starts, and a symbol's cells take its state numbers in order of u, 64 cells at a time.  Restated here and compared with the
+    serial construction of RFC 8878 4.1.1 over random normalised counts of every accuracy log, with "less than one" symbols."""
+    import random
+
+    def serial(counts, log):
+        size = 1 << log
+        table, high = [None] * size, size - 1
+        for s, c in enumerate(counts):
+            if c == -1:
+                table[high] = s
+                high -= 1
+        step, pos = (size >> 1) + (size >> 3) + 3, 0
+        for s, c in enumerate(counts):
+            for _ in range(max(c, 0)):
+                table[pos] = s
+                pos = (pos + step) & (size - 1)
+                while pos > high:
+                    pos = (pos + step) & (size - 1)
+        assert pos == 0
+        nxt = [1 if c == -1 else c for c in counts]
+        out = []
+        for u in range(size):
+            s = table[u]
+            out.append((s, nxt[s]))
+            nxt[s] += 1
+        return out
+
+    def by_cell(counts, log):
+        size = 1 << log
+        mask = size - 1
+        low = [s for s, c in enumerate(counts) if c == -1]
+        high = size - 1 - len(low)
+        n = [max(c, 0) for c in counts]
+        slotsym, at = [0] * size, 0
+        for s, k in enumerate(n):
+            if k:
+                slotsym[at] = s + 1
+            at += k
+        assert at == high + 1
+        for i in range(1, size):
+            slotsym[i] = max(slotsym[i], slotsym[i - 1])
+        step = (size >> 1) + (size >> 3) + 3
+        inv = step
+        for _ in range(3):
+            inv = (inv * (2 - step * inv)) & 0xFFFFFFFF
+        assert (inv * step) & mask == 1
+        skipk = [((size - 1 - r) * inv) & mask for r in range(len(low))]
+        run, out = list(n), [None] * size
+        for base in range(0, size, 64):
+            seen = {}
+            for u in range(base, min(base + 64, size)):
+                if u > high:
+                    out[u] = (low[size - 1 - u], 1)
+                    continue
+                k = (u * inv) & mask
+                sym = slotsym[k - sum(1 for v in skipk if v < k)] - 1
+                out[u] = (sym, run[sym] + seen.get(sym, 0))
+                seen[sym] = seen.get(sym, 0) + 1
+            for sym, c in seen.items():
+                run[sym] += c
+        return out
+
+    rng = random.Random(1)
+    done = 0
+    while done < 1500:
+        log = rng.choice([5, 6, 7, 8, 9])
+        size, nsym = 1 << log, rng.randint(2, 53)
+        lows = set(rng.sample(range(nsym), rng.randint(0, min(nsym - 1, size // 4))))
+        others = [s for s in range(nsym) if s not in lows]
+        pick = rng.sample(others, rng.randint(1, len(others)))
+        rest = size - len(lows) - len(pick)
+        if rest < 0:
+            continue
+        counts = [-1 if s in lows else (1 if s in pick else 0) for s in range(nsym)]
+        for _ in range(rest):
+            counts[rng.choice(pick)] += 1
+        assert serial(counts, log) == by_cell(counts, log), (counts, log)
+        done += 1
