@@ -660,6 +660,9 @@ int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_
         return fsint::fail_text("cannot stat file");
     }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    // (a file that is not in the page cache yet starts coming in NOW, while the first call of a process still creates its engine:
+    // the HIP runtime's initialisation alone takes 50-70 ms, profiles/r05/cold_start.log)
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_WILLNEED);
     // File mode: every worker preads the compressed payload of its block into a private buffer (30 % of
     // the decoders' CPU time).  FLAGSTATS_HIP_BLOCK_IO=mmap decodes straight out of a read-only mapping
     // instead (each worker populates its own block's pages with one madvise): built and measured SLOWER
@@ -784,6 +787,9 @@ int file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats, 
         return fsint::fail_text("cannot stat file");
     }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    // (a file that is not in the page cache yet starts coming in NOW, while the first call of a process still creates its engine:
+    // the HIP runtime's initialisation alone takes 50-70 ms, profiles/r05/cold_start.log)
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_WILLNEED);
     fsint::Engine* eng = fsint::default_engine();
     Source in;
     in.fd = fd;

@@ -69,6 +69,8 @@ struct RegisteredHost {
     void* ptr = nullptr;       // what the caller uses (2 MiB aligned when mapped here)
     void* map = nullptr;       // the mapping behind it (nullptr: `ptr` came from hipHostMalloc)
     size_t map_bytes = 0;
+    size_t len = 0;            // bytes registered (or to be registered) from ptr
+    bool registered = false;   // false after host_alloc_registered(..., false) until host_register_late
 };
 
 struct Engine {
@@ -112,8 +114,9 @@ struct Engine {
     hipEvent_t lz4_landed[kLz4MaxPieces] = {}, lz4_joined[kLz4Streams] = {}, lz4_pin_free[kLz4MaxSpans] = {};
     uint8_t* lz4_pin = nullptr;                    // ... ONE page-locked allocation holding the ring (on the GPU's NUMA node)
     uint64_t lz4_pin_bytes = 0;
-    void* lz4_pin_map = nullptr;                   // (the mapping behind it when it is registered anonymous memory: host_alloc_registered)
-    size_t lz4_pin_map_bytes = 0;
+    RegisteredHost lz4_pin_reg;                    // (what it is made of: host_alloc_registered)
+    RegisteredHost lz4_index_host;                 // page-locked staging of a segment's block index (a copy out of pageable memory costs
+    uint64_t lz4_index_host_cap = 0;               //  the first call of a process 11 ms: the runtime sets its own staging up)
     uint8_t* zstd_scratch[kLz4Streams] = {};       // GPU Zstandard decoder: records / literals / checkpoints of a piece, per decode stream
     uint64_t zstd_scratch_cap[kLz4Streams] = {};   // (kept and released with the two large buffers)
     void* lz4_index = nullptr;                     // blocks + status + tally of a segment
@@ -196,7 +199,10 @@ void* host_alloc_on_node(size_t bytes, int numa_node);   // pinned, pages placed
 // `numa_node`'s CPUs (so it lies there), then hipHostRegister-ed -- 48 MiB in 0.8 ms where hipHostMalloc takes 6-40 ms (it locks
 // and maps 4 KiB pages one by one: 0.2-0.5 ms per MiB; profiles/r05/file_h2d.log), copies out of it at the link's rate.
 // Falls back to host_alloc_on_node.  Release with host_free_registered (the pair keeps no table: the owner remembers `bytes`).
-RegisteredHost host_alloc_registered(size_t bytes, int numa_node);   // ptr == nullptr on failure (error recorded)
+// touch_and_register = false: only the mapping is made (0.03 ms) -- the owner's own threads touch it as they fill it (their
+// first writes place the pages) and host_register_late page-locks it before the first copy out of it.
+RegisteredHost host_alloc_registered(size_t bytes, int numa_node, bool touch_and_register = true);   // ptr == nullptr on failure (error recorded)
+bool host_register_late(RegisteredHost& r);   // false: the runtime refused; the memory stays usable as ordinary (pageable) memory
 void host_free_registered(RegisteredHost& r);
 extern thread_local double g_reg_times[4];   // the last host_alloc_registered's phases in ms (diagnostics)
 uint64_t chunk_bytes();

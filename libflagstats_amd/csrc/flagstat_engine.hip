@@ -212,10 +212,17 @@ int engine_setup(Engine& e, int device)
             if (err1 == hipSuccess) err1 = hipMemcpyAsync(e.d_out[1], zeros, sizeof zeros, hipMemcpyHostToDevice, e.stream[1]);
             if (err1 == hipSuccess) err1 = hipStreamSynchronize(e.stream[1]);
         });
+        const clk::time_point t_s0 = clk::now();
         hipError_t err0 = hipStreamCreateWithFlags(&e.stream[0], hipStreamNonBlocking);
+        const clk::time_point t_s1 = clk::now();
         if (err0 == hipSuccess) err0 = hipMalloc(&e.d_out[0], 4096);  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
         for (int i = 0; i < 2 && err0 == hipSuccess; ++i) err0 = hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming);
+        const clk::time_point t_s2 = clk::now();
         second.join();
+        if (timed)
+            std::fprintf(stderr, "engine creation, streams (ms): first stream %.2f | counters + events %.2f | waiting for the helper thread (second stream, its counters, first fill + copy) %.2f\n",
+                         std::chrono::duration<double, std::milli>(t_s1 - t_s0).count(), std::chrono::duration<double, std::milli>(t_s2 - t_s1).count(),
+                         std::chrono::duration<double, std::milli>(clk::now() - t_s2).count());
         if (err0 != hipSuccess) return fail_hip("engine creation: stream / counters / events", err0);
         if (err1 != hipSuccess) return fail_hip("engine creation: second stream", err1);
     }
@@ -711,7 +718,7 @@ void* host_alloc_on_node(size_t bytes, int numa_node)
 
 thread_local double g_reg_times[4] = {0, 0, 0, 0};   // last host_alloc_registered: mmap + madvise, first touch, hipHostRegister, fallback (ms; tests/perf)
 
-RegisteredHost host_alloc_registered(size_t bytes, int numa_node)
+RegisteredHost host_alloc_registered(size_t bytes, int numa_node, bool touch_and_register)
 {
     RegisteredHost r;
     using clk = std::chrono::steady_clock;
@@ -729,6 +736,14 @@ RegisteredHost host_alloc_registered(size_t bytes, int numa_node)
         (void)madvise(base, len, MADV_HUGEPAGE);   // (refused where huge pages are off: 4 KiB pages then, still 5x quicker than hipHostMalloc)
 #endif
         g_reg_times[0] = since(t0);
+        if (!touch_and_register) {
+            r.ptr = base;
+            r.map = map;
+            r.map_bytes = len + huge;
+            r.len = len;
+            r.registered = false;
+            return r;
+        }
         const clk::time_point t1 = clk::now();
         // first touch = placement: by threads on the node's CPUs, a slice each
         cpu_set_t cpus;
@@ -751,6 +766,8 @@ RegisteredHost host_alloc_registered(size_t bytes, int numa_node)
             r.ptr = base;
             r.map = map;
             r.map_bytes = len + huge;
+            r.len = len;
+            r.registered = true;
             return r;
         }
         (void)hipGetLastError();
@@ -758,14 +775,31 @@ RegisteredHost host_alloc_registered(size_t bytes, int numa_node)
     }
     const clk::time_point t3 = clk::now();
     r.ptr = host_alloc_on_node(bytes, numa_node);
+    r.len = bytes;
+    r.registered = r.ptr != nullptr;
     g_reg_times[3] = since(t3);
     return r;
+}
+
+bool host_register_late(RegisteredHost& r)
+{
+    if (r.registered || !r.map) return r.registered;
+    using clk = std::chrono::steady_clock;
+    const clk::time_point t2 = clk::now();
+    const hipError_t reg = hipHostRegister(r.ptr, r.len, hipHostRegisterDefault);
+    g_reg_times[2] = std::chrono::duration<double, std::milli>(clk::now() - t2).count();
+    if (reg != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    r.registered = true;
+    return true;
 }
 
 void host_free_registered(RegisteredHost& r)
 {
     if (r.map) {
-        (void)hipHostUnregister(r.ptr);
+        if (r.registered) (void)hipHostUnregister(r.ptr);
         munmap(r.map, r.map_bytes);
     } else if (r.ptr) {
         (void)hipHostFree(r.ptr);

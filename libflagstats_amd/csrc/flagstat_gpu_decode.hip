@@ -56,7 +56,7 @@ struct PhaseClock {
     using clk = std::chrono::steady_clock;
     bool on = false;
     clk::time_point last;
-    double index = 0, meminfo = 0, streams = 0, alloc_comp = 0, alloc_out = 0, alloc_small = 0, alloc_scratch = 0, pinned = 0, queue = 0, wait = 0;
+    double index = 0, meminfo = 0, streams = 0, alloc_comp = 0, alloc_out = 0, alloc_small = 0, alloc_scratch = 0, preset = 0, pinned = 0, queue = 0, wait = 0;
     void start()
     {
         const char* k = std::getenv("FLAGSTATS_HIP_GPU_DECODE_TIMES");
@@ -75,15 +75,9 @@ struct PhaseClock {
 
 static void lz4_gpu_free_ring(Engine& e)
 {
-    RegisteredHost r;
-    r.ptr = e.lz4_pin;
-    r.map = e.lz4_pin_map;
-    r.map_bytes = e.lz4_pin_map_bytes;
-    host_free_registered(r);
+    host_free_registered(e.lz4_pin_reg);
     e.lz4_pin = nullptr;
     e.lz4_pin_bytes = 0;
-    e.lz4_pin_map = nullptr;
-    e.lz4_pin_map_bytes = 0;
 }
 
 void lz4_gpu_release(Engine& e, bool all)
@@ -117,6 +111,8 @@ void lz4_gpu_release(Engine& e, bool all)
     e.lz4_index = nullptr;
     e.lz4_index_cap = 0;
     lz4_gpu_free_ring(e);
+    host_free_registered(e.lz4_index_host);
+    e.lz4_index_host_cap = 0;
     e.lz4_ready = false;
 }
 
@@ -285,12 +281,42 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     // writer are whole multiples of 16 bytes, so this is normally nothing at all
     bool ragged = false;
     for (const fsk::GpuBlock& b : blocks) ragged = ragged || (b.dst_len & 15u);
+    double t_pre[4] = {0, 0, 0, 0};
+    auto pre_lap = [&](int k) {
+        if (!pc_.on) return;
+        const PhaseClock::clk::time_point now = PhaseClock::clk::now();
+        t_pre[k] = std::chrono::duration<double, std::milli>(now - pc_.last).count();
+        pc_.preset += t_pre[k];
+        pc_.last = now;
+    };
+    pre_lap(0);
     LZG_TRY(hipEventRecord(e.lz4_ev[0], s));
+    pre_lap(1);
     if (ragged) LZG_TRY(hipMemsetAsync(d_out, 0, dpos + 16, s));
     LZG_TRY(hipMemsetAsync(d_status, 0xFF, blocks.size() * sizeof(uint32_t), s));
     LZG_TRY(hipMemsetAsync(d_tally, 0, fsk::kLz4TallyWords * 8, s));
     LZG_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), s));
-    LZG_TRY(hipMemcpyAsync(d_blocks, blocks.data(), blocks.size() * sizeof(fsk::GpuBlock), hipMemcpyHostToDevice, s));
+    pre_lap(2);
+    {
+        // The index goes up out of a small page-locked buffer of the engine's: a copy out of pageable memory made the first call of a
+        // process wait 11.5 ms for the runtime's own staging set-up (profiles/r05/cold_start.log); the engine's streams are idle
+        // between calls (every call ends with a stream wait), so the buffer is free to be rewritten here.
+        const uint64_t nbytes = blocks.size() * sizeof(fsk::GpuBlock);
+        if (e.lz4_index_host_cap < nbytes) {
+            host_free_registered(e.lz4_index_host);
+            e.lz4_index_host_cap = 0;
+            e.lz4_index_host = host_alloc_registered((nbytes + (1u << 20) - 1) & ~static_cast<uint64_t>((1u << 20) - 1), e.numa_node);
+            if (e.lz4_index_host.ptr) e.lz4_index_host_cap = (nbytes + (1u << 20) - 1) & ~static_cast<uint64_t>((1u << 20) - 1);
+        }
+        const void* src = blocks.data();
+        if (e.lz4_index_host_cap >= nbytes) {
+            std::memcpy(e.lz4_index_host.ptr, blocks.data(), nbytes);
+            src = e.lz4_index_host.ptr;
+        }
+        LZG_TRY(hipMemcpyAsync(d_blocks, src, nbytes, hipMemcpyHostToDevice, s));
+    }
+    pre_lap(3);
+    if (pc_.on) std::fprintf(stderr, "gpu decode, presets: before %.2f ms, hipEventRecord %.2f, three hipMemsetAsync %.2f, hipMemcpyAsync of the index (%zu bytes) %.2f\n", t_pre[0], t_pre[1], t_pre[2], blocks.size() * sizeof(fsk::GpuBlock), t_pre[3]);
     // env FLAGSTATS_HIP_GPU_LZ4_RING = 8 (default) | 16: KiB of recent output per wave in LDS (r03's kernel only)
     const char* rk = std::getenv("FLAGSTATS_HIP_GPU_LZ4_RING");
     const bool big_ring = rk && std::atoi(rk) == 16;
@@ -328,6 +354,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     if (npieces < 1) npieces = 1;
     if (npieces > static_cast<uint32_t>(Engine::kLz4MaxPieces)) npieces = Engine::kLz4MaxPieces;
     if (npieces > blocks.size()) npieces = static_cast<uint32_t>(blocks.size());
+    pc_.lap(pc_.preset);
     // File mode: a ring of page-locked spans, filled by parallel preads ahead of the copies.  ONE allocation on the GPU's NUMA
     // node, made on first use and kept with the engine: 4 spans of 16 MiB -- r04 took the host pipeline's three 64 MiB chunk
     // buffers, whose page-locking cost the first call of a process 40-53 ms (0.2-0.25 ms per MiB; 48 MiB in one call: 7.6 ms;
@@ -355,18 +382,14 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             }
             // Page-locked the quick way (host_alloc_registered: huge pages touched on the GPU's node, then registered): r04's three
             // hipHostMalloc-ed 64 MiB buffers cost the first call of a process 40-53 ms, this ring 1 ms.
-            DeviceGuard g2(e.device);
-            RegisteredHost r = g2.ok() ? host_alloc_registered(ring_bytes, e.numa_node) : RegisteredHost{};
-            if (!r.ptr) {
+            // ... and not even that here: the mapping is made now, the READERS touch it as they fill it (parallel, on the GPU's node:
+            // that places the pages) and it is page-locked just before the first copy out of it (ring_register below).
+            e.lz4_pin_reg = host_alloc_registered(ring_bytes, e.numa_node, false);
+            if (!e.lz4_pin_reg.ptr) {
                 settle();
                 return -1;
             }
-            if (pc_.on)
-                std::fprintf(stderr, "gpu decode, pinned ring of %llu MiB: mmap + madvise %.2f ms, first touch %.2f, hipHostRegister %.2f, hipHostMalloc fallback %.2f\n",
-                             static_cast<unsigned long long>(ring_bytes >> 20), g_reg_times[0], g_reg_times[1], g_reg_times[2], g_reg_times[3]);
-            e.lz4_pin = static_cast<uint8_t*>(r.ptr);
-            e.lz4_pin_map = r.map;
-            e.lz4_pin_map_bytes = r.map_bytes;
+            e.lz4_pin = static_cast<uint8_t*>(e.lz4_pin_reg.ptr);
             e.lz4_pin_bytes = ring_bytes;
         }
         for (int i = 0; i < nspans_ring; ++i) pinned[i] = e.lz4_pin + span_cap * static_cast<uint64_t>(i);
@@ -388,15 +411,24 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     // = per cent of an equal share overrides (0 / 100: equal pieces).
     const char* fpk = std::getenv("FLAGSTATS_HIP_GPU_FIRST_PIECE");
     int first_pct = fpk ? std::atoi(fpk) : (zstd ? 50 : 0);
-    if (first_pct < 0 || first_pct >= 100) first_pct = 0;
+    if (first_pct <= 0 || first_pct >= 100) first_pct = 100;
+    // ... and the LAST piece may be a fraction of a share too (env FLAGSTATS_HIP_GPU_LAST_PIECE, per cent): what is left exposed
+    // behind the last copy is the last piece's way through the kernels
+    const char* lpk = std::getenv("FLAGSTATS_HIP_GPU_LAST_PIECE");
+    int last_pct = lpk ? std::atoi(lpk) : 100;
+    if (last_pct <= 0 || last_pct >= 100) last_pct = 100;
     auto cut_pieces = [&] {
         pieces.clear();
+        // the first piece is first_pct of an equal share; the others share what is left, the last one weighing last_pct of a middle one
+        const uint64_t t0 = npieces > 1 ? bytes / npieces * static_cast<uint64_t>(first_pct) / 100u : bytes;
+        const uint64_t wsum = npieces > 2 ? 100u * (npieces - 2u) + static_cast<uint64_t>(last_pct) : 100u;
+        uint64_t wrun = 0;
         for (uint64_t first = 0; pieces.size() < npieces && first < blocks.size();) {
             const uint64_t c = pieces.size();
-            uint64_t target = bytes / npieces * (c + 1);
-            if (first_pct > 0 && npieces > 1) {
-                const uint64_t t0 = bytes / npieces * static_cast<uint64_t>(first_pct) / 100u;
-                target = t0 + (bytes - t0) / (npieces - 1) * c;
+            uint64_t target = t0;
+            if (c > 0) {
+                wrun += (c + 1 == npieces && npieces > 2) ? static_cast<uint64_t>(last_pct) : 100u;
+                target = t0 + static_cast<uint64_t>(static_cast<unsigned __int128>(bytes - t0) * wrun / wsum);
             }
             uint64_t last = first + 1;
             while (last < blocks.size() && (c + 1 == npieces || blocks[last].src_off + blocks[last].src_len <= target)) ++last;
@@ -540,6 +572,14 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
                 std::unique_lock<std::mutex> ul(m);
                 cv_done.wait(ul, [&] { return done[i] == readers; });
                 if (failed) return fail_text("block file: short read");
+            }
+            if (!e.lz4_pin_reg.registered) {
+                // (first use of the ring: the spans released so far have been touched by the readers; a refusal leaves ordinary memory,
+                // out of which the copies still work, through the runtime's staging)
+                DeviceGuard g2(e.device);
+                const bool locked = g2.ok() && host_register_late(e.lz4_pin_reg);
+                if (pc_.on) std::fprintf(stderr, "gpu decode, pinned ring of %llu MiB: mapped, touched by the readers' first reads, hipHostRegister %.2f ms%s\n",
+                                         static_cast<unsigned long long>(e.lz4_pin_bytes >> 20), g_reg_times[2], locked ? "" : " (refused)");
             }
             hipError_t e_ = hipMemcpyAsync(d_comp + spans[i].at, pinned[i % ring], spans[i].len, hipMemcpyHostToDevice, s);
             if (e_ == hipSuccess) e_ = hipEventRecord(pin_free[i % ring], s);
@@ -871,9 +911,9 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         double keep_rule = 0;
         pc.lap(keep_rule);
         std::fprintf(stderr, "gpu decode, host side (ms): index %.2f | device memory query %.2f | streams + events %.2f | hipMalloc compressed %.2f, decoded %.2f, "
-                             "index %.2f, scratch %.2f | pinned spans %.2f | reading + queueing the pieces %.2f | waiting for the device %.2f | keep rule %.2f | "
+                             "index %.2f, scratch %.2f | presets + index upload queued %.2f | pinned ring %.2f | reading + queueing the pieces %.2f | waiting for the device %.2f | keep rule %.2f | "
                              "call %.2f (stream events: copies %.2f, decode behind the last copy %.2f, K1 %.2f)\n",
-                     pc.index, pc.meminfo, pc.streams, pc.alloc_comp, pc.alloc_out, pc.alloc_small, pc.alloc_scratch, pc.pinned, pc.queue, pc.wait, keep_rule,
+                     pc.index, pc.meminfo, pc.streams, pc.alloc_comp, pc.alloc_out, pc.alloc_small, pc.alloc_scratch, pc.preset, pc.pinned, pc.queue, pc.wait, keep_rule,
                      stats->wall_s * 1e3, stats->h2d_ms, stats->decode_ms, stats->count_ms);
     }
     return 0;

@@ -39,9 +39,28 @@ def build_oneshot():
                     "-Wl,-rpath," + libdir], check=True)
 
 
+EVICT = False
+
+
+def evict(path):
+    """--evict: the file's (clean, written-back) pages are dropped from the page cache before a sample: a job without root
+    cannot drop the whole cache, but POSIX_FADV_DONTNEED on its own file does that much"""
+    if EVICT and os.path.isfile(str(path)):
+        fd = os.open(path, os.O_RDONLY)
+        try:
+            os.posix_fadvise(fd, 0, 0, os.POSIX_FADV_DONTNEED)
+        finally:
+            os.close(fd)
+
+
+GAP_S = 1.0
+
+
 def spawn_oneshot(mode, arg, calls=3, env_extra=None):
     env = dict(os.environ, FLAGSTATS_HIP_GPU_DECODE_TIMES="1", FLAGSTATS_HIP_INIT_TIMES="1")
     env.update(env_extra or {})
+    evict(arg)
+    time.sleep(GAP_S)   # (the process before has exited; the driver releases its device memory behind it -- a one-shot user does not start in that wake)
     t_spawn = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
     r = subprocess.run([ONESHOT, str(t_spawn), mode, str(arg), str(calls)], capture_output=True, text=True, env=env)
     t_exit = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
@@ -50,7 +69,7 @@ def spawn_oneshot(mode, arg, calls=3, env_extra=None):
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     d["process_ms"] = (t_exit - t_spawn) * 1e-6
     d["phases"] = [ln for ln in r.stderr.splitlines() if ln.startswith("gpu decode, host side")]
-    d["ring"] = [ln for ln in r.stderr.splitlines() if ln.startswith("gpu decode, pinned ring")]
+    d["ring"] = [ln for ln in r.stderr.splitlines() if ln.startswith("gpu decode, pinned ring") or ln.startswith("gpu decode, presets")]
     d["init_phases"] = [ln for ln in r.stderr.splitlines() if ln.startswith("engine creation")]
     return d
 
@@ -77,8 +96,8 @@ def report(name, samples, n_flags, ref_note=""):
         print("    " + typical["init_phases"][0], flush=True)
     if typical["phases"]:
         print("    first call (the median sample), " + typical["phases"][0], flush=True)
-        if typical.get("ring"):
-            print("    " + typical["ring"][0], flush=True)
+        for ln in typical.get("ring", [])[:2]:
+            print("    " + ln, flush=True)
         if len(typical["phases"]) > 1:
             print("    second call, " + typical["phases"][1], flush=True)
     if slowest is not typical and slowest["calls_ms"][0] > 1.5 * med(first) and slowest["phases"]:
@@ -91,6 +110,7 @@ def reference_program(path, raw):
         return None
     best = None
     for _ in range(2):
+        evict(path)
         t0 = time.perf_counter()
         r = subprocess.run([BENCH_REF, "decompress", "-i", path, "-D" if raw else "-d"], capture_output=True, text=True)
         t = (time.perf_counter() - t0) * 1e3
@@ -119,12 +139,17 @@ def main():
     ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--which", default="u16,python,hc9,fast,zstd,raw")
     ap.add_argument("--env", default="", help="KEY=VALUE[,KEY=VALUE] for the children (A/B of library knobs)")
+    ap.add_argument("--gap-s", type=float, default=1.0, help="pause before every fresh process")
+    ap.add_argument("--evict", action="store_true", help="drop the file from the page cache before every sample (the FIRST call then reads the disk; the repeated calls of the same process are warm again)")
     args = ap.parse_args()
+    global EVICT, GAP_S
+    EVICT = args.evict
+    GAP_S = args.gap_s
     which = args.which.split(",")
     env_extra = dict(kv.split("=", 1) for kv in args.env.split(",") if kv)
     build_oneshot()
     tmp = os.environ.get("TMPDIR", "/tmp")
-    print("one-shot times, %d fresh processes per line; files of %d flags in %s (page cache)%s" % (args.samples, args.flags, tmp, " env " + args.env if args.env else ""), flush=True)
+    print("one-shot times, %d fresh processes per line; files of %d flags in %s (%s)%s" % (args.samples, args.flags, tmp, "EVICTED from the page cache before every sample" if EVICT else "page cache", " env " + args.env if args.env else ""), flush=True)
     if "u16" in which:
         for n in (1_000_000, 100_000_000):
             report("FLAGSTATS_u16, %d flags" % n, [spawn_oneshot("u16", n, env_extra=env_extra) for _ in range(args.samples)], n)

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--reps", type=int, default=4)
     ap.add_argument("--pinned", type=int, default=0, help="1: the image in page-locked host memory (the runtime then copies it with the DMA engines, not with a staged shader copy)")
     ap.add_argument("--first", default="0", help="first piece as a percentage of an equal share (100: equal pieces; 0: the shipped rule), comma list")
+    ap.add_argument("--last", default="0", help="last piece as a percentage of a middle one (0 / 100: like the others), comma list")
     args = ap.parse_args()
     import oracle
     n = int(eval(args.flags))
@@ -48,7 +49,11 @@ def main():
     _lib.check(lib.FLAGSTATS_hip_set(b"zstd_decoder" if zstd else b"lz4_decoder", 1), "set")
     entry = lib.FLAGSTATS_hip_blockimage_zstd if zstd else lib.FLAGSTATS_hip_blockimage_lz4
     print("%s  %s-%s, %d flags, %.0f MiB%s" % (os.path.basename(_lib.LIB_PATH), mode, level, n, buf.size / 2**20, ", image page-locked" if args.pinned else ""), flush=True)
-    for pc, fp in [(int(x), int(y)) for x in args.pieces.split(",") for y in args.first.split(",")]:
+    for pc, fp, lp in [(int(x), int(y), int(z)) for x in args.pieces.split(",") for y in args.first.split(",") for z in args.last.split(",")]:
+        if lp:
+            os.environ["FLAGSTATS_HIP_GPU_LAST_PIECE"] = str(lp)
+        else:
+            os.environ.pop("FLAGSTATS_HIP_GPU_LAST_PIECE", None)
         if fp:
             os.environ["FLAGSTATS_HIP_GPU_FIRST_PIECE"] = str(fp)
         else:
@@ -66,7 +71,7 @@ def main():
             ts.append(time.perf_counter() - t0)
             assert np.array_equal(out, want) and st.gpu_decode == 1
         ts = ts[1:]
-        print("   pieces %-8s first %3d %% (0 = rule)  best %6.1f ms  median %6.1f ms  = %5.1f Gflags/s  (%d pieces ran)" % (pc or "rule", fp, min(ts) * 1e3, sorted(ts)[len(ts) // 2] * 1e3, n / min(ts) / 1e9, st.chunks), flush=True)
+        print("   pieces %-8s first %3d %% (0 = rule) last %3d %%  best %6.1f ms  median %6.1f ms  = %5.1f Gflags/s  (%d pieces ran)" % (pc or "rule", fp, lp, min(ts) * 1e3, sorted(ts)[len(ts) // 2] * 1e3, n / min(ts) / 1e9, st.chunks), flush=True)
 
 
 if __name__ == "__main__":
