@@ -207,16 +207,30 @@ int engine_setup(Engine& e, int device)
             err1 = hipSetDevice(device);
             if (err1 == hipSuccess) err1 = hipStreamCreateWithFlags(&e.stream[1], hipStreamNonBlocking);
             if (err1 == hipSuccess) err1 = hipMalloc(&e.d_out[1], 4096);
-            uint64_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (err1 == hipSuccess) err1 = hipMemsetAsync(e.d_out[1], 0, 4096, e.stream[1]);
-            if (err1 == hipSuccess) err1 = hipMemcpyAsync(e.d_out[1], zeros, sizeof zeros, hipMemcpyHostToDevice, e.stream[1]);
+            // (first uses: a fill, a copy out of pageable memory -- the runtime's own kernels and staging -- and copies both ways
+            // out of / into page-locked memory -- the DMA engines' queues: the first such copy of a process takes 13-16 ms)
+            // (the page-locked copies are 256 KiB: small ones go through a copy kernel, not through the DMA engines)
+            constexpr size_t kWarm = 256u << 10;
+            void *pinned_warm = nullptr, *device_warm = nullptr;
+            if (err1 == hipSuccess) err1 = hipHostMalloc(&pinned_warm, kWarm, hipHostMallocDefault);
+            if (err1 == hipSuccess) err1 = hipMalloc(&device_warm, kWarm);
+            if (err1 == hipSuccess) err1 = hipMemcpyAsync(device_warm, pinned_warm, kWarm, hipMemcpyHostToDevice, e.stream[1]);
+            if (err1 == hipSuccess) err1 = hipMemcpyAsync(pinned_warm, device_warm, kWarm, hipMemcpyDeviceToHost, e.stream[1]);
             if (err1 == hipSuccess) err1 = hipStreamSynchronize(e.stream[1]);
+            if (pinned_warm) (void)hipHostFree(pinned_warm);
+            if (device_warm) (void)hipFree(device_warm);
         });
         const clk::time_point t_s0 = clk::now();
         hipError_t err0 = hipStreamCreateWithFlags(&e.stream[0], hipStreamNonBlocking);
         const clk::time_point t_s1 = clk::now();
         if (err0 == hipSuccess) err0 = hipMalloc(&e.d_out[0], 4096);  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
         for (int i = 0; i < 2 && err0 == hipSuccess; ++i) err0 = hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming);
+        {   // (this thread's share of the first uses: the runtime's fill kernel and its staged copy out of pageable memory)
+            uint64_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (err0 == hipSuccess) err0 = hipMemsetAsync(e.d_out[0], 0, 4096, e.stream[0]);
+            if (err0 == hipSuccess) err0 = hipMemcpyAsync(e.d_out[0], zeros, sizeof zeros, hipMemcpyHostToDevice, e.stream[0]);
+            if (err0 == hipSuccess) err0 = hipStreamSynchronize(e.stream[0]);
+        }
         const clk::time_point t_s2 = clk::now();
         second.join();
         if (timed)

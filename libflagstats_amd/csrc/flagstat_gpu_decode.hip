@@ -95,8 +95,9 @@ void lz4_gpu_release(Engine& e, bool all)
         if (p) (void)hipFree(p);
     }
     if (!all) return;
-    for (hipStream_t& x : e.lz4_stream) {
-        if (x) (void)hipStreamDestroy(x);
+    for (int i = 0; i < Engine::kLz4Streams; ++i) {
+        hipStream_t& x = e.lz4_stream[i];
+        if (x && i > 0) (void)hipStreamDestroy(x);   // ([0] is the engine's own second stream, borrowed)
         x = nullptr;
     }
     auto drop = [](hipEvent_t& x) {
@@ -148,9 +149,12 @@ static int lz4_gpu_streams(Engine& e, int codec)   // (runs on a helper thread: 
 {
     DeviceGuard guard(e.device);
     if (!guard.ok()) return -1;
+    // The first decode stream is the engine's own second stream (idle while the decoder has the engine: every call ends with a
+    // stream wait), so ONE stream is made here: a stream costs 8-10 ms, and the first call of a process waited 12 ms for two.
     hipError_t err = hipSuccess;
-    for (hipStream_t& x : e.lz4_stream)
-        if (err == hipSuccess && !x) err = hipStreamCreateWithFlags(&x, hipStreamNonBlocking);
+    e.lz4_stream[0] = e.stream[1];
+    for (int i = 1; i < Engine::kLz4Streams; ++i)
+        if (err == hipSuccess && !e.lz4_stream[i]) err = hipStreamCreateWithFlags(&e.lz4_stream[i], hipStreamNonBlocking);
     if (err != hipSuccess) return fail_hip("GPU block decoder: streams", err);
     // ... and the code objects the call is about to launch from are loaded here instead of inside the first launches (the
     // occupancy queries load the decode kernels' translation unit, fsk_warm K1's)

@@ -119,13 +119,14 @@ def reference_program(path, raw):
     return best
 
 
-def python_oneshot(n):
+def python_oneshot(n, env_extra=None):
     """python/README.md:45-47: `fs.flagstats(np.random.randint(0, 8192, 100_000_000, dtype="uint16"))` "completes in around 1 second" """
     code = ("import time, sys; t0 = time.perf_counter(); import numpy as np; t1 = time.perf_counter(); sys.path.insert(0, %r); import pyflagstats as fs; t2 = time.perf_counter();"
             "a = np.random.randint(0, 8192, %d, dtype='uint16'); t3 = time.perf_counter(); r = fs.flagstats(a); t4 = time.perf_counter(); r2 = fs.flagstats(a); t5 = time.perf_counter();"
             "print('PY %%.1f %%.1f %%.1f %%.1f %%.1f %%d' %% ((t1 - t0) * 1e3, (t2 - t1) * 1e3, (t3 - t2) * 1e3, (t4 - t3) * 1e3, (t5 - t4) * 1e3, r['n_values']))") % (ROOT, n)
+    time.sleep(GAP_S)
     t0 = time.perf_counter()
-    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=dict(os.environ, **(env_extra or {})))
     wall = (time.perf_counter() - t0) * 1e3
     if r.returncode:
         raise RuntimeError(r.stderr[-2000:])
@@ -154,11 +155,14 @@ def main():
         for n in (1_000_000, 100_000_000):
             report("FLAGSTATS_u16, %d flags" % n, [spawn_oneshot("u16", n, env_extra=env_extra) for _ in range(args.samples)], n)
     if "python" in which:
-        rows = [python_oneshot(100_000_000) for _ in range(max(2, args.samples // 2))]
-        wall = med([w for w, _ in rows])
-        parts = [med([p[i] for _, p in rows]) for i in range(5)]
-        print("%-34s whole interpreter run %7.1f ms = import numpy %.1f + import pyflagstats (dlopen, no GPU call yet) %.1f + np.random.randint %.1f + FIRST flagstats() %.1f (hipInit + engine + "
-              "200 MB over PCIe) | second flagstats() %.1f ms  [python/README.md:45-47: \"around 1 second\" incl. RNG]" % ("pyflagstats.flagstats, 1e8 flags", wall, *parts), flush=True)
+        # (the package loads torch's bundled HIP runtime first when torch is installed, so that a later `import torch` in the same
+        # process binds to the same copy: libflagstats_amd/_lib.py; FLAGSTATS_HIP_SYSTEM_RUNTIME=1 skips that)
+        for label, extra in (("pyflagstats.flagstats, 1e8 flags", {}), ("... FLAGSTATS_HIP_SYSTEM_RUNTIME=1", {"FLAGSTATS_HIP_SYSTEM_RUNTIME": "1"})):
+            rows = [python_oneshot(100_000_000, extra) for _ in range(max(2, args.samples // 2))]
+            wall = med([w for w, _ in rows])
+            parts = [med([p[i] for _, p in rows]) for i in range(5)]
+            print("%-34s whole interpreter run %7.1f ms = import numpy %.1f + import pyflagstats (no GPU call yet) %.1f + np.random.randint %.1f + FIRST flagstats() %.1f (loading the HIP runtime, "
+                  "hipInit, engine, 200 MB over PCIe) | second flagstats() %.1f ms  [python/README.md:45-47: \"around 1 second\" incl. RNG]" % (label, wall, *parts), flush=True)
     if any(k in which for k in ("hc9", "fast", "zstd", "raw")):
         import numpy as np  # noqa: F401
 
