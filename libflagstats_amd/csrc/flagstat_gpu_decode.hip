@@ -538,11 +538,13 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         std::condition_variable cv_work, cv_done;
         size_t released = 0;                       // spans [0, released) may be read
         std::vector<int> done(spans.size(), 0);    // reader threads finished per span
+        std::vector<std::atomic<uint64_t>> slice_next(spans.size());   // next slice of a span to be read
+        for (auto& a : slice_next) a.store(0, std::memory_order_relaxed);
         bool stop = false, failed = false;
         // (the pinned spans live on the GPU's host NUMA node: the readers run there too, like the host pipeline's decoders)
         cpu_set_t node_cpus;
         const bool pin_threads = knobs().numa.load() && node_cpuset(e.numa_node, &node_cpus);
-        auto reader = [&](int t) {
+        auto reader = [&](int) {
             if (pin_threads) (void)pthread_setaffinity_np(pthread_self(), sizeof node_cpus, &node_cpus);
             for (size_t i = 0; i < spans.size(); ++i) {
                 {
@@ -550,19 +552,29 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
                     cv_work.wait(ul, [&] { return released > i || stop; });
                     if (stop) return;
                 }
+                // A span is read in slices of 256 KiB that the readers TAKE (an atomic counter per span), not in one fixed share each:
+                // a reader that is descheduled or sits on a slower core then holds up one slice, not a sixteenth of the span (the
+                // box's CPUs are shared with other jobs: with fixed shares the file-mode rounds of a soak spread over 33-44 ms where
+                // image mode, which no CPU touches, stays within 1 %; profiles/r05/lz4hc9_gpu_soak_gpu_rounds_only.log)
                 const Span& sp = spans[i];
-                const uint64_t share = ((sp.len + static_cast<uint64_t>(readers) - 1) / static_cast<uint64_t>(readers) + 4095) & ~4095ull;
-                uint64_t o = share * static_cast<uint64_t>(t);
-                const uint64_t end = o + share < sp.len ? o + share : sp.len;
+                constexpr uint64_t kSlice = 256u << 10;
+                const uint64_t nslices = (sp.len + kSlice - 1) / kSlice;
                 bool ok = true;
                 uint8_t* base = pinned[i % ring];
-                while (o < end) {
-                    const ssize_t r = pread(in.fd, base + o, end - o, static_cast<off_t>(file_lo + sp.at + o));
-                    if (r <= 0) {
-                        ok = false;
-                        break;
+                for (;;) {
+                    const uint64_t k = slice_next[i].fetch_add(1, std::memory_order_relaxed);
+                    if (k >= nslices) break;
+                    uint64_t o = k * kSlice;
+                    const uint64_t end = o + kSlice < sp.len ? o + kSlice : sp.len;
+                    while (o < end) {
+                        const ssize_t r = pread(in.fd, base + o, end - o, static_cast<off_t>(file_lo + sp.at + o));
+                        if (r <= 0) {
+                            ok = false;
+                            break;
+                        }
+                        o += static_cast<uint64_t>(r);
                     }
-                    o += static_cast<uint64_t>(r);
+                    if (!ok) break;
                 }
                 std::lock_guard<std::mutex> g(m);
                 if (!ok) failed = true;

@@ -56,6 +56,9 @@ def test_multi_gpu_step_at_world_size_one_self_spawned(hip):
     assert d["n_gpus"] == 1 and d["config"]["allreduce"].split()[0] == "in-line"
     assert d["config"]["allreduce_impl"].startswith("FLAGSTATS_hip_allreduce_counters")
     assert d["config"]["rccl_nranks"] == 1
+    # which RCCL carried it: the shared object that holds the bound ncclAllReduce, and its version
+    lib_info = d["config"]["rccl_library"]
+    assert lib_info and "rccl" in lib_info["path"].lower() and lib_info["version"] > 20000, lib_info
     assert d["parity"].startswith("bit-exact") and d["cpu_baseline"] is None
 
 
