@@ -104,13 +104,13 @@ def report(name, samples, n_flags, ref_note=""):
         print("    first call (the SLOWEST sample), " + slowest["phases"][0], flush=True)
 
 
-def reference_program(path, raw):
+def reference_program(path, raw, evict_path=None):
     """the reference's own binary on the same file (CPU, one thread): wall time of the whole process, best of 2"""
     if not os.path.exists(BENCH_REF):
         return None
     best = None
     for _ in range(2):
-        evict(path)
+        evict(evict_path or path)
         t0 = time.perf_counter()
         r = subprocess.run([BENCH_REF, "decompress", "-i", path, "-D" if raw else "-d"], capture_output=True, text=True)
         t = (time.perf_counter() - t0) * 1e3
@@ -186,16 +186,17 @@ def main():
                 report("%s block file, %.0f MiB" % ({"hc9": "LZ4-HC-c9", "fast": "LZ4-fast-c2", "zstd": "Zstd-c1"}[key], size / 2**20), samples, args.flags, note)
         if "raw" in which:
             per = 1 << 26
-            # (the reference's `decompress` refuses a file whose name does not end in .lz4 / .zst even for its raw modes -R / -D,
-            # benchmark/flagstats.cpp:889-896: the raw file gets such a name)
-            with tempfile.NamedTemporaryFile(suffix=".raw.lz4", dir=tmp) as f:
+            # (the reference's `decompress` refuses an input name that does not end in .lz4 / .zst even for its raw modes -R / -D
+            # (benchmark/flagstats.cpp:889-896), and its raw reader then opens the name cut behind ".bin" (:416-424): the file is
+            # X.bin, the reference is given "X.bin.lz4")
+            with tempfile.NamedTemporaryFile(suffix=".bin", dir=tmp) as f:
                 for at in range(0, args.flags, per):
                     f.write(oracle.generate(oracle.GEN_NA12878, 7, 1, at, min(per, args.flags - at)).tobytes())
                 f.flush()
                 os.fsync(f.fileno())   # written back before the timed reads: a file in the page cache, clean
                 samples = [spawn_oneshot("raw", f.name, env_extra=env_extra) for _ in range(args.samples)]
                 assert all(s["n_flags"] == args.flags for s in samples)
-                ref = reference_program(f.name, raw=True)
+                ref = reference_program(f.name + ".lz4", raw=True, evict_path=f.name)
                 note = " | reference program on this host, same file: %.0f ms [README.md:36: 0.48 s, hardware not stated]" % ref if ref else " [README.md:36: 0.48 s]"
                 report("raw uint16 file, %.0f MiB" % (2 * args.flags / 2**20), samples, args.flags, note)
 
