@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--which", default="u16,python,hc9,fast,zstd,raw")
     ap.add_argument("--env", default="", help="KEY=VALUE[,KEY=VALUE] for the children (A/B of library knobs)")
     ap.add_argument("--gap-s", type=float, default=1.0, help="pause before every fresh process")
+    ap.add_argument("--lazy-init", action="store_true", help="the children do not call FLAGSTATS_hip_init: the first call creates the engine (init_ms then reads 0 and is inside the first call)")
     ap.add_argument("--evict", action="store_true", help="drop the file from the page cache before every sample (the FIRST call then reads the disk; the repeated calls of the same process are warm again)")
     args = ap.parse_args()
     global EVICT, GAP_S
@@ -148,6 +149,8 @@ def main():
     GAP_S = args.gap_s
     which = args.which.split(",")
     env_extra = dict(kv.split("=", 1) for kv in args.env.split(",") if kv)
+    if args.lazy_init:
+        env_extra["ONESHOT_LAZY_INIT"] = "1"
     build_oneshot()
     tmp = os.environ.get("TMPDIR", "/tmp")
     print("one-shot times, %d fresh processes per line; files of %d flags in %s (%s)%s" % (args.samples, args.flags, tmp, "EVICTED from the page cache before every sample" if EVICT else "page cache", " env " + args.env if args.env else ""), flush=True)

@@ -6,6 +6,9 @@
  *   oneshot SPAWN_NS blockfile PATH FLAGSTATS_hip_blockfile (codec by extension)
  *   oneshot SPAWN_NS raw PATH       FLAGSTATS_hip_file_raw
  * optional 4th argument: how many times to repeat the call in the same process (the later calls are the warm ones).
+ * env ONESHOT_LAZY_INIT=1: no FLAGSTATS_hip_init first -- the first call creates the engine itself, as a caller that only
+ * knows the reference's API would have it (the library then opens the file and asks for readahead BEFORE the 90 ms of
+ * runtime initialisation: what a cold page cache gains from).
  * Links libflagstats_hip.so directly: gcc -O2 oneshot.c -I../../include -L../../libflagstats_amd -lflagstats_hip -Wl,-rpath,... */
 #include <stdint.h>
 #include <stdio.h>
@@ -42,7 +45,8 @@ int main(int argc, char** argv)
     }
     const double t_input = now_ms();
     FLAGSTATS_hip_set("on_error", 0);
-    int rc = FLAGSTATS_hip_init(0); /* hipInit, device selection, the default engine (streams, staging, counters) */
+    const char* lazy = getenv("ONESHOT_LAZY_INIT");
+    int rc = (lazy && atoi(lazy)) ? 0 : FLAGSTATS_hip_init(0); /* hipInit, device selection, the default engine (streams, staging, counters) */
     const double t_init = now_ms();
     if (rc) return fprintf(stderr, "init failed: %s\n", FLAGSTATS_hip_last_error()), 1;
     printf("{\"mode\": \"%s\", \"since_spawn_at_main_ms\": %.3f, \"input_ms\": %.3f, \"init_ms\": %.3f, \"calls_ms\": [", mode, t_main - t_spawn, t_input - t_main,

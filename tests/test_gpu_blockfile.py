@@ -578,3 +578,26 @@ def test_a_header_that_declares_more_than_its_payload_can_decode_to_is_refused(h
                     entry(bad, 1)
             finally:
                 assert hip.FLAGSTATS_hip_set(knob, 2) == 0
+
+
+def test_file_mode_ring_of_other_shapes_and_the_hipHostMalloc_fallback(gpu_decoder, tmp_path, monkeypatch):
+    """File mode reads into a ring of page-locked spans (four of 16 MiB: registered huge pages the readers touch themselves).
+    Other ring shapes (two 1 MiB spans: every span boundary inside a block; eight spans) and the fallback allocator
+    (FLAGSTATS_HIP_HOST_ALLOC=malloc: plain hipHostMalloc, what a system without transparent huge pages or with a runtime that
+    refuses the registration gets) must give the same counters; a ring that grows is re-made."""
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_NA12878, 91, 1, 0, 512000 * 21 + 7)
+    path = tmp_path / "ring.lz4"
+    bt.write_block_file(path, flags, mode="hc", level=4)
+    want, n = expect(flags, bt.BLOCK_BYTES)
+    for spans, mib, alloc in ((2, 1, None), (8, 1, None), (3, 2, "malloc"), (5, 4, "malloc"), (4, 16, None)):
+        monkeypatch.setenv("FLAGSTATS_HIP_GPU_SPANS", str(spans))
+        monkeypatch.setenv("FLAGSTATS_HIP_GPU_SPAN_MIB", str(mib))
+        if alloc:
+            monkeypatch.setenv("FLAGSTATS_HIP_HOST_ALLOC", alloc)
+        else:
+            monkeypatch.delenv("FLAGSTATS_HIP_HOST_ALLOC", raising=False)
+        for threads in (1, 0):
+            got, st = blockfile.flagstat_lz4_file(str(path), threads)
+            assert st["gpu_decode"] == 1 and st["n_flags"] == n and np.array_equal(got, want), (spans, mib, alloc, threads)
