@@ -660,9 +660,10 @@ int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_
         return fsint::fail_text("cannot stat file");
     }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
-    // (a file that is not in the page cache yet starts coming in NOW, while the first call of a process still creates its engine:
-    // the HIP runtime's initialisation alone takes 50-70 ms, profiles/r05/cold_start.log)
-    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_WILLNEED);
+    // (POSIX_FADV_WILLNEED here -- so that a file that is not in the page cache starts coming in while the first call of a process
+    // still creates its engine -- was measured and does not pay: one-shot processes without an explicit init, file evicted before
+    // every sample: 204 ms against 178 for the README-size HC-9 file, 333 against 319 for the raw file; the advice walks / queues the
+    // whole file on the calling thread first: profiles/r05/cold_start_evicted_lazy_init.log)
     // File mode: every worker preads the compressed payload of its block into a private buffer (30 % of
     // the decoders' CPU time).  FLAGSTATS_HIP_BLOCK_IO=mmap decodes straight out of a read-only mapping
     // instead (each worker populates its own block's pages with one madvise): built and measured SLOWER
@@ -787,9 +788,10 @@ int file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats, 
         return fsint::fail_text("cannot stat file");
     }
     (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
-    // (a file that is not in the page cache yet starts coming in NOW, while the first call of a process still creates its engine:
-    // the HIP runtime's initialisation alone takes 50-70 ms, profiles/r05/cold_start.log)
-    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_WILLNEED);
+    // (POSIX_FADV_WILLNEED here -- so that a file that is not in the page cache starts coming in while the first call of a process
+    // still creates its engine -- was measured and does not pay: one-shot processes without an explicit init, file evicted before
+    // every sample: 204 ms against 178 for the README-size HC-9 file, 333 against 319 for the raw file; the advice walks / queues the
+    // whole file on the calling thread first: profiles/r05/cold_start_evicted_lazy_init.log)
     fsint::Engine* eng = fsint::default_engine();
     Source in;
     in.fd = fd;
