@@ -345,7 +345,12 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         // 1536 frames then: what the chain kernel holds at a time) -- a frame takes ~6 ms through the four kernels whatever
         // else runs, so few large launches, two of them in flight; the stash, records, literals and checkpoints between the
         // kernels take 8.5 MB of scratch per frame and decode stream
-        npieces = static_cast<uint32_t>((blocks.size() + 1023) / 1024);
+        // (r05, profiles/r05/zstd_pieces_by_size.log: up to ~2400 frames a share of 800 is the better cut -- 1611 frames, the README's
+        // file: three pieces 16.5 ms, two 17.9; 2098 frames: three 21.0, two 25.1, four 22.3; 1049 frames: two 13.5, three 14.6 --
+        // what is exposed behind the last copy is the last piece's way through the four kernels, and a chain launch lasts 3 ms
+        // however few frames it holds; 4195 frames: four or five pieces 35.9-36.1, six 37.2)
+        const uint64_t share = blocks.size() <= 2400 ? 800 : 1024;
+        npieces = static_cast<uint32_t>((blocks.size() + share - 1) / share);
         if (npieces < 2) npieces = 2;
     } else if (kernel == fsk::LZ4K_WORKGROUP) {
         uint64_t per = blocks.size() / 16;
