@@ -331,6 +331,14 @@ def test_gpu_zstd_decoder_takes_frames_of_many_small_blocks(zgpu):
         if takes:
             got, st = blockfile.flagstat_zstd_image(img, 2)
             assert st["gpu_decode"] == 1 and np.array_equal(got, want), every
+            if every == 1024:
+                # ... the same with every frame in a segment of its own: each segment makes its own second pass
+                os.environ["FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES"] = "1000"
+                try:
+                    got, st = blockfile.flagstat_zstd_image(img, 2)
+                finally:
+                    del os.environ["FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES"]
+                assert st["gpu_decode"] == 1 and np.array_equal(got, want)
         else:
             with pytest.raises(_lib.FlagstatsHipError):
                 blockfile.flagstat_zstd_image(img, 2)
