@@ -56,7 +56,7 @@ struct PhaseClock {
     using clk = std::chrono::steady_clock;
     bool on = false;
     clk::time_point last;
-    double index = 0, meminfo = 0, streams = 0, alloc_comp = 0, alloc_out = 0, alloc_small = 0, alloc_scratch = 0, preset = 0, pinned = 0, queue = 0, wait = 0;
+    double index = 0, meminfo = 0, streams = 0, alloc_comp = 0, alloc_out = 0, alloc_out_own = 0, alloc_small = 0, alloc_scratch = 0, preset = 0, pinned = 0, queue = 0, wait = 0;
     void start()
     {
         const char* k = std::getenv("FLAGSTATS_HIP_GPU_DECODE_TIMES");
@@ -197,8 +197,32 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             maker_rc = lz4_gpu_streams(e, in.codec);
             if (maker_rc) maker_err = last_error_text();
         });
+    // The decoded buffer is not needed before the first decode launch, and on some hosts a hipMalloc of a gigabyte and more takes
+    // 30 ms where it takes 0.03 on others (profiles/r05/cold_start_exit.log: 1.6 GB, every fresh process of that box): when it
+    // has to be made it is made on a thread of its own, beside the index upload, the first reads and the first copies.
+    std::thread out_maker;
+    uint8_t* d_out = nullptr;   // (known once join_streams / join_out has returned 0)
+    int out_rc = 0;   // 0, kLz4GpuNoMemory, or -1 with out_err
+    std::string out_err;
+    Joiner out_joiner{out_maker};
     bool streams_wait_index = false;   // the decode streams still have to be told to wait for the index (event 3)
+    auto join_out = [&]() -> int {
+        if (out_maker.joinable()) {
+            pc_.lap(pc_.queue);
+            out_maker.join();
+            pc_.lap(pc_.alloc_out);   // (only what the call WAITED for it)
+        }
+        if (out_rc) {
+            const int r = out_rc;
+            out_rc = 0;
+            return r == kLz4GpuNoMemory ? r : fail_again(out_err.c_str(), r);
+        }
+        d_out = e.lz4_buf[1];
+        return 0;
+    };
     auto join_streams = [&]() -> int {
+        const int orc = join_out();
+        if (orc) return orc;
         if (maker.joinable()) {
             pc_.lap(pc_.queue);
             maker.join();
@@ -221,6 +245,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     // everything queued so far must be over before an error leaves (the buffers may be released by the caller)
     auto settle = [&] {
         if (maker.joinable()) maker.join();
+        if (out_maker.joinable()) out_maker.join();
         (void)hipStreamSynchronize(s);
         for (hipStream_t x : e.lz4_stream)
             if (x) (void)hipStreamSynchronize(x);
@@ -241,24 +266,50 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     uint64_t grain = 64ull << 20;
     if (const char* gk = std::getenv("FLAGSTATS_HIP_GPU_BUFFER_GRAIN"))
         if (std::strtoull(gk, nullptr, 0) >= 16) grain = std::strtoull(gk, nullptr, 0);
-    for (int i = 0; i < 2; ++i)
-        if (e.lz4_cap[i] < want[i]) {
-            uint8_t* old = e.lz4_buf[i];
-            e.lz4_buf[i] = nullptr;
-            e.lz4_cap[i] = 0;
-            if (old) LZG_TRY(hipFree(old));
-            const uint64_t cap = (want[i] + grain - 1) / grain * grain;
-            const hipError_t e_ = hipMalloc(&e.lz4_buf[i], cap);
-            if (e_ != hipSuccess) {
-                (void)hipGetLastError();
-                e.lz4_buf[i] = nullptr;
-                return kLz4GpuNoMemory;
+    auto grow = [&e, grain](int i, uint64_t bytes_wanted, std::string& err_text) -> int {   // 0, kLz4GpuNoMemory, -1 (err_text)
+        uint8_t* old = e.lz4_buf[i];
+        e.lz4_buf[i] = nullptr;
+        e.lz4_cap[i] = 0;
+        if (old) {
+            const hipError_t f_ = hipFree(old);
+            if (f_ != hipSuccess) {
+                fail_hip("hipFree(decoder buffer)", f_);
+                err_text = last_error_text();
+                return -1;
             }
-            e.lz4_cap[i] = cap;
-            pc_.lap(i ? pc_.alloc_out : pc_.alloc_comp);
         }
+        const uint64_t cap = (bytes_wanted + grain - 1) / grain * grain;
+        const hipError_t e_ = hipMalloc(&e.lz4_buf[i], cap);
+        if (e_ != hipSuccess) {
+            (void)hipGetLastError();
+            e.lz4_buf[i] = nullptr;
+            return kLz4GpuNoMemory;
+        }
+        e.lz4_cap[i] = cap;
+        return 0;
+    };
+    if (e.lz4_cap[1] < want[1])
+        out_maker = std::thread([&] {
+            DeviceGuard g2(e.device);
+            if (!g2.ok()) {
+                out_err = last_error_text();
+                out_rc = -1;
+                return;
+            }
+            const PhaseClock::clk::time_point t0 = PhaseClock::clk::now();
+            out_rc = grow(1, want[1], out_err);
+            pc_.alloc_out_own += std::chrono::duration<double, std::milli>(PhaseClock::clk::now() - t0).count();   // (read after the join)
+        });
+    if (e.lz4_cap[0] < want[0]) {
+        std::string text;
+        rc = grow(0, want[0], text);
+        if (rc) {
+            settle();
+            return rc;   // (kLz4GpuNoMemory, or the error of a hipFree: message set)
+        }
+        pc_.lap(pc_.alloc_comp);
+    }
     uint8_t* const d_comp = e.lz4_buf[0];
-    uint8_t* const d_out = e.lz4_buf[1];
     // blocks | status | tally in one small allocation that grows with the largest segment seen
     const uint64_t off_status = (blocks.size() * sizeof(fsk::GpuBlock) + 255) & ~255ull;
     const uint64_t off_tally = (off_status + blocks.size() * sizeof(uint32_t) + 255) & ~255ull;
@@ -296,7 +347,14 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
     pre_lap(0);
     LZG_TRY(hipEventRecord(e.lz4_ev[0], s));
     pre_lap(1);
-    if (ragged) LZG_TRY(hipMemsetAsync(d_out, 0, dpos + 16, s));
+    if (ragged) {
+        rc = join_out();
+        if (rc) {
+            settle();
+            return rc;
+        }
+        LZG_TRY(hipMemsetAsync(d_out, 0, dpos + 16, s));
+    }
     LZG_TRY(hipMemsetAsync(d_status, 0xFF, blocks.size() * sizeof(uint32_t), s));
     LZG_TRY(hipMemsetAsync(d_tally, 0, fsk::kLz4TallyWords * 8, s));
     LZG_TRY(hipMemsetAsync(e.d_out[0], 0, 32 * sizeof(uint64_t), s));
@@ -931,10 +989,10 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
     if (pc.on) {
         double keep_rule = 0;
         pc.lap(keep_rule);
-        std::fprintf(stderr, "gpu decode, host side (ms): index %.2f | device memory query %.2f | streams + events %.2f | hipMalloc compressed %.2f, decoded %.2f, "
+        std::fprintf(stderr, "gpu decode, host side (ms): index %.2f | device memory query %.2f | streams + events %.2f | hipMalloc compressed %.2f, decoded %.2f waited for (%.2f on its own thread), "
                              "index %.2f, scratch %.2f | presets + index upload queued %.2f | pinned ring %.2f | reading + queueing the pieces %.2f | waiting for the device %.2f | keep rule %.2f | "
                              "call %.2f (stream events: copies %.2f, decode behind the last copy %.2f, K1 %.2f)\n",
-                     pc.index, pc.meminfo, pc.streams, pc.alloc_comp, pc.alloc_out, pc.alloc_small, pc.alloc_scratch, pc.preset, pc.pinned, pc.queue, pc.wait, keep_rule,
+                     pc.index, pc.meminfo, pc.streams, pc.alloc_comp, pc.alloc_out, pc.alloc_out_own, pc.alloc_small, pc.alloc_scratch, pc.preset, pc.pinned, pc.queue, pc.wait, keep_rule,
                      stats->wall_s * 1e3, stats->h2d_ms, stats->decode_ms, stats->count_ms);
     }
     return 0;

@@ -56,7 +56,11 @@ def evict(path):
 GAP_S = 1.0
 
 
-def spawn_oneshot(mode, arg, calls=3, env_extra=None):
+CALLS = 3
+
+
+def spawn_oneshot(mode, arg, calls=None, env_extra=None):
+    calls = CALLS if calls is None else calls
     env = dict(os.environ, FLAGSTATS_HIP_GPU_DECODE_TIMES="1", FLAGSTATS_HIP_INIT_TIMES="1")
     env.update(env_extra or {})
     evict(arg)
@@ -66,8 +70,13 @@ def spawn_oneshot(mode, arg, calls=3, env_extra=None):
     t_exit = time.clock_gettime_ns(time.CLOCK_MONOTONIC)
     if r.returncode:
         raise RuntimeError("oneshot %s %s failed: %s" % (mode, arg, r.stderr[-2000:]))
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    d = {}
+    for ln in r.stdout.splitlines():
+        if ln.startswith("{"):
+            d.update(json.loads(ln))
     d["process_ms"] = (t_exit - t_spawn) * 1e-6
+    d["teardown_ms"] = d["process_ms"] - d.get("main_returns_since_spawn_ms", d["process_ms"])   # return from main -> the parent sees it gone
+    d["shutdown"] = [ln for ln in r.stderr.splitlines() if ln.startswith("oneshot: FLAGSTATS_hip_shutdown")]
     d["phases"] = [ln for ln in r.stderr.splitlines() if ln.startswith("gpu decode, host side")]
     d["ring"] = [ln for ln in r.stderr.splitlines() if ln.startswith("gpu decode, pinned ring") or ln.startswith("gpu decode, presets")]
     d["init_phases"] = [ln for ln in r.stderr.splitlines() if ln.startswith("engine creation")]
@@ -87,11 +96,15 @@ def report(name, samples, n_flags, ref_note=""):
                                  med([s["input_ms"] for s in samples]), med([s["init_ms"] for s in samples]), med(first)))
     if warm:
         line += " | the same call again in that process %.1f ms: first / warm = %.2fx" % (med(warm), med(first) / med(warm))
-    line += " | whole process %.1f ms | %.2f Gflags/s one-shot" % (med([s["process_ms"] for s in samples]), n_flags / med(ready) / 1e6)
+    line += " | whole process (%d call%s) %.1f ms, of which return from main -> process gone %.1f | %.2f Gflags/s one-shot" % (
+        len(samples[0]["calls_ms"]), "" if len(samples[0]["calls_ms"]) == 1 else "s", med([s["process_ms"] for s in samples]), med([s["teardown_ms"] for s in samples]),
+        n_flags / med(ready) / 1e6)
     print(line + ref_note, flush=True)
     print("    every sample: start -> counters %s ms; first call %s ms" % (" ".join("%.0f" % x for x in ready), " ".join("%.0f" % x for x in first)), flush=True)
     typical = min(samples, key=lambda s: abs(s["calls_ms"][0] - med(first)))
     slowest = max(samples, key=lambda s: s["calls_ms"][0])
+    if typical.get("shutdown"):
+        print("    " + typical["shutdown"][0], flush=True)
     if typical.get("init_phases"):
         print("    " + typical["init_phases"][0], flush=True)
     if typical["phases"]:
@@ -140,11 +153,13 @@ def main():
     ap.add_argument("--samples", type=int, default=5)
     ap.add_argument("--which", default="u16,python,hc9,fast,zstd,raw")
     ap.add_argument("--env", default="", help="KEY=VALUE[,KEY=VALUE] for the children (A/B of library knobs)")
+    ap.add_argument("--calls", type=int, default=3, help="calls per fresh process (1: the one-shot program itself; the whole-process time is then the reference's measure)")
     ap.add_argument("--gap-s", type=float, default=1.0, help="pause before every fresh process")
     ap.add_argument("--lazy-init", action="store_true", help="the children do not call FLAGSTATS_hip_init: the first call creates the engine (init_ms then reads 0 and is inside the first call)")
     ap.add_argument("--evict", action="store_true", help="drop the file from the page cache before every sample (the FIRST call then reads the disk; the repeated calls of the same process are warm again)")
     args = ap.parse_args()
-    global EVICT, GAP_S
+    global EVICT, GAP_S, CALLS
+    CALLS = args.calls
     EVICT = args.evict
     GAP_S = args.gap_s
     which = args.which.split(",")

@@ -6,6 +6,9 @@
  *   oneshot SPAWN_NS blockfile PATH FLAGSTATS_hip_blockfile (codec by extension)
  *   oneshot SPAWN_NS raw PATH       FLAGSTATS_hip_file_raw
  * optional 4th argument: how many times to repeat the call in the same process (the later calls are the warm ones).
+ * env ONESHOT_EXIT=shutdown: FLAGSTATS_hip_shutdown() before main returns (timed, on stderr); =fast: _exit(0) after the output is
+ * flushed -- no atexit handlers, neither the HIP runtime's nor anybody's; unset: return from main.  The parent sees when the
+ * process is gone, so "return from main -> process gone" is what the runtime's and the driver's teardown cost.
  * env ONESHOT_LAZY_INIT=1: no FLAGSTATS_hip_init first -- the first call creates the engine itself, as a caller that only
  * knows the reference's API would have it (the library then opens the file and asks for readahead BEFORE the 90 ms of
  * runtime initialisation: what a cold page cache gains from).
@@ -15,6 +18,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
+#include <unistd.h>
 
 #include "libflagstats_hip.h"
 
@@ -76,6 +80,15 @@ int main(int argc, char** argv)
     for (int k = 0; k < 32; ++k) sum += out[k] * (unsigned long long)(k + 1);
     printf("], \"counters_ready_since_spawn_ms\": %.3f, \"n_flags\": %llu, \"gpu_decode\": %d, \"checksum\": %llu}\n", t_first_done - t_spawn,
            (unsigned long long)(flags ? n : st.n_flags), (int)st.gpu_decode, sum);
+    const char* how = getenv("ONESHOT_EXIT");
+    if (how && !strcmp(how, "shutdown")) {
+        const double t0 = now_ms();
+        FLAGSTATS_hip_shutdown();
+        fprintf(stderr, "oneshot: FLAGSTATS_hip_shutdown %.3f ms\n", now_ms() - t0);
+    }
+    printf("{\"main_returns_since_spawn_ms\": %.3f}\n", now_ms() - t_spawn);
     fflush(stdout);
+    fflush(stderr);
+    if (how && !strcmp(how, "fast")) _exit(0);
     return 0;
 }
