@@ -279,7 +279,9 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             }
         }
         const uint64_t cap = (bytes_wanted + grain - 1) / grain * grain;
-        const hipError_t e_ = hipMalloc(&e.lz4_buf[i], cap);
+        // (env FLAGSTATS_HIP_GPU_OUT_CAP: tests make requests for the DECODED buffer above it fail, as a full device would)
+        const char* ock = i == 1 ? std::getenv("FLAGSTATS_HIP_GPU_OUT_CAP") : nullptr;
+        const hipError_t e_ = ock && cap > std::strtoull(ock, nullptr, 0) ? hipErrorOutOfMemory : hipMalloc(&e.lz4_buf[i], cap);
         if (e_ != hipSuccess) {
             (void)hipGetLastError();
             e.lz4_buf[i] = nullptr;

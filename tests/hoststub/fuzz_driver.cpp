@@ -39,6 +39,7 @@ static uint64_t rnd()
 static uint64_t below(uint64_t n) { return n ? rnd() % n : 0; }
 
 static long g_fail = 0;
+static long g_refused = 0, g_refused_host = 0;   // path 6: calls made, calls that the host threads took
 #define CHECK(cond, ...)                                              \
     do {                                                              \
         if (!(cond)) {                                                \
@@ -265,14 +266,22 @@ static int run_blockfile_input(bool zstd, const Bytes& img, bool valid, const ui
     }
     const bool huge = max_us > (8ull << 20);   // (beyond the chunk buffer the host pipeline refuses what the GPU path may take)
     const char* pm = std::getenv("FUZZ_PATHS");
-    for (int path = 0; path < 6; ++path) {
+    for (int path = 0; path < 7; ++path) {
         if (pm && !std::strchr(pm, '0' + path)) continue;
         // 0 host threads / image, 1 GPU path / image, 2 GPU path / file, 3 host threads / file, 4 GPU path / image / small segments,
-        // 5 GPU path / file / odd pieces + small segments
+        // 5 GPU path / file / odd pieces + small segments, 6 decoder chosen by size / image or file / the device "cannot hold" the decoded
+        // buffer (found out on the allocation's own thread, with copies already queued): the host threads take the file
         if (path >= 2 && below(3) && !(path == 2 && input_no % 4 == 0)) continue;   // the file and segment paths on a third of the inputs
         if (huge && path != 1 && path != 2) continue;
-        FLAGSTATS_hip_set(knob, (path == 0 || path == 3) ? 0 : 1);
-        if (path >= 4) {
+        if (path == 6 && input_no % 8 != 3) continue;
+        FLAGSTATS_hip_set(knob, (path == 0 || path == 3) ? 0 : (path == 6 ? 2 : 1));
+        const bool p6_file = path == 6 && below(2);
+        if (path == 6) {
+            FLAGSTATS_hip_set(zstd ? "zstd_gpu_min_bytes" : "lz4_gpu_min_bytes", 1);
+            FLAGSTATS_hip_set("lz4_gpu_keep_bytes", 0);   // (nothing kept from the input before: the buffer has to be asked for)
+            setenv("FLAGSTATS_HIP_GPU_OUT_CAP", "1", 1);
+        }
+        if (path == 4 || path == 5) {
             setenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES", below(2) ? "1" : std::to_string(1 + below(200000)).c_str(), 1);
             if (path == 5) setenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS", std::to_string(1 + below(9)).c_str(), 1);
         }
@@ -280,7 +289,7 @@ static int run_blockfile_input(bool zstd, const Bytes& img, bool valid, const ui
         for (int k = 0; k < 32; ++k) v.out[k] = kPreset + static_cast<uint64_t>(k);
         const int threads = static_cast<int>(below(6));
         FLAGSTATS_blockfile_stats st;
-        if (path == 2 || path == 3 || path == 5) {
+        if (path == 2 || path == 3 || path == 5 || p6_file) {
             if (!file_written) write_file(img, zstd ? ".zst" : ".lz4");
             file_written = true;
             v.rc = below(2) ? FLAGSTATS_hip_blockfile(g_path.c_str(), threads, v.out, &st)
@@ -290,11 +299,19 @@ static int run_blockfile_input(bool zstd, const Bytes& img, bool valid, const ui
             Bytes copy(img);
             v.rc = zstd ? FLAGSTATS_hip_blockimage_zstd(copy.data(), copy.size(), threads, v.out, &st) : FLAGSTATS_hip_blockimage_lz4(copy.data(), copy.size(), threads, v.out, &st);
         }
-        if (path >= 4) {
+        if (path == 6) {
+            unsetenv("FLAGSTATS_HIP_GPU_OUT_CAP");
+            FLAGSTATS_hip_set(zstd ? "zstd_gpu_min_bytes" : "lz4_gpu_min_bytes", 64ull << 20);
+            FLAGSTATS_hip_set("lz4_gpu_keep_bytes", ~0ull);
+            // (a buffer kept from the input before may be large enough: then nothing is asked for and the GPU decoder runs)
+            ++g_refused;
+            if (v.rc == 0 && st.gpu_decode == 0) ++g_refused_host;
+        }
+        if (path == 4 || path == 5) {
             unsetenv("FLAGSTATS_HIP_GPU_LZ4_SEGMENT_BYTES");
             unsetenv("FLAGSTATS_HIP_GPU_LZ4_CHUNKS");
         }
-        static const char* const pname[6] = {"host/image", "gpu/image", "gpu/file", "host/file", "gpu/image/segments", "gpu/file/pieces+segments"};
+        static const char* const pname[7] = {"host/image", "gpu/image", "gpu/file", "host/file", "gpu/image/segments", "gpu/file/pieces+segments", "by size/decoded buffer refused"};
         names.push_back(pname[path]);
         got.push_back(v);
         if (v.rc != 0) CHECK(untouched(v.out), "input %ld (%s, damage %d), %s: a failed call changed the caller's counters", input_no, zstd ? "zstd" : "lz4", how, pname[path]);
@@ -481,6 +498,8 @@ int main(int argc, char** argv)
     }
     if (!g_path.empty()) std::remove(g_path.c_str());
     FLAGSTATS_hip_shutdown();
+    if (g_refused >= 100) CHECK(g_refused_host > 0, "the refused decoded buffer never sent a file to the host threads (%ld calls)", g_refused);
+    std::fprintf(stderr, "fuzz_driver: decoded buffer refused in %ld calls, %ld of them valid files that the host threads then took\n", g_refused, g_refused_host);
     std::printf("fuzz_driver: %ld inputs (%ld LZ4 block files, %ld Zstandard, %ld of them undamaged, %ld reference-written; %ld FLAG texts, %ld raw files), %ld calls: %s\n", inputs, n_lz4,
                 n_zstd, n_valid, n_golden, n_text, n_raw, calls, g_fail ? "FAILED" : "all checks passed");
     return g_fail ? 1 : 0;

@@ -601,3 +601,38 @@ def test_file_mode_ring_of_other_shapes_and_the_hipHostMalloc_fallback(gpu_decod
         for threads in (1, 0):
             got, st = blockfile.flagstat_lz4_file(str(path), threads)
             assert st["gpu_decode"] == 1 and st["n_flags"] == n and np.array_equal(got, want), (spans, mib, alloc, threads)
+
+
+@pytest.mark.parametrize("as_file", [False, True], ids=["image", "file"])
+def test_a_decoded_buffer_the_device_cannot_hold_is_found_out_beside_the_copies(gpu_decoder, tmp_path, monkeypatch, as_file):
+    """The decoded buffer is allocated on a thread of its own while the index goes up and the first pieces are read and copied
+    (a 1.6 GB hipMalloc took 30 ms on one host); a refusal therefore arrives with copies already queued.  Forced with the test
+    knob FLAGSTATS_HIP_GPU_OUT_CAP: the forced GPU decoder fails loudly and leaves the caller's counters alone, the decoder
+    chosen by size hands the file to the host threads, and the next call (cap lifted) decodes on the GPU again."""
+    import oracle
+    from libflagstats_amd import blockfile
+    hip = gpu_decoder
+    flags = oracle.generate(oracle.GEN_NA12878, 123, 1, 0, 512000 * 5 + 77)
+    img = bt.block_file_image(flags)
+    want = expect(flags, bt.BLOCK_BYTES)[0]
+    path = tmp_path / "refused.lz4"
+    path.write_bytes(img)
+    call = (lambda: blockfile.flagstat_lz4_file(str(path), 3)) if as_file else (lambda: blockfile.flagstat_lz4_image(img, 3))
+    auto = (1 << 64) - 1
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", 0) == 0      # nothing kept from earlier files: the buffer is asked for anew
+    try:
+        got, st = call()
+        assert st["gpu_decode"] == 1 and np.array_equal(got, want) and hip.FLAGSTATS_hip_get(b"lz4_gpu_kept_bytes") == 0
+        monkeypatch.setenv("FLAGSTATS_HIP_GPU_OUT_CAP", str(1 << 20))
+        with pytest.raises(Exception, match="cannot hold"):
+            call()
+        assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 2) == 0 and hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 1) == 0
+        got, st = call()
+        assert st["gpu_decode"] == 0 and np.array_equal(got, want)
+        monkeypatch.delenv("FLAGSTATS_HIP_GPU_OUT_CAP")
+        got, st = call()
+        assert st["gpu_decode"] == 1 and np.array_equal(got, want)
+    finally:
+        assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 64 << 20) == 0
+        assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0          # (the fixture puts 2 back)
+        assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", auto) == 0
