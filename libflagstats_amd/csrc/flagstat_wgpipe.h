@@ -147,47 +147,52 @@ __device__ void wgpipe_scan(LDS& L, const uint32_t oend, const uint32_t lane, co
         }
         if (lane == 0u) L.s_carry[(kc + 1u) & 7u] = last ? (last & 0x1FFFFu) : carry;
         wg_st(&L.c_ready, kc + 1u);
+        // Per byte: the last marker at or before it (a key in this lane, else the scan's value from the lanes before, else the
+        // carry -- keys carry their position above bit 17, so "the last" is the maximum and the carry is below every key); its low
+        // 16 bits are the distance, 0 for a literal run (kMarkLiteral) and for "nothing yet": such a byte is its own root.
+        static_assert((kMarkLiteral & 0xFFFFu) == 0u, "a literal marker reads as distance 0");
+        const uint32_t before2 = umax(before, carry);
         uint32_t ptr[4], ext[4];
-        bool any_in = false;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const uint32_t kk = k[j] ? k[j] : before;
-            const uint32_t m = kk ? (kk & 0x1FFFFu) : carry;
-            const uint32_t off = m & 0xFFFFu;
+            const uint32_t off = umax(k[j], before2) & 0xFFFFu;
             const uint32_t rel = r0 + static_cast<uint32_t>(j);
-            const bool lit = ((m >> 16) != 0u) | (m == 0u);
-            const bool in = !lit & (off <= rel);
-            any_in |= in;
-            ptr[j] = in ? rel - off : rel;
-            // where a root's byte comes from: itself (a literal an emitter wrote) or the ring at distance off
-            uint32_t s = cidx + rel;
-            if (!lit) s = s >= off ? s - off : s + LDS::kNR - off;
-            ext[j] = s;
+            const uint32_t t = rel - off;                        // (negative: the source lies before this chunk)
+            ptr[j] = static_cast<int32_t>(t) >= 0 ? t : rel;     // inside the chunk: a pointer to chase; else a root
+            // where a root's byte comes from: the ring at distance off (itself for a literal, which an emitter wrote)
+            const uint32_t d = t + cidx;
+            ext[j] = umin(d, d + LDS::kNR);                      // (d < 0 wraps to the ring's end)
         }
-        if (__builtin_amdgcn_ballot_w64(any_in)) {
-            // pointers inside the chunk: chase to the roots, doubling (<= 255 hops -> <= 8 rounds), four byte indices a dword
+        uint32_t p4 = ptr[0] | (ptr[1] << 8) | (ptr[2] << 16) | (ptr[3] << 24);
+        const uint32_t self4 = 0x03020100u + 0x04040404u * lane;
+        const bool any_in = __builtin_amdgcn_ballot_w64(p4 != self4) != 0ull;
+        if (any_in) {
+            // pointers inside the chunk: chase to the roots, doubling (<= 255 hops -> <= 8 rounds), four byte indices a dword.
+            // ds_bpermute takes the lane from address bits 7:2, so a byte index IS the address of the dword that holds it (and what
+            // lies above the byte in the shifted dword is ignored); the four fetched dwords give up their bytes to two v_perm_b32.
             ++n_inchunk;
-            uint32_t p4 = ptr[0] | (ptr[1] << 8) | (ptr[2] << 16) | (ptr[3] << 24);
             for (int round = 0; round < 8; ++round) {
-                uint32_t n[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t t = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(ptr[j] & ~3u), static_cast<int>(p4)));
-                    n[j] = (t >> ((ptr[j] & 3u) * 8u)) & 255u;
-                }
-                const uint32_t n4 = n[0] | (n[1] << 8) | (n[2] << 16) | (n[3] << 24);
+                const uint32_t t0 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(p4), static_cast<int>(p4)));
+                const uint32_t t1 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(p4 >> 8), static_cast<int>(p4)));
+                const uint32_t t2 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(p4 >> 16), static_cast<int>(p4)));
+                const uint32_t t3 = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(static_cast<int>(p4 >> 24), static_cast<int>(p4)));
+                // selectors: byte 0 <- t0[p & 3], byte 1 <- t1[p' & 3] (the first operand's bytes are 4..7), 0x0C = a zero byte
+                const uint32_t s01 = (p4 & 0x00000303u) | 0x0C0C0400u, s23 = (p4 & 0x03030000u) | 0x04000C0Cu;
+                const uint32_t n4 = __builtin_amdgcn_perm(t1, t0, s01) | __builtin_amdgcn_perm(t3, t2, s23);
                 const bool changed = n4 != p4;
                 p4 = n4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) ptr[j] = n[j];
                 if (PROF) ++n_rounds;
                 if (!__builtin_amdgcn_ballot_w64(changed)) break;
             }
+            ptr[0] = p4 & 255u;
+            ptr[1] = (p4 >> 8) & 255u;
+            ptr[2] = (p4 >> 16) & 255u;
+            ptr[3] = p4 >> 24;
         }
         if (!wg_wait_timed<PROF>(L, t_wait, [&] { return c + LDS::kChunk <= wg_ld(&L.d_op) + LDS::kK; })) break;
         const uint32_t base = c & (LDS::kK - 1u);
         *reinterpret_cast<uint4*>(&L.fsrc[base + r0]) = make_uint4(ext[0], ext[1], ext[2], ext[3]);
-        if (__builtin_amdgcn_ballot_w64(any_in)) {
+        if (any_in) {
             const uint4 f = make_uint4(L.fsrc[base + ptr[0]], L.fsrc[base + ptr[1]], L.fsrc[base + ptr[2]], L.fsrc[base + ptr[3]]);
             asm volatile("" ::: "memory");  // (every lane's reads are one instruction each, all before this write)
             *reinterpret_cast<uint4*>(&L.fsrc[base + r0]) = f;

@@ -1507,13 +1507,16 @@ static_assert(kZxThreads == 512, "two waves per SIMD: the second workgroup of a 
 // ---- emitters: records -> markers, literal bytes.  Emitter `which` takes the batches (64 records, one checkpoint)
 // which, which + kZxEmit, ...; a checkpoint carries the batch's output and literal positions, so the emitters do not depend
 // on each other.  Records and the first 256 literal bytes of a batch are loaded one batch ahead, checkpoints two.
+#ifndef FLAGSTAT_ZSTD_FAR_SCOPE
+#define FLAGSTAT_ZSTD_FAR_SCOPE "sc0"
+#endif
 template <bool PROF>
 __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* __restrict__ recs, const uint8_t* __restrict__ lits,
                         const uint32_t lit_cap, const uint8_t* __restrict__ dst, const uint32_t nslots, const uint32_t oend, const uint32_t lane,
                         const uint32_t which, unsigned long long* __restrict__ tally)
 {
     uint32_t err = 0, s_seen = 0, d_seen = 0, f_seen = 0, nfar = 0;
-    unsigned long long t_wait = 0, n_groups = 0, n_batches = 0;
+    unsigned long long t_wait = 0, n_groups = 0, n_batches = 0, n_long = 0, n_far_rounds = 0, n_short = 0, n_far_groups = 0, t_pre = 0, t_mark = 0, t_long = 0, t_far = 0;
     const unsigned long long t_begin = PROF ? __builtin_readcyclecounter() : 0ull;
     auto room = [&](uint32_t at, uint32_t nbytes) -> bool {
         if (__builtin_expect(at + nbytes <= s_seen + ZxLds::kMR && at + nbytes <= d_seen + ZxLds::kAhead, 1)) return true;
@@ -1536,17 +1539,24 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
         return c.z && at + 4u <= lit_cap ? *reinterpret_cast<const uint32_t*>(lits + at) : 0u;
     };
     uint4 c0 = load_ck(which), c1 = load_ck(which + kZxEmit);
-    uint64_t rec0 = which < nslots && lane < c0.z ? recs[static_cast<uint64_t>(which) * 64u + lane] : 0ull;
+    uint64_t rec0 = which < nslots && lane < c0.z ? recs[which * 64u + lane] : 0ull;
     uint32_t lit0 = load_lit(c0);
     wg_st(&L.e_pos[which], c0.x);
     for (uint32_t g = which; g < nslots; g += kZxEmit) {
         // loads for the next two batches first
         const uint4 c2 = load_ck(g + 2u * kZxEmit);
-        const uint64_t rec1 = g + kZxEmit < nslots && lane < c1.z ? recs[static_cast<uint64_t>(g + kZxEmit) * 64u + lane] : 0ull;
-        const uint32_t lit1 = load_lit(c1);
+        // (the next batch's records and literal bytes are asked for behind this batch's own arithmetic, just before its stores and
+        // far loads: issued at the top, the compiler made the batch wait for them there -- a memory latency a batch)
+        uint64_t rec1 = 0ull;
+        uint32_t lit1 = 0u;
+        auto prefetch = [&] {
+            rec1 = g + kZxEmit < nslots && lane < c1.z ? recs[(g + kZxEmit) * 64u + lane] : 0ull;
+            lit1 = load_lit(c1);
+        };
         const uint32_t nvalid = c0.z;
         if (nvalid) {
             ++n_batches;
+            const unsigned long long tb0 = PROF ? __builtin_readcyclecounter() : 0ull;
             const bool valid = lane < nvalid;
             const uint32_t w0 = static_cast<uint32_t>(rec0), w1 = static_cast<uint32_t>(rec0 >> 32);
             const uint32_t ll = valid ? w1 & 16383u : 0u, ml = valid ? (w1 >> 14) & 16383u : 0u, off = w0 & 0x3FFFFFFFu;
@@ -1574,8 +1584,10 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
             // much, not across the end of the ring
             const bool shortlit = valid & (ll >= 1u) & (ll <= 4u) & (ll + ml >= 4u) & (a + 4u <= 252u) & (ri + 4u <= ZxLds::kNR);
             const bool longlit = valid & (ll >= 1u) & !shortlit;
+            prefetch();
             uint32_t lo = 0;  // records [0, lo) of the batch are done
             bool failed = false;
+            if (PROF) t_pre += __builtin_readcyclecounter() - tb0;
             while (lo < nvalid) {
                 ++n_groups;
                 // the records [lo, hi) whose output fits one publication
@@ -1640,6 +1652,7 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
                     failed = true;
                     break;
                 }
+                const unsigned long long tm0 = PROF ? __builtin_readcyclecounter() : 0ull;
                 const bool now = valid & (lane >= lo) & (lane < hi);
                 // markers: a near match at its first byte, "literal" where this record's own bytes start
                 if (now & (ml > 0u) & !far) L.mark[mpos & (ZxLds::kMR - 1u)] = off;
@@ -1647,15 +1660,22 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
                 if (now & shortlit) __builtin_memcpy(&L.ring[ri], &lit4, 4);
                 // longer literal runs: the whole wave, run after run
                 uint64_t lm = __builtin_amdgcn_ballot_w64(now & longlit);
+                const unsigned long long tm1 = PROF ? __builtin_readcyclecounter() : 0ull;
+                if (PROF) t_mark += tm1 - tm0;
+                if (PROF) n_short += static_cast<unsigned long long>(__builtin_popcountll(__builtin_amdgcn_ballot_w64(now & shortlit)));
                 while (lm) {
                     const uint32_t j = static_cast<uint32_t>(__builtin_ctzll(lm));
                     lm &= lm - 1ull;
                     const uint32_t r_ll = __builtin_amdgcn_readlane(ll, j), r_op = __builtin_amdgcn_readlane(op, j), r_lp = __builtin_amdgcn_readlane(lp, j);
                     for (uint32_t b = lane; b < r_ll; b += 64u) L.ring[ring_at(r_op + b)] = lits[r_lp + b];
+                    if (PROF) ++n_long;
                 }
+                const unsigned long long tm2 = PROF ? __builtin_readcyclecounter() : 0ull;
+                if (PROF) t_long += tm2 - tm1;
                 // far matches: every lane its own, read from the flushed output (device-scope loads, past the L1)
                 const uint64_t fm = __builtin_amdgcn_ballot_w64(now & far);
                 if (fm) {
+                    if (PROF) ++n_far_groups;
                     nfar += static_cast<uint32_t>(__builtin_popcountll(fm));
                     const uint32_t src = mpos - off;
                     uint32_t src_end = (now & far) ? src + ml : 0u;
@@ -1679,36 +1699,54 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
                     // inside the output buffer and not used), stored whole where the match has them and the ring does not wrap,
                     // as bytes otherwise.
                     for (uint32_t b = 0;; b += 16u) {
+                        if (PROF) ++n_far_rounds;
                         uint32_t u0, u1, u2, u3;
-                        asm volatile("global_load_dword %0, %4, off sc0 sc1\n\t"
-                                     "global_load_dword %1, %4, off offset:4 sc0 sc1\n\t"
-                                     "global_load_dword %2, %4, off offset:8 sc0 sc1\n\t"
-                                     "global_load_dword %3, %4, off offset:12 sc0 sc1\n\t"
+                        asm volatile("global_load_dword %0, %4, off " FLAGSTAT_ZSTD_FAR_SCOPE "\n\t"
+                                     "global_load_dword %1, %4, off offset:4 " FLAGSTAT_ZSTD_FAR_SCOPE "\n\t"
+                                     "global_load_dword %2, %4, off offset:8 " FLAGSTAT_ZSTD_FAR_SCOPE "\n\t"
+                                     "global_load_dword %3, %4, off offset:12 " FLAGSTAT_ZSTD_FAR_SCOPE "\n\t"
                                      "s_waitcnt vmcnt(0)"
                                      : "=&v"(u0), "=&v"(u1), "=&v"(u2), "=&v"(u3)
                                      : "v"(sp)
                                      : "memory");
                         const bool live = fl & (b < ml);
-                        const bool whole = rm + b + 16u <= ZxLds::kNR;
+                        const bool whole = rm + b + 16u <= ZxLds::kNR;   // (the sixteen bytes of this round lie in the ring without a wrap)
+                        const uint32_t left = live ? ml - b : 0u;        // bytes of the match still to be stored
                         const uint32_t uu[4] = {u0, u1, u2, u3};
+                        if (__builtin_expect(__builtin_amdgcn_ballot_w64(live & !whole) != 0ull, 0)) {
+                            // across the ring's end (one round in 2,300): byte by byte
+                            if (live & !whole) {
 #pragma unroll
-                        for (uint32_t k = 0; k < 4u; ++k) {
-                            const uint32_t u = uu[k];
-                            const uint32_t at = b + 4u * k;
-                            if (live & whole & (at + 4u <= ml)) __builtin_memcpy(&L.ring[rm + at], &u, 4);
-                            if (live & (at < ml) & !(whole & (at + 4u <= ml))) {
-                                for (uint32_t x = 0; x < 4u && at + x < ml; ++x) L.ring[ring_at(mpos + at + x)] = static_cast<uint8_t>(u >> (8u * x));
+                                for (uint32_t x = 0; x < 16u; ++x)
+                                    if (x < left) L.ring[ring_at(mpos + b + x)] = static_cast<uint8_t>(uu[x >> 2] >> (8u * (x & 3u)));
                             }
                         }
+                        // whole dwords where the match has them, then what is left of it below a dword: two bytes and / or one.
+                        // (Byte stores only where they must be: the byte behind the match is the next record's, maybe another emitter's.)
+                        const bool lw = live & whole;
+                        uint8_t* const at = &L.ring[rm + b];
+#pragma unroll
+                        for (uint32_t k = 0; k < 4u; ++k)
+                            if (lw & (left >= 4u * k + 4u)) __builtin_memcpy(at + 4u * k, &uu[k], 4);
+                        const uint32_t tk = left >> 2;   // the dword the tail lies in (< 4 when there is one)
+                        const uint32_t ut = tk == 0u ? u0 : (tk == 1u ? u1 : (tk == 2u ? u2 : u3));
+                        const bool tail = lw & (left < 16u);
+                        if (tail & ((left & 2u) != 0u)) {
+                            const uint16_t h = static_cast<uint16_t>(ut);
+                            __builtin_memcpy(at + (left & ~3u), &h, 2);
+                        }
+                        if (tail & ((left & 1u) != 0u)) at[(left & ~3u) + (left & 2u)] = static_cast<uint8_t>(ut >> (8u * (left & 2u)));
                         if (!__builtin_amdgcn_ballot_w64(fl & (b + 16u < ml))) break;
                         sp += (fl & (b + 16u < ml)) ? 16 : 0;   // (a lane that is done stays where it is: inside the buffer)
                     }
                 }
+                if (PROF) t_far += __builtin_readcyclecounter() - tm2;
                 lo = hi;
                 wg_st(&L.e_pos[which], lo < nvalid ? c0.x + span_end : c1.x);
             }
             if (failed) break;
         } else {
+            prefetch();
             wg_st(&L.e_pos[which], c1.x);
         }
         c0 = c1;
@@ -1725,6 +1763,14 @@ __device__ void zx_emit(ZxLds& L, const uint4* __restrict__ ck, const uint64_t* 
             atomicAdd(&tally[16], t_wait);
             atomicAdd(&tally[5], n_batches);
             atomicAdd(&tally[6], n_groups);
+            atomicAdd(&tally[2], n_long);
+            atomicAdd(&tally[3], t_long);
+            atomicAdd(&tally[4], n_far_rounds);
+            atomicAdd(&tally[7], n_short);
+            atomicAdd(&tally[28], n_far_groups);
+            atomicAdd(&tally[29], t_far);
+            atomicAdd(&tally[30], t_pre);
+            atomicAdd(&tally[31], t_mark);
         }
     }
 }

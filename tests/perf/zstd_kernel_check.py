@@ -143,6 +143,10 @@ def main():
         if args.prof:
             print("chain, per wave of two frames: %.0f refills of the bit-stream rings, %.0f cycles each = %.1f %% of the wave's cycles" % (
                 tally[27] / max(tally[21], 1), tally[26] / max(tally[27], 1), 100.0 * tally[26] / max(tally[20], 1)))
+        if args.prof:
+            print("emitters, per frame: %.0f short literal runs (a 4-byte store), %.0f long ones, %.0f groups with far matches in %.0f rounds of 16 bytes; cycles per batch and emitter: "
+                  "loads, scans and checks %.0f | markers and short runs %.0f | long runs %.0f | far matches %.0f" % (
+                tally[7] / nb, tally[2] / nb, tally[28] / nb, tally[4] / nb, tally[30] / max(tally[5], 1), tally[31] / max(tally[5], 1), tally[3] / max(tally[5], 1), tally[29] / max(tally[5], 1)), flush=True)
         print("%d frames of 1,024,000 bytes (zstd-1): %d wrong, best %.2f ms = %.1f Gflags/s; %d records, %d far" % (args.many, nbad, ms, args.many * per / ms / 1e6, tally[0], tally[1]), flush=True)
         bad += nbad
     print("FAILED: %d" % bad if bad else "all exact")
