@@ -9,6 +9,8 @@
  * env ONESHOT_EXIT=shutdown: FLAGSTATS_hip_shutdown() before main returns (timed, on stderr); =fast: _exit(0) after the output is
  * flushed -- no atexit handlers, neither the HIP runtime's nor anybody's; unset: return from main.  The parent sees when the
  * process is gone, so "return from main -> process gone" is what the runtime's and the driver's teardown cost.
+ * env ONESHOT_FRESH_BUFFER=1 (u16 mode): every call gets its own newly allocated copy of the flags -- the HIP runtime pins a pageable
+ * buffer the first time it copies out of it and remembers that, so repeats on ONE buffer are not what a caller with a new buffer per call sees.
  * env ONESHOT_LAZY_INIT=1: no FLAGSTATS_hip_init first -- the first call creates the engine itself, as a caller that only
  * knows the reference's API would have it (the library then opens the file and asks for readahead BEFORE the 90 ms of
  * runtime initialisation: what a cold page cache gains from).
@@ -60,10 +62,17 @@ int main(int argc, char** argv)
     memset(&st, 0, sizeof st);
     double t_first_done = 0;
     for (int c = 0; c < calls; ++c) {
-        const double t0 = now_ms();
+        double t0 = now_ms();
         memset(out, 0, sizeof out);
         if (flags) {
             uint32_t o32[32] = {0};
+            const char* fresh = getenv("ONESHOT_FRESH_BUFFER");
+            if (fresh && atoi(fresh) && c > 0) {
+                uint16_t* copy = (uint16_t*)malloc(n * 2 + 2);   /* (never freed: the next call must not get the same pages back) */
+                memcpy(copy, flags, n * 2);
+                flags = copy;
+            }
+            t0 = now_ms();   /* (the copy above is the caller's business, not the call's) */
             rc = (int)FLAGSTATS_u16(flags, (uint32_t)n, o32);
             for (int k = 0; k < 32; ++k) out[k] = o32[k];
         } else if (!strcmp(mode, "raw")) {
