@@ -111,6 +111,7 @@ SIGNATURES = {
     "FLAGSTATS_hip_blockfile_superset": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_file_raw_superset": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_hip_file_raw": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
+    "FLAGSTATS_hip_host_staged_u16": (ctypes.c_int, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(BlockfileStats)]),
     "FLAGSTATS_lz4_block_decode": (ctypes.c_int64, [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]),
     "FLAGSTATS_hip_stream_open": (ctypes.c_void_p, []),
     "FLAGSTATS_hip_stream_acquire": (ctypes.c_void_p, [ctypes.c_void_p, ctypes.c_uint64]),

@@ -240,6 +240,7 @@ struct Source {
     block_decode_fn decode = lz4_block_decode; // block codec (ignored for raw)
     bool raw = false;                          // headerless uint16 file: 1 MiB slices pread straight into the chunks
     bool superset = false;                     // also count slots 0 / 16 (n_pair_all) and 9 (pass-QC reads)
+    uint64_t chunk_cap = 0;                    // > 0: chunks of at most this many bytes instead of the knob's (host arrays: a short head)
 };
 
 int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* st)
@@ -253,6 +254,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
     const double t0 = now_s();
     uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
     if (chunk_cap < (4ull << 20)) chunk_cap = 4ull << 20;
+    if (in.chunk_cap && in.chunk_cap < chunk_cap) chunk_cap = (in.chunk_cap + 15) & ~15ull;
     std::vector<BlockRef> blocks;
     std::vector<ChunkRef> chunks;
     uint64_t uncompressed = 0;
@@ -363,6 +365,15 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
                     const uintptr_t a0 = reinterpret_cast<uintptr_t>(src) & ~static_cast<uintptr_t>(4095);
                     const uintptr_t a1 = (reinterpret_cast<uintptr_t>(src) + br.csize + 4095) & ~static_cast<uintptr_t>(4095);
                     (void)madvise(reinterpret_cast<void*>(a0), a1 - a0, 22 /* MADV_POPULATE_READ */);
+                }
+                if (raw && img) {
+                    // (a pageable array in memory: the workers' copies into the page-locked chunk replace the runtime's own
+                    // pin-as-you-go copy, which moves 24 GB/s out of memory it has not seen before)
+                    std::memcpy(dst, img + br.file_off, br.usize);
+                    const uint64_t keep = br.usize & ~1ull;
+                    std::memset(dst + keep, 0, padded - keep);
+                    ++mine;
+                    continue;
                 }
                 if (raw) {
                     size_t have = 0;
@@ -755,6 +766,21 @@ int FLAGSTATS_hip_zstd_available(void) { return zstd_load() ? 1 : 0; }
 }  // extern "C"
 
 namespace {
+// a host array through the chunk pipeline: 16 MiB chunks (the head -- the first chunk's fill, which nothing overlaps -- stays short)
+int host_staged(fsint::Engine& eng, const uint16_t* array, uint64_t n, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, bool superset)
+{
+    if (!out) return fsint::fail_text("NULL out");
+    if (n && !array) return fsint::fail_text("NULL array with n > 0");
+    Source in;
+    in.img = reinterpret_cast<const uint8_t*>(array);
+    in.bytes = n * 2;
+    in.raw = true;
+    in.superset = superset;
+    const char* ck = std::getenv("FLAGSTATS_HIP_STAGED_CHUNK_MIB");   // (measurement knob)
+    in.chunk_cap = (ck && std::atoi(ck) > 0 ? static_cast<uint64_t>(std::atoi(ck)) : 16ull) << 20;
+    return run_pipeline(eng, in, threads, out, stats);
+}
+
 int file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats, bool superset)
 {
     if (!out) return fsint::fail_text("NULL out");
@@ -804,7 +830,20 @@ int file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats, 
 }
 }  // namespace
 
+namespace fsint {
+int count_host_staged(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, bool superset, int threads)
+{
+    return host_staged(e, h, n, threads, out, nullptr, superset);
+}
+}  // namespace fsint
+
 extern "C" {
+
+int FLAGSTATS_hip_host_staged_u16(const uint16_t* array, uint64_t n, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
+{
+    fsint::Engine* eng = fsint::default_engine();
+    return eng ? host_staged(*eng, array, n, threads, out, stats, false) : -1;
+}
 
 int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
 {

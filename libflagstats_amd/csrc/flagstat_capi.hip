@@ -211,6 +211,8 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
         k.lz4_gpu_kernel = static_cast<int>(value);
     } else if (!std::strcmp(key, "lz4_gpu_min_bytes")) {
         k.lz4_gpu_min_bytes = value;
+    } else if (!std::strcmp(key, "staged_min_flags")) {
+        k.staged_min_flags = value;
     } else if (!std::strcmp(key, "lz4_gpu_keep_bytes")) {
         k.lz4_gpu_keep_bytes = value;
     } else if (!std::strcmp(key, "numa")) {
@@ -256,6 +258,8 @@ uint64_t FLAGSTATS_hip_get(const char* key)
     if (!std::strcmp(key, "zstd_gpu_min_bytes")) return k.zstd_gpu_min_bytes.load();
     if (!std::strcmp(key, "lz4_gpu_kernel")) return static_cast<uint64_t>(k.lz4_gpu_kernel.load());
     if (!std::strcmp(key, "lz4_gpu_min_bytes")) return k.lz4_gpu_min_bytes.load();
+    if (!std::strcmp(key, "staged_min_flags")) return k.staged_min_flags.load();
+    if (!std::strcmp(key, "staged_calls")) return k.staged_calls.load();
     if (!std::strcmp(key, "lz4_gpu_keep_bytes")) return k.lz4_gpu_keep_bytes.load();
     if (!std::strcmp(key, "lz4_gpu_kept_bytes")) {
         if (fsint::default_device() < 0) return 0;

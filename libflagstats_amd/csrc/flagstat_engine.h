@@ -51,6 +51,9 @@ struct Knobs {
     std::atomic<int> lz4_decoder{2};              // LZ4 block files: 0 = decode on host threads, 1 = on the GPU, 2 = by size
     std::atomic<int> lz4_gpu_kernel{0};           // GPU LZ4 decode kernel: 0 = workgroup pipeline (r04), 1 = one wave per block (r03)
     std::atomic<uint64_t> lz4_gpu_min_bytes{64ull << 20};  // lz4_decoder 2: GPU decode for files of at least this many bytes
+    std::atomic<uint64_t> staged_min_flags{1ull << 28};    // host arrays in PAGEABLE memory of at least this many flags go through the
+                                                           // engine's page-locked chunks, copied there by worker threads (0 = never)
+    std::atomic<uint64_t> staged_calls{0};                 // (read-only from outside: how many calls that rule has sent there)
     std::atomic<uint64_t> lz4_gpu_keep_bytes{~0ull};  // device bytes the GPU LZ4 decoder may keep between calls; ~0 = automatic: what the
                                                   // last call needed, at most a quarter of the device, until 8 other calls have passed
     std::atomic<int> zstd_decoder{2};             // Zstandard block files: 0 = libzstd on host threads, 1 = decode on the GPU, 2 = by size
@@ -191,6 +194,8 @@ int count_host(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op =
 // the same for the DEFAULT engine's reference-shaped entry points: concurrent caller threads do not queue behind each
 // other, they spread over the engine and up to Engine::kSideEngines side engines of its device
 int count_host_shared(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op = OP_FLAGSTAT);
+// flagstat_blocks.hip: a host array through the block pipeline's page-locked chunks (worker threads copy 1 MiB slices; takes e.mu)
+int count_host_staged(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, bool superset, int threads);
 
 int stage_reserve(Engine& e, int slot, uint64_t flags);   // e.mu held
 int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3]);  // e.mu held

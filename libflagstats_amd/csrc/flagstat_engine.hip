@@ -100,6 +100,7 @@ void read_env_knobs()
         g_knobs.lz4_decoder = static_cast<int>(env_u64("FLAGSTATS_HIP_LZ4_DECODER", static_cast<uint64_t>(g_knobs.lz4_decoder)));
         g_knobs.lz4_gpu_kernel = static_cast<int>(env_u64("FLAGSTATS_HIP_LZ4_GPU_KERNEL", static_cast<uint64_t>(g_knobs.lz4_gpu_kernel)));
         g_knobs.lz4_gpu_min_bytes = env_u64("FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES", g_knobs.lz4_gpu_min_bytes);
+        g_knobs.staged_min_flags = env_u64("FLAGSTATS_HIP_STAGED_MIN_FLAGS", g_knobs.staged_min_flags);
         g_knobs.zstd_decoder = static_cast<int>(env_u64("FLAGSTATS_HIP_ZSTD_DECODER", static_cast<uint64_t>(g_knobs.zstd_decoder)));
         if (g_knobs.zstd_decoder > 2) g_knobs.zstd_decoder = 2;
         g_knobs.zstd_gpu_min_bytes = env_u64("FLAGSTATS_HIP_ZSTD_GPU_MIN_BYTES", g_knobs.zstd_gpu_min_bytes);
@@ -849,10 +850,37 @@ int pinned_reserve(Engine& e, uint64_t bytes, void* bufs[3])
 // on first need, released with the default engine); only when all are busy does it wait for the default engine.
 static int count_host_locked(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op);
 
+// true if the HIP runtime does not know `p`: ordinary (pageable) host memory -- neither page-locked by hipHostMalloc /
+// hipHostRegister nor device or managed memory
+static bool pageable_host(const void* p)
+{
+    hipPointerAttribute_t attr;
+    std::memset(&attr, 0, sizeof attr);
+    const hipError_t e = hipPointerGetAttributes(&attr, p);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        return e == hipErrorInvalidValue;
+    }
+    return attr.type == hipMemoryTypeUnregistered;
+}
+
 int count_host_shared(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, int op)
 {
     if (n == 0) return 0;
     if (!h) return fail_text("NULL array with n > 0");
+    // Large arrays in pageable memory: hipMemcpyAsync out of such memory makes the runtime pin it as it goes -- 53 GB/s out of
+    // transparent huge pages (numpy's arrays), 35-49 GB/s, box by box and run by run, out of the 4 KiB pages of a plain malloc (a
+    // 4 GiB array: 91 ms at best, 102 in the median).  Eight worker threads copying 1 MiB slices into the engine's page-locked
+    // chunks, which go over PCIe behind them, move 53-57 GB/s whatever the pages are (76 ms; profiles/r05/pageable_c.log).  Below
+    // 512 MiB the pipeline's head costs huge-page arrays more than it saves (256 MiB: +6 %), so the rule starts there (knob
+    // "staged_min_flags"); FLAGSTATS_hip_host_staged_u16 is the same thing for callers who know their pages are small.
+    {
+        const uint64_t staged_min = g_knobs.staged_min_flags.load();
+        if (staged_min && n >= staged_min && (op & OP_BASE_MASK) == OP_FLAGSTAT && pageable_host(h)) {
+            g_knobs.staged_calls.fetch_add(1, std::memory_order_relaxed);
+            return count_host_staged(e, h, n, out, (op & OP_SUPERSET) != 0, 8);
+        }
+    }
     {
         std::unique_lock<std::mutex> lk(e.mu, std::try_to_lock);
         if (lk.owns_lock()) return count_host_locked(e, h, n, out, op);

@@ -412,6 +412,26 @@ static void fuzz_raw_file(long input_no)
     bool ok = rc == 0 && st.n_flags == fl.size();
     for (int k = 0; k < 32 && ok; ++k) ok = out[k] == kPreset + static_cast<uint64_t>(k) + want[k];
     CHECK(ok, "raw file input %ld (%zu bytes): rc %d (%s)", input_no, n, rc, FLAGSTATS_hip_last_error());
+    // the same flags as a host ARRAY in pageable memory, through the size rule that sends large ones into the page-locked chunks
+    // (knob staged_min_flags, set to 1 here) and through the runtime's own copy (0): an exact-size heap copy, odd starts included
+    if (!fl.empty()) {
+        const size_t skip = below(2) ? 0 : below(fl.size() < 3 ? fl.size() : 3);
+        std::vector<uint16_t> exact(fl.begin() + static_cast<std::ptrdiff_t>(skip), fl.end());
+        uint64_t w2[32] = {0};
+        if (!exact.empty()) oracle_flagstat_u16(exact.data(), exact.size(), w2);
+        for (int staged = 0; staged < 2; ++staged) {
+            FLAGSTATS_hip_set("staged_min_flags", staged ? 1 : 0);
+            if (below(2)) FLAGSTATS_hip_set("chunk_flags", 8 + below(100000));
+            uint64_t o2[32];
+            for (int k = 0; k < 32; ++k) o2[k] = kPreset + static_cast<uint64_t>(k);
+            const int rc2 = exact.empty() ? 0 : FLAGSTATS_u16_x64(exact.data(), exact.size(), o2);
+            FLAGSTATS_hip_set("chunk_flags", 4ull << 20);
+            bool ok2 = rc2 == 0;
+            for (int k = 0; k < 32 && ok2; ++k) ok2 = o2[k] == kPreset + static_cast<uint64_t>(k) + w2[k];
+            CHECK(ok2, "host array input %ld (%zu flags, %s): rc %d (%s)", input_no, exact.size(), staged ? "staged" : "runtime copy", rc2, FLAGSTATS_hip_last_error());
+        }
+        FLAGSTATS_hip_set("staged_min_flags", 1ull << 28);
+    }
 }
 
 int main(int argc, char** argv)

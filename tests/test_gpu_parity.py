@@ -209,6 +209,63 @@ def test_host_streaming_chunks_and_pinned(hip):
         hip.FLAGSTATS_hip_set(b"chunk_flags", old)
 
 
+def test_large_pageable_host_arrays_go_through_the_page_locked_chunks(hip):
+    """r05: a host array in PAGEABLE memory of at least `staged_min_flags` flags (default 2^28 = 512 MiB) is copied by worker
+    threads into the engine's page-locked chunks instead of being handed to hipMemcpyAsync, which pins such memory as it goes
+    (profiles/r05/pageable_c.log).  Same counters whichever way: ragged sizes, odd starts, tiny chunks, the superset entry, the
+    32-bit entry; page-locked arrays and small ones do not take the rule."""
+    import oracle
+    from libflagstats_amd import _lib
+    assert hip.FLAGSTATS_hip_get(b"staged_min_flags") == 1 << 28
+    a = np.random.RandomState(23).randint(0, 65536, 6_000_013).astype(np.uint16)
+    old = hip.FLAGSTATS_hip_get(b"chunk_flags")
+    try:
+        calls = hip.FLAGSTATS_hip_get(b"staged_calls")
+        assert np.array_equal(capi_x64(hip, a), oracle.flagstat_hist(a))
+        assert hip.FLAGSTATS_hip_get(b"staged_calls") == calls            # 12 MB: below the rule
+        _lib.check(hip.FLAGSTATS_hip_set(b"staged_min_flags", 1 << 20), "set")
+        for chunk in (old, 1_000_003, 70_000):
+            _lib.check(hip.FLAGSTATS_hip_set(b"chunk_flags", chunk), "set chunk")
+            for lo, hi in ((0, a.size), (1, a.size), (3, a.size - 5), (7, (1 << 20) + 7)):
+                calls = hip.FLAGSTATS_hip_get(b"staged_calls")
+                assert np.array_equal(capi_x64(hip, a[lo:hi]), oracle.flagstat_hist(a[lo:hi])), (chunk, lo, hi)
+                assert hip.FLAGSTATS_hip_get(b"staged_calls") == calls + 1, (chunk, lo, hi)
+        _lib.check(hip.FLAGSTATS_hip_set(b"chunk_flags", old), "set chunk")
+        # the superset entry (slots 0 / 16 / 9 counted too) and the reference-shaped 32-bit entry
+        out = np.zeros(32, dtype=np.uint64)
+        calls = hip.FLAGSTATS_hip_get(b"staged_calls")
+        _lib.check(hip.FLAGSTATS_u16_x64_superset(a.ctypes.data, a.size, out.ctypes.data), "superset")
+        want = oracle.flagstat_hist(a).copy()
+        pp = ((a & 0x100) == 0) & ((a & 0x800) == 0) & ((a & 1) == 1)
+        fail = (a & 0x200) != 0
+        want[0], want[16], want[9] = int((pp & ~fail).sum()), int((pp & fail).sum()), a.size - int(fail.sum())
+        assert np.array_equal(out, want) and hip.FLAGSTATS_hip_get(b"staged_calls") == calls + 1
+        o32 = np.zeros(32, dtype=np.uint32)
+        assert hip.FLAGSTATS_u16(a.ctypes.data, a.size, o32.ctypes.data) == 0
+        assert np.array_equal(o32.astype(np.uint64), oracle.flagstat_hist(a)) and hip.FLAGSTATS_hip_get(b"staged_calls") == calls + 2
+        # page-locked memory is the runtime's fast path already: not staged
+        p = hip.FLAGSTATS_hip_host_alloc(a.nbytes)
+        assert p
+        ctypes.memmove(p, a.ctypes.data, a.nbytes)
+        out = np.zeros(32, dtype=np.uint64)
+        calls = hip.FLAGSTATS_hip_get(b"staged_calls")
+        _lib.check(hip.FLAGSTATS_u16_x64(p, a.size, out.ctypes.data), "x64 pinned")
+        assert np.array_equal(out, oracle.flagstat_hist(a)) and hip.FLAGSTATS_hip_get(b"staged_calls") == calls
+        hip.FLAGSTATS_hip_host_free(p)
+        # a failed call leaves the counters alone: NULL array
+        out = np.full(32, 5, dtype=np.uint64)
+        assert hip.FLAGSTATS_u16_x64(None, 1 << 21, out.ctypes.data) != 0 and (out == 5).all()
+    finally:
+        hip.FLAGSTATS_hip_set(b"chunk_flags", old)
+        hip.FLAGSTATS_hip_set(b"staged_min_flags", 1 << 28)
+    # at the shipped threshold: 2^28 + 12345 flags (512 MiB) of pageable memory take the rule
+    n = (1 << 28) + 12345
+    big = oracle.generate(oracle.GEN_NA12878, 31, 1, 0, n)
+    calls = hip.FLAGSTATS_hip_get(b"staged_calls")
+    assert np.array_equal(capi_x64(hip, big), oracle.flagstat_generated(oracle.GEN_NA12878, 31, 1, 0, n))
+    assert hip.FLAGSTATS_hip_get(b"staged_calls") == calls + 1
+
+
 # --------------------------------------------------------------------------- full-size properties
 def test_full_size_ramp_is_exact_multiple_of_kat(hip):
     """8 GiB (BASELINE metric size): 2^32 flags = 65536 repetitions of the exhaustive 0..65535
