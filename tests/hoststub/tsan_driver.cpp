@@ -245,6 +245,38 @@ static void callers(const std::vector<uint16_t>& flags)
             }
         });
     for (auto& th : pool) th.join();
+    // large pageable arrays take the staged way (worker threads copy into the page-locked chunks; here from 1,000 flags on):
+    // two such callers and two small-call callers at once -- the staged call holds the default engine, the small calls find it
+    // taken and go to the side engines
+    FLAGSTATS_hip_set("staged_min_flags", 1000);
+    FLAGSTATS_hip_set("chunk_flags", 300000);
+    {
+        std::vector<std::thread> mixed;
+        uint64_t whole[32] = {0};
+        oracle_flagstat_u16(flags.data(), flags.size(), whole);
+        for (int t = 0; t < 2; ++t)
+            mixed.emplace_back([&, t] {
+                for (int it = 0; it < 3; ++it) {
+                    uint64_t o[32] = {0};
+                    CHECK(FLAGSTATS_u16_x64(flags.data() + t, flags.size() - static_cast<size_t>(t), o) == 0, "staged host call");
+                    if (t == 0) CHECK(same(o, whole), "staged host call counters (thread %d, call %d)", t, it);
+                }
+            });
+        for (int t = 0; t < 2; ++t)
+            mixed.emplace_back([&, t] {
+                for (int it = 0; it < 40; ++it) {
+                    const size_t m = 500 + static_cast<size_t>(t) * 37 + static_cast<size_t>(it), off = static_cast<size_t>(it) * 4001;
+                    uint32_t g32[32] = {0};
+                    uint64_t w[32] = {0};
+                    CHECK(FLAGSTATS_u16(flags.data() + off, static_cast<uint32_t>(m), g32) == 0, "small call beside staged ones");
+                    oracle_flagstat_u16(flags.data() + off, m, w);
+                    for (int k = 0; k < 32; ++k) CHECK(g32[k] == w[k], "small call beside staged ones: slot %d", k);
+                }
+            });
+        for (auto& th : mixed) th.join();
+        CHECK(FLAGSTATS_hip_get("staged_calls") >= 6, "the staged rule was not taken");
+    }
+    FLAGSTATS_hip_set("staged_min_flags", 1ull << 28);
     FLAGSTATS_hip_set("chunk_flags", 100000);
     uint64_t got[32] = {0}, want[32] = {0};
     CHECK(FLAGSTATS_u16_x64(flags.data(), flags.size(), got) == 0, "multi-chunk host call");
