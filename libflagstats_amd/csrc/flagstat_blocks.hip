@@ -241,6 +241,7 @@ struct Source {
     bool raw = false;                          // headerless uint16 file: 1 MiB slices pread straight into the chunks
     bool superset = false;                     // also count slots 0 / 16 (n_pair_all) and 9 (pass-QC reads)
     uint64_t chunk_cap = 0;                    // > 0: chunks of at most this many bytes instead of the knob's (host arrays: a short head)
+    bool ramp = false;                         // raw: the first two chunks hold a quarter and a half of a chunk
 };
 
 int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* st)
@@ -269,7 +270,9 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
         for (uint64_t pos = 0; pos < bytes; pos += slice) {
             const uint64_t len = bytes - pos < slice ? bytes - pos : slice;
             const uint64_t padded = (len + 15) & ~15ull;
-            if (cur.bytes + padded > chunk_cap) {
+            // (host arrays: the first chunks are a quarter and a half of the others -- nothing overlaps the first chunk's fill)
+            const uint64_t cap_now = in.ramp && chunks.size() < 2 ? (chunk_cap >> (2 - chunks.size())) : chunk_cap;
+            if (cur.bytes + padded > cap_now && cur.bytes) {
                 cur.b1 = blocks.size();
                 chunks.push_back(cur);
                 cur = ChunkRef{blocks.size(), 0, 0};
@@ -778,6 +781,8 @@ int host_staged(fsint::Engine& eng, const uint16_t* array, uint64_t n, int threa
     in.superset = superset;
     const char* ck = std::getenv("FLAGSTATS_HIP_STAGED_CHUNK_MIB");   // (measurement knob)
     in.chunk_cap = (ck && std::atoi(ck) > 0 ? static_cast<uint64_t>(std::atoi(ck)) : 16ull) << 20;
+    const char* rk = std::getenv("FLAGSTATS_HIP_STAGED_RAMP");       // (measurement knob: 0 = equal chunks)
+    in.ramp = !(rk && std::atoi(rk) == 0);
     return run_pipeline(eng, in, threads, out, stats);
 }
 

@@ -51,7 +51,7 @@ struct Knobs {
     std::atomic<int> lz4_decoder{2};              // LZ4 block files: 0 = decode on host threads, 1 = on the GPU, 2 = by size
     std::atomic<int> lz4_gpu_kernel{0};           // GPU LZ4 decode kernel: 0 = workgroup pipeline (r04), 1 = one wave per block (r03)
     std::atomic<uint64_t> lz4_gpu_min_bytes{64ull << 20};  // lz4_decoder 2: GPU decode for files of at least this many bytes
-    std::atomic<uint64_t> staged_min_flags{1ull << 28};    // host arrays in PAGEABLE memory of at least this many flags go through the
+    std::atomic<uint64_t> staged_min_flags{1ull << 27};    // host arrays in PAGEABLE memory of at least this many flags go through the
                                                            // engine's page-locked chunks, copied there by worker threads (0 = never)
     std::atomic<uint64_t> staged_calls{0};                 // (read-only from outside: how many calls that rule has sent there)
     std::atomic<uint64_t> lz4_gpu_keep_bytes{~0ull};  // device bytes the GPU LZ4 decoder may keep between calls; ~0 = automatic: what the

@@ -869,11 +869,13 @@ int count_host_shared(Engine& e, const uint16_t* h, uint64_t n, uint64_t* out, i
     if (n == 0) return 0;
     if (!h) return fail_text("NULL array with n > 0");
     // Large arrays in pageable memory: hipMemcpyAsync out of such memory makes the runtime pin it as it goes -- 53 GB/s out of
-    // transparent huge pages (numpy's arrays), 35-49 GB/s, box by box and run by run, out of the 4 KiB pages of a plain malloc (a
-    // 4 GiB array: 91 ms at best, 102 in the median).  Eight worker threads copying 1 MiB slices into the engine's page-locked
-    // chunks, which go over PCIe behind them, move 53-57 GB/s whatever the pages are (76 ms; profiles/r05/pageable_c.log).  Below
-    // 512 MiB the pipeline's head costs huge-page arrays more than it saves (256 MiB: +6 %), so the rule starts there (knob
-    // "staged_min_flags"); FLAGSTATS_hip_host_staged_u16 is the same thing for callers who know their pages are small.
+    // transparent huge pages (numpy's arrays), 30-49 GB/s, box by box and run by run, out of the 4 KiB pages of a plain malloc (a
+    // 4 GiB array: 91 ms at best, 102 in the median; 256 MiB: 7.4 at best, 9.4 in the median).  Eight worker threads copying 1 MiB
+    // slices into the engine's page-locked chunks (4, 8, then 16 MiB), which go over PCIe behind them, move 51-57 GB/s whatever the
+    // pages are (76 ms; 5.3 ms; profiles/r05/pageable_c.log, pageable_c_ramp.log).  Below 256 MiB the pipeline's head costs
+    // huge-page arrays more than the steadier rate gives back (128 MiB: +11 %, 256 MiB: +3 %, 512 MiB: -2 %), so the rule starts
+    // there (knob "staged_min_flags"); FLAGSTATS_hip_host_staged_u16 is the same thing for callers who know their pages are small
+    // (from 64 MiB: -20 to -50 %).
     {
         const uint64_t staged_min = g_knobs.staged_min_flags.load();
         if (staged_min && n >= staged_min && (op & OP_BASE_MASK) == OP_FLAGSTAT && pageable_host(h)) {

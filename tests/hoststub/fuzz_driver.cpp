@@ -430,7 +430,7 @@ static void fuzz_raw_file(long input_no)
             for (int k = 0; k < 32 && ok2; ++k) ok2 = o2[k] == kPreset + static_cast<uint64_t>(k) + w2[k];
             CHECK(ok2, "host array input %ld (%zu flags, %s): rc %d (%s)", input_no, exact.size(), staged ? "staged" : "runtime copy", rc2, FLAGSTATS_hip_last_error());
         }
-        FLAGSTATS_hip_set("staged_min_flags", 1ull << 28);
+        FLAGSTATS_hip_set("staged_min_flags", 1ull << 27);
     }
 }
 

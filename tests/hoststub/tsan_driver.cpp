@@ -276,7 +276,7 @@ static void callers(const std::vector<uint16_t>& flags)
         for (auto& th : mixed) th.join();
         CHECK(FLAGSTATS_hip_get("staged_calls") >= 6, "the staged rule was not taken");
     }
-    FLAGSTATS_hip_set("staged_min_flags", 1ull << 28);
+    FLAGSTATS_hip_set("staged_min_flags", 1ull << 27);
     FLAGSTATS_hip_set("chunk_flags", 100000);
     uint64_t got[32] = {0}, want[32] = {0};
     CHECK(FLAGSTATS_u16_x64(flags.data(), flags.size(), got) == 0, "multi-chunk host call");

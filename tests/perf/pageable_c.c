@@ -51,7 +51,7 @@ int main(int argc, char** argv)
             for (int r = 0; r < reps && r < 64; ++r) {
                 uint16_t* a = fresh(base, n, huge);
                 uint64_t out[32] = {0};
-                FLAGSTATS_hip_set("staged_min_flags", how == 0 ? 0 : 1ull << 28);
+                FLAGSTATS_hip_set("staged_min_flags", how == 0 ? 0 : 1ull << 27);
                 const double t0 = now_ms();
                 const int rc = how == 1 ? FLAGSTATS_hip_host_staged_u16(a, n, 8, out, NULL) : FLAGSTATS_u16_x64(a, n, out);
                 t[r] = now_ms() - t0;

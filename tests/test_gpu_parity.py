@@ -210,13 +210,13 @@ def test_host_streaming_chunks_and_pinned(hip):
 
 
 def test_large_pageable_host_arrays_go_through_the_page_locked_chunks(hip):
-    """r05: a host array in PAGEABLE memory of at least `staged_min_flags` flags (default 2^28 = 512 MiB) is copied by worker
+    """r05: a host array in PAGEABLE memory of at least `staged_min_flags` flags (default 2^27 = 256 MiB) is copied by worker
     threads into the engine's page-locked chunks instead of being handed to hipMemcpyAsync, which pins such memory as it goes
     (profiles/r05/pageable_c.log).  Same counters whichever way: ragged sizes, odd starts, tiny chunks, the superset entry, the
     32-bit entry; page-locked arrays and small ones do not take the rule."""
     import oracle
     from libflagstats_amd import _lib
-    assert hip.FLAGSTATS_hip_get(b"staged_min_flags") == 1 << 28
+    assert hip.FLAGSTATS_hip_get(b"staged_min_flags") == 1 << 27
     a = np.random.RandomState(23).randint(0, 65536, 6_000_013).astype(np.uint16)
     old = hip.FLAGSTATS_hip_get(b"chunk_flags")
     try:
@@ -257,9 +257,9 @@ def test_large_pageable_host_arrays_go_through_the_page_locked_chunks(hip):
         assert hip.FLAGSTATS_u16_x64(None, 1 << 21, out.ctypes.data) != 0 and (out == 5).all()
     finally:
         hip.FLAGSTATS_hip_set(b"chunk_flags", old)
-        hip.FLAGSTATS_hip_set(b"staged_min_flags", 1 << 28)
-    # at the shipped threshold: 2^28 + 12345 flags (512 MiB) of pageable memory take the rule
-    n = (1 << 28) + 12345
+        hip.FLAGSTATS_hip_set(b"staged_min_flags", 1 << 27)
+    # at the shipped threshold: 2^27 + 12345 flags (256 MiB) of pageable memory take the rule
+    n = (1 << 27) + 12345
     big = oracle.generate(oracle.GEN_NA12878, 31, 1, 0, n)
     calls = hip.FLAGSTATS_hip_get(b"staged_calls")
     assert np.array_equal(capi_x64(hip, big), oracle.flagstat_generated(oracle.GEN_NA12878, 31, 1, 0, n))
