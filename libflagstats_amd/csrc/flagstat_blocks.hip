@@ -111,7 +111,9 @@ double now_s()
 // Parse the block headers of a file image.  Every block's decoded bytes get a 16-byte aligned
 // slot in a chunk buffer; the gap up to the next slot is zero-filled, and a zero flag counts
 // nothing, so a whole chunk is counted as ONE array.
-int index_blocks(const uint8_t* img, int fd, uint64_t bytes, uint64_t chunk_cap, std::vector<BlockRef>& blocks,
+// Chunks: a chunk is closed when the next block would take it over `soft_cap` (the first two chunks: a quarter and a half of it
+// when `ramp` -- nothing overlaps the first chunk's decode); a block larger than that has a chunk of its own, up to `hard_cap`.
+int index_blocks(const uint8_t* img, int fd, uint64_t bytes, uint64_t soft_cap, uint64_t hard_cap, bool ramp, std::vector<BlockRef>& blocks,
                  std::vector<ChunkRef>& chunks, uint64_t& uncompressed, int codec)
 {
     uint64_t pos = 0;
@@ -134,8 +136,9 @@ int index_blocks(const uint8_t* img, int fd, uint64_t bytes, uint64_t chunk_cap,
         if (!fsint::block_sizes_plausible(codec, static_cast<uint64_t>(us), static_cast<uint64_t>(cs)))
             return fsint::fail_text("block file: a block header declares more decoded bytes than a payload of its size can hold");
         const uint64_t padded = (static_cast<uint64_t>(us) + 15) & ~15ull;
-        if (padded > chunk_cap) return fsint::fail_text("block file: block larger than the chunk buffer");
-        if (cur.bytes + padded > chunk_cap) {
+        if (padded > hard_cap) return fsint::fail_text("block file: block larger than the chunk buffer");
+        const uint64_t cap_now = ramp && chunks.size() < 2 ? soft_cap >> (2 - chunks.size()) : soft_cap;
+        if (cur.bytes && cur.bytes + padded > cap_now) {
             cur.b1 = blocks.size();
             chunks.push_back(cur);
             cur = ChunkRef{blocks.size(), 0, 0};
@@ -240,8 +243,6 @@ struct Source {
     block_decode_fn decode = lz4_block_decode; // block codec (ignored for raw)
     bool raw = false;                          // headerless uint16 file: 1 MiB slices pread straight into the chunks
     bool superset = false;                     // also count slots 0 / 16 (n_pair_all) and 9 (pass-QC reads)
-    uint64_t chunk_cap = 0;                    // > 0: chunks of at most this many bytes instead of the knob's (host arrays: a short head)
-    bool ramp = false;                         // raw: the first two chunks hold a quarter and a half of a chunk
 };
 
 int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* st)
@@ -253,9 +254,20 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
     const block_decode_fn decode = in.decode;
     const bool raw = in.raw, superset = in.superset;
     const double t0 = now_s();
-    uint64_t chunk_cap = (fsint::chunk_bytes() + 15) & ~15ull;  // knob "chunk_flags" (default 64 MiB)
-    if (chunk_cap < (4ull << 20)) chunk_cap = 4ull << 20;
-    if (in.chunk_cap && in.chunk_cap < chunk_cap) chunk_cap = (in.chunk_cap + 15) & ~15ull;
+    // Chunk sizes.  The knob "chunk_flags" (default 64 MiB) is the LARGEST chunk the pipeline makes -- a block up to that size has a
+    // chunk of its own; what it aims for is 16 MiB, and a quarter and a half of that for the first two chunks: nothing overlaps the
+    // first chunk's decode and nothing the last chunk's copy, and with 64 MiB chunks a file that decodes to 200 MB was hardly
+    // pipelined at all (LZ4-fast, 2^25 flags: 3.2 -> 2.1 ms, 2^26: 4.0 -> 3.2; Zstandard 2^26: 7.1 -> 5.4; the raw file of the
+    // README's size 32-34 -> 29.6-30.2 ms; large files: the same; profiles/r05/pipeline_chunk_sizes.log).
+    // env FLAGSTATS_HIP_PIPE_CHUNK_MIB / FLAGSTATS_HIP_PIPE_RAMP=0: measurement knobs.
+    uint64_t hard_cap = (fsint::chunk_bytes() + 15) & ~15ull;
+    if (hard_cap < (4ull << 20)) hard_cap = 4ull << 20;
+    uint64_t chunk_cap = 16ull << 20;
+    if (const char* ck = std::getenv("FLAGSTATS_HIP_PIPE_CHUNK_MIB"))
+        if (std::atoi(ck) > 0) chunk_cap = static_cast<uint64_t>(std::atoi(ck)) << 20;
+    if (chunk_cap > hard_cap) chunk_cap = hard_cap;
+    const char* rk = std::getenv("FLAGSTATS_HIP_PIPE_RAMP");
+    const bool ramp = !(rk && std::atoi(rk) == 0);
     std::vector<BlockRef> blocks;
     std::vector<ChunkRef> chunks;
     uint64_t uncompressed = 0;
@@ -270,8 +282,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
         for (uint64_t pos = 0; pos < bytes; pos += slice) {
             const uint64_t len = bytes - pos < slice ? bytes - pos : slice;
             const uint64_t padded = (len + 15) & ~15ull;
-            // (host arrays: the first chunks are a quarter and a half of the others -- nothing overlaps the first chunk's fill)
-            const uint64_t cap_now = in.ramp && chunks.size() < 2 ? (chunk_cap >> (2 - chunks.size())) : chunk_cap;
+            const uint64_t cap_now = ramp && chunks.size() < 2 ? (chunk_cap >> (2 - chunks.size())) : chunk_cap;
             if (cur.bytes + padded > cap_now && cur.bytes) {
                 cur.b1 = blocks.size();
                 chunks.push_back(cur);
@@ -285,7 +296,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
         if (cur.b1 > cur.b0) chunks.push_back(cur);
         uncompressed = bytes;
     } else {
-        rc = index_blocks(img, fd, bytes, chunk_cap, blocks, chunks, uncompressed, in.decode == lz4_block_decode ? 0 : 1);
+        rc = index_blocks(img, fd, bytes, chunk_cap, hard_cap, ramp, blocks, chunks, uncompressed, in.decode == lz4_block_decode ? 0 : 1);
     }
     if (rc) return rc;
     if (map)  // file mode with a mapping: headers were pread (no fault per block), payloads are decoded in place
@@ -309,8 +320,11 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
     fsint::lz4_gpu_other_use(eng);  // (the GPU LZ4 decoder's kept buffers go after eight calls that did not use it)
     fsint::DeviceGuard guard(eng.device);
     if (!guard.ok()) return -1;
+    uint64_t buf_cap = chunk_cap;   // what the chunk buffers must hold: the largest chunk (a large block has one of its own)
+    for (const ChunkRef& c : chunks) buf_cap = c.bytes > buf_cap ? c.bytes : buf_cap;
+    buf_cap = (buf_cap + 15) & ~15ull;
     if (!chunks.empty()) {
-        for (int s = 0; s < 2 && !rc; ++s) rc = fsint::stage_reserve(eng, s, chunk_cap / 2);
+        for (int s = 0; s < 2 && !rc; ++s) rc = fsint::stage_reserve(eng, s, buf_cap / 2);
         if (rc) return rc;
     }
     uint8_t* pinned[kPinned] = {nullptr, nullptr, nullptr};
@@ -318,7 +332,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
     const int npin = chunks.size() < static_cast<size_t>(kPinned) ? static_cast<int>(chunks.size()) : kPinned;
     if (npin) {
         void* bufs[3];
-        rc = fsint::pinned_reserve(eng, chunk_cap, bufs);  // allocated once per process: hipHostMalloc costs ~10 ms / 64 MiB
+        rc = fsint::pinned_reserve(eng, buf_cap, bufs);  // allocated once per process: hipHostMalloc costs ~10 ms / 64 MiB
         if (rc) return rc;
         for (int i = 0; i < kPinned; ++i) pinned[i] = static_cast<uint8_t*>(bufs[i]);
     }
@@ -769,7 +783,7 @@ int FLAGSTATS_hip_zstd_available(void) { return zstd_load() ? 1 : 0; }
 }  // extern "C"
 
 namespace {
-// a host array through the chunk pipeline: 16 MiB chunks (the head -- the first chunk's fill, which nothing overlaps -- stays short)
+// a host array through the chunk pipeline (1 MiB slices copied by the workers)
 int host_staged(fsint::Engine& eng, const uint16_t* array, uint64_t n, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, bool superset)
 {
     if (!out) return fsint::fail_text("NULL out");
@@ -779,10 +793,6 @@ int host_staged(fsint::Engine& eng, const uint16_t* array, uint64_t n, int threa
     in.bytes = n * 2;
     in.raw = true;
     in.superset = superset;
-    const char* ck = std::getenv("FLAGSTATS_HIP_STAGED_CHUNK_MIB");   // (measurement knob)
-    in.chunk_cap = (ck && std::atoi(ck) > 0 ? static_cast<uint64_t>(std::atoi(ck)) : 16ull) << 20;
-    const char* rk = std::getenv("FLAGSTATS_HIP_STAGED_RAMP");       // (measurement knob: 0 = equal chunks)
-    in.ramp = !(rk && std::atoi(rk) == 0);
     return run_pipeline(eng, in, threads, out, stats);
 }
 
