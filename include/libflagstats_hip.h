@@ -166,7 +166,9 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *                    0 = partials + K2 (then one counter array must be targeted from one stream at a time).
  *                    The store forms and counters in pinned host memory always use K2.
  *   "fuse"           tuning build only (the r01 experiment that lost): 1 = the last-arriving workgroup of K1 finalises
- *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB)
+ *   "chunk_flags"    flags per H2D chunk of the host-pointer entries (default 32 Mi = 64 MiB); for the chunk pipeline (block files on
+ *                    host threads, raw files, large pageable arrays) the LARGEST chunk: it aims for 16 MiB, a larger block has its own
+ *   "staged_min_flags" pageable host arrays of at least this many flags go through the chunk pipeline (default 2^27; 0 = never)
  *   "on_error"       reference-shaped entry points on failure: 1 abort() after the message (default), 0 return non-zero
  *   "numa"           1 (default): pinned buffers and block-decoder threads are placed on the GPU's host NUMA node
  *   "group_min_grid" K1's atomic epilogue goes through the workspace's 8 per-XCD copies (8 x 2 contended adds on the
