@@ -257,7 +257,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
     // Chunk sizes.  The knob "chunk_flags" (default 64 MiB) is the LARGEST chunk the pipeline makes -- a block up to that size has a
     // chunk of its own; what it aims for is 16 MiB, and a quarter and a half of that for the first two chunks: nothing overlaps the
     // first chunk's decode and nothing the last chunk's copy, and with 64 MiB chunks a file that decodes to 200 MB was hardly
-    // pipelined at all (LZ4-fast, 2^25 flags: 3.2 -> 2.1 ms, 2^26: 4.0 -> 3.2; Zstandard 2^26: 7.1 -> 5.4; the raw file of the
+    // pipelined at all (LZ4-fast, 2^25 flags: 2.9 -> 2.1 ms, 2^26: 4.2 -> 3.3; Zstandard 2^26: 7.1 -> 6.3; the raw file of the
     // README's size 32-34 -> 29.6-30.2 ms; large files: the same; profiles/r05/pipeline_chunk_sizes.log).
     // env FLAGSTATS_HIP_PIPE_CHUNK_MIB / FLAGSTATS_HIP_PIPE_RAMP=0: measurement knobs.
     uint64_t hard_cap = (fsint::chunk_bytes() + 15) & ~15ull;
@@ -385,7 +385,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
                 }
                 if (raw && img) {
                     // (a pageable array in memory: the workers' copies into the page-locked chunk replace the runtime's own
-                    // pin-as-you-go copy, which moves 24 GB/s out of memory it has not seen before)
+                    // pin-as-you-go copy, which moves 30-49 GB/s out of 4 KiB pages it has not seen before: count_host_shared)
                     std::memcpy(dst, img + br.file_off, br.usize);
                     const uint64_t keep = br.usize & ~1ull;
                     std::memset(dst + keep, 0, padded - keep);
