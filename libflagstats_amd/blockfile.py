@@ -18,6 +18,25 @@ def _stats(st: _lib.BlockfileStats) -> dict:
     return {name: getattr(st, name) for name, _ in st._fields_}
 
 
+def _image_pointer(image):
+    """(pointer argument, byte count, object to keep alive) for a file image WITHOUT copying it: `bytes` go to the C side as they
+    are, numpy arrays by their data pointer, other buffers (bytearray, memoryview, mmap) through the buffer protocol; only a
+    read-only buffer that is neither is copied (a 30 MB image: 3 ms, more than the call takes)."""
+    if image is None or len(image) == 0:
+        return None, 0, None
+    if isinstance(image, bytes):
+        return image, len(image), image
+    if isinstance(image, np.ndarray):
+        a = np.ascontiguousarray(image)
+        return a.ctypes.data, a.nbytes, a
+    mv = memoryview(image)
+    if mv.readonly or not mv.contiguous:
+        b = mv.tobytes()
+        return b, len(b), b
+    buf = (ctypes.c_char * mv.nbytes).from_buffer(mv)
+    return buf, mv.nbytes, buf
+
+
 def flagstat_lz4_file(path: str, threads: int = 0):
     out = np.zeros(32, dtype=np.uint64)
     st = _lib.BlockfileStats()
@@ -29,8 +48,8 @@ def flagstat_lz4_file(path: str, threads: int = 0):
 def flagstat_lz4_image(image: bytes, threads: int = 0):
     out = np.zeros(32, dtype=np.uint64)
     st = _lib.BlockfileStats()
-    buf = (ctypes.c_char * len(image)).from_buffer_copy(image) if image else None
-    _lib.check(_lib.lib().FLAGSTATS_hip_blockimage_lz4(buf, len(image), threads, out.ctypes.data, ctypes.byref(st)),
+    buf, nbytes, _keep = _image_pointer(image)
+    _lib.check(_lib.lib().FLAGSTATS_hip_blockimage_lz4(buf, nbytes, threads, out.ctypes.data, ctypes.byref(st)),
                "FLAGSTATS_hip_blockimage_lz4")
     return out, _stats(st)
 
@@ -49,8 +68,8 @@ def flagstat_zstd_file(path: str, threads: int = 0):
 def flagstat_zstd_image(image: bytes, threads: int = 0):
     out = np.zeros(32, dtype=np.uint64)
     st = _lib.BlockfileStats()
-    buf = (ctypes.c_char * len(image)).from_buffer_copy(image) if image else None
-    _lib.check(_lib.lib().FLAGSTATS_hip_blockimage_zstd(buf, len(image), threads, out.ctypes.data, ctypes.byref(st)),
+    buf, nbytes, _keep = _image_pointer(image)
+    _lib.check(_lib.lib().FLAGSTATS_hip_blockimage_zstd(buf, nbytes, threads, out.ctypes.data, ctypes.byref(st)),
                "FLAGSTATS_hip_blockimage_zstd")
     return out, _stats(st)
 

@@ -636,3 +636,21 @@ def test_a_decoded_buffer_the_device_cannot_hold_is_found_out_beside_the_copies(
         assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 64 << 20) == 0
         assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0          # (the fixture puts 2 back)
         assert hip.FLAGSTATS_hip_set(b"lz4_gpu_keep_bytes", auto) == 0
+
+
+def test_image_entries_take_any_buffer_without_copying_it(hip):
+    """The Python image entries hand bytes, numpy arrays and writable buffers to the C side as they are (r05: they used to copy
+    the image into a ctypes array first -- 3 ms for a 30 MB image, more than the call takes); a read-only memoryview is the one
+    case that is copied.  Same counters from every kind."""
+    import oracle
+    from libflagstats_amd import blockfile
+    flags = oracle.generate(oracle.GEN_NA12878, 5, 1, 0, 512000 * 3 + 11)
+    for entry, img in ((blockfile.flagstat_lz4_image, bt.block_file_image(flags)),
+                       (blockfile.flagstat_zstd_image, bt.block_file_image(flags, mode="zstd", level=1))):
+        want = expect(flags, bt.BLOCK_BYTES)[0]
+        ba = bytearray(img)
+        for image in (img, ba, np.frombuffer(img, dtype=np.uint8), memoryview(ba), memoryview(img), np.frombuffer(img, dtype=np.uint8)[:]):
+            got, st = entry(image, 2)
+            assert np.array_equal(got, want) and st["n_flags"] == flags.size
+        got, st = entry(b"", 2)
+        assert not got.any() and st["n_flags"] == 0
