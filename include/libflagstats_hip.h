@@ -190,18 +190,19 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device);
  *                    system-scope fence (default 0)
  *   "lz4_decoder"    LZ4 block files (FLAGSTATS_hip_blockfile*, blockimage_lz4): 0 = decode on host threads into pinned
  *                    chunks (decoded flags cross PCIe), 1 = decode on the GPU (the compressed bytes cross PCIe, one
- *                    workgroup per block), 2 (default) = on the GPU for files of at least "lz4_gpu_min_bytes" (default
- *                    64 MiB compressed: the measured break-even of an LZ4-fast file, an LZ4-HC file wins from 40 MiB,
- *                    profiles/r04/lz4_decoder_sweep.log), on the host below -- and on the host whatever the size when
+ *                    workgroup per block), 2 (default) = by size: on the GPU for files of at least "lz4_gpu_min_bytes"
+ *                    (default 64 MiB compressed) and for smaller ones that DECODE to at least 2.5 x that (160 MiB of flags:
+ *                    the two decoders cross at 120-200 MB decoded whatever the codec and level, which is 27-95 MiB of
+ *                    file; profiles/r05/decoder_crossover.log), on the host below -- and on the host whatever the size when
  *                    the blocks hardly compress (decoded bytes < 1.25 x the file's; Zstandard: 1.9 x): the host pipeline is
  *                    PCIe-bound on such a file and the GPU decoders' literal paths are their slow ones
  *                    (profiles/r04/incompressible_blockfiles.log).  env FLAGSTATS_HIP_LZ4_DECODER / FLAGSTATS_HIP_LZ4_GPU_MIN_BYTES
  *   "zstd_decoder"   Zstandard block files (blockfile_zstd, blockimage_zstd, blockfile): 0 = libzstd on host threads, 1 = decode
  *                    on the GPU (four kernels: Huffman literals + FSE tables, the serial walk of the FSE states, sequence
  *                    records, execution; a frame the decoder does not take -- dictionary, content checksum, concatenated
- *                    or skippable frames, damage -- fails the call with its status code), 2 (default) = on the GPU for
- *                    files of at least "zstd_gpu_min_bytes" (default 64 MiB: the measured break-even,
- *                    profiles/r04/zstd_decoder_sweep.log), and a file with a frame the GPU decoder does not take is
+ *                    or skippable frames, damage -- fails the call with its status code), 2 (default) = by size, like
+ *                    "lz4_decoder": on the GPU for files of at least "zstd_gpu_min_bytes" (default 64 MiB) or that decode
+ *                    to at least 2.5 x that, and a file with a frame the GPU decoder does not take is
  *                    decoded by libzstd on the host threads instead.  env FLAGSTATS_HIP_ZSTD_DECODER / FLAGSTATS_HIP_ZSTD_GPU_MIN_BYTES
  *   "lz4_gpu_keep_bytes" device memory the GPU LZ4 / Zstandard decoder may keep between calls: its two buffers -- a segment's
  *                    compressed and decoded bytes -- are reused by the next file (allocating them right after freeing

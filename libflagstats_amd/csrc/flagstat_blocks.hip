@@ -602,13 +602,16 @@ int pick_decoder(int codec, block_decode_fn* fn)
     return 0;
 }
 
-// Block files: knob "lz4_decoder" / "zstd_decoder" -- 0 host threads, 1 GPU, 2 (default) GPU from "lz4_gpu_min_bytes" /
-// "zstd_gpu_min_bytes" compressed bytes up
+// Block files: knob "lz4_decoder" / "zstd_decoder" -- 0 host threads, 1 GPU, 2 (default) by size: GPU for files of at least
+// "lz4_gpu_min_bytes" / "zstd_gpu_min_bytes" compressed bytes, and for smaller ones that DECODE to at least 2.5 x that (known after
+// the GPU path's index pass, which hands the file back otherwise: lz4_gpu_run) -- what a file costs either decoder goes with its
+// decoded size: the two cross at 120-200 MB decoded for LZ4-fast, LZ4-HC-9 and Zstandard 1 / 3 / 19 alike, which is 27-95 MiB of
+// file (profiles/r05/decoder_crossover.log).  Files under a quarter of the knob are not even indexed twice.
 bool decode_on_gpu(int codec, uint64_t bytes)
 {
     const int mode = codec == 0 ? fsint::knobs().lz4_decoder.load() : fsint::knobs().zstd_decoder.load();
     const uint64_t from = codec == 0 ? fsint::knobs().lz4_gpu_min_bytes.load() : fsint::knobs().zstd_gpu_min_bytes.load();
-    return mode == 1 || (mode == 2 && bytes >= from);
+    return mode == 1 || (mode == 2 && bytes >= from / 4);
 }
 
 // > 0: the GPU decoder did not take the file and nothing was counted -- the caller decodes it on host threads

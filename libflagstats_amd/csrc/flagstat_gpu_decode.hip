@@ -909,6 +909,10 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
     {
         const uint64_t pct = in.codec == 1 ? 190 : 125;
         if (in.by_size && usum * 100 < bytes * pct) return kGpuDecodeRejected;
+        // ... and the size rule proper (flagstat_blocks.hip, decode_on_gpu): a file below the knob's compressed size is taken if
+        // it decodes to at least 2.5 x the knob (default: 64 MiB of file or 160 MiB of flags)
+        const uint64_t from = in.codec == 0 ? knobs().lz4_gpu_min_bytes.load() : knobs().zstd_gpu_min_bytes.load();
+        if (in.by_size && bytes < from && usum * 2 < from * 5) return kGpuDecodeRejected;
     }
     // What the kernels cannot address is known from the index -- a capability limit, not damage.  LZ4: the workgroup kernel's
     // records carry 24-bit input and 28-bit output positions (status 10 if it met such a block); a file with a block of 16 MiB of

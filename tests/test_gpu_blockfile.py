@@ -276,6 +276,11 @@ def test_gpu_decoder_is_chosen_by_size_and_fails_loudly(gpu_decoder, tmp_path):
     assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", len(img)) == 0
     got, st = blockfile.flagstat_lz4_image(img, 2)
     assert np.array_equal(got, want) and st["gpu_decode"] == 1
+    # a byte below the knob the file is taken only if it decodes to 2.5 x the knob: LZ4-fast flags are 2.14 : 1
+    assert 5 * (len(img) + 1) > 2 * flags.nbytes
+    assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", len(img) + 1) == 0
+    got, st = blockfile.flagstat_lz4_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 0
     assert hip.FLAGSTATS_hip_set(b"lz4_gpu_min_bytes", 64 << 20) == 0
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 1) == 0
     assert hip.FLAGSTATS_hip_set(b"lz4_decoder", 3) != 0
@@ -654,3 +659,26 @@ def test_image_entries_take_any_buffer_without_copying_it(hip):
             assert np.array_equal(got, want) and st["n_flags"] == flags.size
         got, st = entry(b"", 2)
         assert not got.any() and st["n_flags"] == 0
+
+
+def test_shipped_size_rule_goes_by_what_a_file_decodes_to(hip):
+    """r05: the two decoders cross at 120-200 MB of DECODED flags whatever the codec and level, which is 27-95 MiB of file
+    (profiles/r05/decoder_crossover.log) -- so besides files of 64 MiB and more, the GPU decoders take smaller ones that decode to at
+    least 160 MiB: a 41 MiB Zstandard file of 90 M flags goes to the GPU, a 54 MiB LZ4-fast file of 60 M flags stays on the host."""
+    import oracle
+    from libflagstats_amd import blockfile
+    assert hip.FLAGSTATS_hip_get(b"lz4_decoder") == 2 and hip.FLAGSTATS_hip_get(b"zstd_decoder") == 2
+    assert hip.FLAGSTATS_hip_get(b"lz4_gpu_min_bytes") == 64 << 20 and hip.FLAGSTATS_hip_get(b"zstd_gpu_min_bytes") == 64 << 20
+    n = 90_000_000
+    flags = oracle.generate(oracle.GEN_NA12878, 7, 1, 0, n)
+    want = oracle.flagstat_generated(oracle.GEN_NA12878, 7, 1, 0, n)
+    z = bt.block_file_image(flags, mode="zstd", level=1)
+    assert (16 << 20) < len(z) < (64 << 20) and flags.nbytes >= (160 << 20)
+    got, st = blockfile.flagstat_zstd_image(z, 0)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 1
+    del z
+    m = 60_000_000
+    l4 = bt.block_file_image(flags[:m], mode="fast", level=2)
+    assert (16 << 20) < len(l4) < (64 << 20) and 2 * m < (160 << 20)
+    got, st = blockfile.flagstat_lz4_image(l4, 0)
+    assert np.array_equal(got, oracle.flagstat_generated(oracle.GEN_NA12878, 7, 1, 0, m)) and st["gpu_decode"] == 0

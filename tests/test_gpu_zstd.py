@@ -148,12 +148,21 @@ def test_gpu_zstd_decoder_is_chosen_by_size_and_rejects_loudly(zgpu, tmp_path):
     img = bt.block_file_image(flags, mode="zstd", level=1)
     want = expect(flags, bt.BLOCK_BYTES)[0]
     assert hip.FLAGSTATS_hip_set(b"zstd_decoder", 2) == 0
-    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", len(img) + 1) == 0
+    # the size rule: GPU for a file of at least `zstd_gpu_min_bytes`, or a smaller one that decodes to at least 2.5 x that
+    assert 5 * len(img) < 2 * flags.nbytes                                   # (this file: 4.2 : 1)
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", flags.nbytes) == 0   # neither: host threads
+    got, st = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 0
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", len(img)) == 0       # by its compressed size
+    got, st = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 1
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 2 * flags.nbytes // 5) == 0   # smaller than the knob, but it decodes to 2.5 x it
+    got, st = blockfile.flagstat_zstd_image(img, 2)
+    assert np.array_equal(got, want) and st["gpu_decode"] == 1
+    assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", 2 * flags.nbytes // 5 + 2) == 0   # ... and just not
     got, st = blockfile.flagstat_zstd_image(img, 2)
     assert np.array_equal(got, want) and st["gpu_decode"] == 0
     assert hip.FLAGSTATS_hip_set(b"zstd_gpu_min_bytes", len(img)) == 0
-    got, st = blockfile.flagstat_zstd_image(img, 2)
-    assert np.array_equal(got, want) and st["gpu_decode"] == 1
     # a damaged payload: by size the file goes to libzstd, whose verdict counts; forced, the GPU decoder's code is the error
     bad = bytearray(img)
     bad[8 + 40] ^= 0x55
