@@ -268,25 +268,44 @@ __device__ void lz4wg_walk(WgLds& L, const uint8_t* __restrict__ src, const uint
 #pragma unroll
         for (int k = 0; k < 8; ++k) asm volatile("" : "+v"(w[k]));
         tock(t_dp);
-        // ---- (2) the chain through the tile: entry of every segment.  Straight-line (a taken branch costs this wave ~50
-        // cycles, four of them per segment made this loop the most expensive part of the tile): selects instead of
-        // branches, one exit test per 8 segments; segments behind the end compute garbage that nothing uses.
-        uint32_t ent = 0, e = 0, nvalid = nseg, e_next = 0;
+        // ---- (2) the chain through the tile: entry of every segment.  r04 walked it: 64 dependent scalar table lookups, 186 cycles
+        // each = 12 k of a tile's 27 k cycles, on the one wave every byte of the block waits for.  r05: a prefix scan over the
+        // segments' exit tables instead -- lane s ends up with F(s) = T(s) o ... o T(0), six doubling rounds in which every lane
+        // composes its table with the one 1, 2, 4 ... 32 lanes to its left (twelve 5-bit entries, looked up in a 60-bit word; an
+        // exit of 12 or more -- the tile ends behind that segment -- stays what it is through every later table).  F(s)(0) is the
+        // exit of segment s for the chain that enters the tile at 0, the entry of segment s + 1; the first lane whose exit is 12 or
+        // more, or the tile's last segment, ends the tile.
+        uint32_t flo = tlo, fhi = thi;
+        {
+            constexpr uint64_t kIdentity = 0ull | (1ull << 5) | (2ull << 10) | (3ull << 15) | (4ull << 20) | (5ull << 25) | (6ull << 30) | (7ull << 35) |
+                                           (8ull << 40) | (9ull << 45) | (10ull << 50) | (11ull << 55);
 #pragma unroll
-        for (uint32_t sg = 0; sg < kWgTileSegs; ++sg) {
-            if ((sg & 7u) == 0u && sg >= nvalid) break;
-            ent = lane == sg ? e : ent;
-            // (the builtin returns int: through uint32_t, or the cast to 64 bits extends bit 31 over the upper entries)
-            const uint64_t tab = static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(tlo, sg))) |
-                                 (static_cast<uint64_t>(static_cast<uint32_t>(__builtin_amdgcn_readlane(thi, sg))) << 32);
-            const uint32_t e2 = static_cast<uint32_t>(tab >> (e * 5u)) & 31u;
-            // the tile ends behind this segment: it was the last one, or the chain leaves it at 12 or more (or through a
-            // token for the scalar code: 31, which the members pass turns into a stop inside the segment)
-            const bool last = (sg + 1u == nvalid) | (e2 >= 12u);
-            e_next = (last & (sg < nvalid)) ? e2 : e_next;
-            nvalid = last ? umin(nvalid, sg + 1u) : nvalid;
-            e = e2 >= 12u ? 0u : e2;
+            for (uint32_t d = 1; d < kWgTileSegs; d <<= 1) {
+                const int from = static_cast<int>((lane - d) << 2);
+                uint32_t glo = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(from, static_cast<int>(flo)));
+                uint32_t ghi = static_cast<uint32_t>(__builtin_amdgcn_ds_bpermute(from, static_cast<int>(fhi)));
+                glo = lane < d ? static_cast<uint32_t>(kIdentity) : glo;
+                ghi = lane < d ? static_cast<uint32_t>(kIdentity >> 32) : ghi;
+                const uint64_t g = static_cast<uint64_t>(glo) | (static_cast<uint64_t>(ghi) << 32);
+                const uint64_t f = static_cast<uint64_t>(flo) | (static_cast<uint64_t>(fhi) << 32);
+                uint64_t n = 0;
+#pragma unroll
+                for (uint32_t en = 0; en < 12u; ++en) {
+                    const uint32_t v = static_cast<uint32_t>(g >> (5u * en)) & 31u;      // where the tables to the left leave a chain that entered them at `en`
+                    const uint32_t t = static_cast<uint32_t>(f >> ((5u * v) & 63u)) & 31u;   // ... and this lane's tables take it from there (v >= 12: not used)
+                    n |= static_cast<uint64_t>(v >= 12u ? v : t) << (5u * en);
+                }
+                flo = static_cast<uint32_t>(n);
+                fhi = static_cast<uint32_t>(n >> 32);
+            }
         }
+        const uint32_t e2 = flo & 31u;   // exit of this lane's segment for the chain that entered the tile at 0 (>= 12: the tile has ended at or before it)
+        const uint32_t ent_shifted = static_cast<uint32_t>(__builtin_amdgcn_update_dpp(0, static_cast<int>(e2), 0x138, 0xF, 0xF, false));  // wave_shr:1 (lane 0: 0)
+        const uint64_t endm = __builtin_amdgcn_ballot_w64((e2 >= 12u) | (lane + 1u >= nseg));
+        const uint32_t last_seg = static_cast<uint32_t>(__builtin_ctzll(endm));   // (nseg >= 1: lane nseg - 1 is in the mask)
+        uint32_t nvalid = last_seg + 1u;
+        const uint32_t e_next = __builtin_amdgcn_readlane(e2, last_seg);
+        const uint32_t ent = ent_shifted;   // (lanes up to last_seg: below 12; the others are not used)
         tock(t_chain);
         // ---- (3) members: the positions reachable from the entry; their output bytes; straight-line
         uint32_t r_lo = lane < nvalid ? 1u << ent : 0u, r_hi = 0;  // reach: bit i = position i is a token (bits >= 32: in the next segment)

@@ -5,7 +5,7 @@ a chain through it lands in the next segment, from the token alone (a sequence w
 3 + literals (+ 1 match-length byte) long); (2) the chain through the tile, segment by segment, from a 12-entry exit table
 per segment; (3) forward again, the positions reachable from each segment's entry.  Tokens whose literal length continues
 in further bytes (or whose match-length byte is 255) stop the tile.  This file pins that restatement -- the tables' sizes,
-the stop rules, the tile-end arithmetic -- on LZ4-fast and LZ4-HC streams of flag data and on streams full of long matches
+the stop rules, the tile-end arithmetic, and (r05) that the prefix SCAN over the exit tables gives what the serial walk gives -- on LZ4-fast and LZ4-HC streams of flag data and on streams full of long matches
 and literal runs; the HIP code itself is checked on the GPU (tests/test_gpu_blockfile.py)."""
 import os
 import sys
@@ -90,6 +90,27 @@ def walk_tile(comp, ip):
         if last:
             nvalid = min(nvalid, sg + 1)
         e = 0 if e2 >= TAB else e2
+    # r05: the kernel does not walk that chain any more, it SCANS it -- lane s ends up with F(s) = T(s) o ... o T(0) after six
+    # doubling rounds (a lane composes its table with the one 1, 2, 4 ... lanes to its left; an exit of 12 or more stays what it
+    # is), F(s)(0) is segment s's exit, the first exit of 12 or more (or the last segment) ends the tile.  Same entries, same end.
+    ident = sum(e << (5 * e) for e in range(TAB))
+    F = list(tabs)
+    d = 1
+    while d < SEGS:
+        G = [F[s - d] if s >= d else ident for s in range(SEGS)]
+        nF = []
+        for s in range(SEGS):
+            n = 0
+            for en in range(TAB):
+                v = (G[s] >> (5 * en)) & 31
+                t = (F[s] >> ((5 * v) & 63)) & 31
+                n |= (v if v >= TAB else t) << (5 * en)
+            nF.append(n)
+        F, d = nF, d * 2
+    exits = [f & 31 for f in F]
+    last_seg = min(s for s in range(SEGS) if exits[s] >= TAB or s + 1 >= nseg)
+    assert last_seg + 1 == nvalid and exits[last_seg] == e_next, ("scan", ip, last_seg, nvalid, exits[last_seg], e_next)
+    assert [0] + exits[:last_seg] == ent[:nvalid], ("scan entries", ip)
     members = []
     for s in range(nvalid):
         reach, stop = 1 << ent[s], SEG
