@@ -446,7 +446,12 @@ def main():
     counters = torch.zeros(32, dtype=torch.int64, device=dev)
     torch.cuda.synchronize()
 
-    overlap = multi and (args.overlap or args.calibrate) and not args.no_overlap   # default: in line
+    # Strong scaling shrinks the shard with N (8 GiB total: 1 GiB shards at N = 8, K1 ~150 us) while K2 + the all-reduce
+    # do not shrink: in line they cost more than the 7 us per step that 7.5x leaves (DESIGN.md "Multi-GPU", budget table),
+    # so --strong times both forms first and takes the faster one unless a form was asked for explicitly.
+    if args.strong and multi and not (args.overlap or args.no_overlap):
+        args.calibrate = True
+    overlap = multi and (args.overlap or args.calibrate) and not args.no_overlap   # weak scaling default: in line
     main_stream = torch.cuda.current_stream(dev)
     comm_stream = torch.cuda.Stream(device=dev) if overlap else None
     RING = 8                   # counter buffers in flight between the launch stream and the all-reduce stream

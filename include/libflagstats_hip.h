@@ -104,6 +104,13 @@ void FLAGSTATS_hip_shutdown(void);          /* releases every engine (close sess
 const char* FLAGSTATS_hip_last_error(void); /* text of the last failure on this thread ("" if none) */
 int FLAGSTATS_hip_device_id(void);          /* device the context is bound to, -1 before init */
 int FLAGSTATS_hip_compute_units(void);      /* CU count of that device, -1 before init */
+/* fork(): unlike the reference's pure function (libflagstats.h:3024-3070) this library is an engine -- a HIP context, streams,
+ * helper threads -- that does not exist in a child fork()ed after its first use.  Every entry point refuses such a child
+ * before touching any GPU state: a message naming the fork on stderr and in FLAGSTATS_hip_last_error, a non-zero / NULL
+ * return (the three reference-shaped entry points then abort() per "on_error"); release-type entries (shutdown, *_free,
+ * *_destroy, stream_close) do nothing there.  Use the "spawn" start method, or make the first call after the fork.
+ * FLAGSTATS_hip_forked: 1 in such a child, else 0 (touches nothing, claims nothing). */
+int FLAGSTATS_hip_forked(void);
 
 /* explicit contexts: a private engine (own streams, staging and workspaces) on `device`; several may
  * exist per device and are fully independent of each other and of the default engines -- one per

@@ -79,6 +79,7 @@ SIGNATURES = {
     "FLAGSTATS_hip_last_error": (ctypes.c_char_p, []),
     "FLAGSTATS_hip_device_id": (ctypes.c_int, []),
     "FLAGSTATS_hip_compute_units": (ctypes.c_int, []),
+    "FLAGSTATS_hip_forked": (ctypes.c_int, []),
     "FLAGSTATS_hip_set": (ctypes.c_int, [ctypes.c_char_p, ctypes.c_uint64]),
     "FLAGSTATS_hip_get": (ctypes.c_uint64, [ctypes.c_char_p]),
     "FLAGSTATS_text_to_u16": (ctypes.c_int64, [ctypes.c_char_p, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_uint64]),
@@ -168,6 +169,12 @@ def lib() -> ctypes.CDLL:
     """Load libflagstats_hip.so (once) and attach the prototypes."""
     global _lib
     if _lib is not None:
+        if _lib.FLAGSTATS_hip_forked():
+            # the C entry points refuse a forked child themselves; raising here names the remedy before any call is made
+            raise FlagstatsHipError(
+                "this process (pid %d) was fork()ed after libflagstats_hip had been used: a HIP context, its streams and the "
+                "library's worker threads do not exist in a forked child. Start workers with the \"spawn\" start method "
+                "(multiprocessing.get_context(\"spawn\")), or make the first call after the fork." % os.getpid())
         return _lib
     _share_hip_runtime_with_torch()
     if not os.path.exists(LIB_PATH):

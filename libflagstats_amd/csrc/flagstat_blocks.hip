@@ -656,6 +656,7 @@ int run_gpu_lz4(fsint::Engine& eng, int codec, const uint8_t* img, int fd, uint6
 int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec,
                bool superset = false)
 {
+    if (fsint::process_guard("FLAGSTATS_hip_blockimage_*")) return -1;
     if (!out) return fsint::fail_text("NULL out");
     if (!image && bytes) return fsint::fail_text("NULL image");
     block_decode_fn fn = nullptr;
@@ -679,6 +680,7 @@ int blockimage(const void* image, uint64_t bytes, int threads, uint64_t* out, FL
 
 int blockfile(const char* path, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, int codec, bool superset = false)
 {
+    if (fsint::process_guard("FLAGSTATS_hip_blockfile*")) return -1;
     if (!out) return fsint::fail_text("NULL out");
     if (!path) return fsint::fail_text("NULL path");
     block_decode_fn fn = nullptr;
@@ -789,6 +791,7 @@ namespace {
 // a host array through the chunk pipeline (1 MiB slices copied by the workers)
 int host_staged(fsint::Engine& eng, const uint16_t* array, uint64_t n, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats, bool superset)
 {
+    if (fsint::process_guard("FLAGSTATS_hip_host_staged_u16")) return -1;
     if (!out) return fsint::fail_text("NULL out");
     if (n && !array) return fsint::fail_text("NULL array with n > 0");
     Source in;
@@ -801,6 +804,7 @@ int host_staged(fsint::Engine& eng, const uint16_t* array, uint64_t n, int threa
 
 int file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_stats* stats, bool superset)
 {
+    if (fsint::process_guard("FLAGSTATS_hip_file_raw*")) return -1;
     if (!out) return fsint::fail_text("NULL out");
     if (!path) return fsint::fail_text("NULL path");
     const char* io = std::getenv("FLAGSTATS_HIP_RAW_IO");
@@ -859,6 +863,7 @@ extern "C" {
 
 int FLAGSTATS_hip_host_staged_u16(const uint16_t* array, uint64_t n, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats)
 {
+    FS_ENTRY();
     fsint::Engine* eng = fsint::default_engine();
     return eng ? host_staged(*eng, array, n, threads, out, stats, false) : -1;
 }

@@ -92,6 +92,7 @@ extern "C" {
 
 int FLAGSTATS_hip_available(void)
 {
+    if (fsint::process_guard(__func__)) return 0;
     if (fsint::default_device() >= 0) return 1;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) {
@@ -107,6 +108,7 @@ int FLAGSTATS_hip_available(void)
 
 int FLAGSTATS_hip_device_count(void)
 {
+    if (fsint::process_guard(__func__)) return 0;
     int count = 0;
     if (hipGetDeviceCount(&count) != hipSuccess) {
         (void)hipGetLastError();
@@ -115,20 +117,30 @@ int FLAGSTATS_hip_device_count(void)
     return count;
 }
 
-int FLAGSTATS_hip_init(int device) { return fsint::select_default_device(device); }
+int FLAGSTATS_hip_init(int device)
+{
+    FS_ENTRY();
+    return fsint::select_default_device(device);
+}
 
 void FLAGSTATS_hip_shutdown(void)
 {
+    FS_ENTRY_RELEASE();
     fsint::multi_forget();
     fsint::shutdown_all();
 }
 
 const char* FLAGSTATS_hip_last_error(void) { return fsint::last_error_text(); }
 
-int FLAGSTATS_hip_device_id(void) { return fsint::default_device(); }
+int FLAGSTATS_hip_device_id(void) { return fsint::process_forked() ? -1 : fsint::default_device(); }
+
+/* 1 in a child fork()ed after the library was first used (every other entry point refuses such a process), else 0; never
+ * claims the library for the calling process and touches no GPU state */
+int FLAGSTATS_hip_forked(void) { return fsint::process_forked() ? 1 : 0; }
 
 int FLAGSTATS_hip_compute_units(void)
 {
+    FS_ENTRY();
     if (fsint::default_device() < 0) return -1;
     Engine* e = fsint::default_engine();
     return e ? e->cus : -1;
@@ -136,6 +148,7 @@ int FLAGSTATS_hip_compute_units(void)
 
 int FLAGSTATS_hip_set(const char* key, uint64_t value)
 {
+    FS_ENTRY();
     if (!key) return fail_text("NULL key");
     fsint::Knobs& k = fsint::knobs();
     if (!std::strcmp(key, "blocks_per_cu")) {
@@ -226,6 +239,7 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
 
 uint64_t FLAGSTATS_hip_get(const char* key)
 {
+    if (fsint::process_guard(__func__)) return 0;
     if (!key) return 0;
     fsint::Knobs& k = fsint::knobs();
     if (!std::strcmp(key, "blocks_per_cu")) return k.blocks_per_cu ? k.blocks_per_cu.load() : 1;
@@ -293,6 +307,7 @@ uint64_t FLAGSTATS_hip_get(const char* key)
 
 int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
 {
+    FS_ENTRY();
     if (!out) return fail_text("NULL out");
     Engine* e = fsint::default_engine();
     if (!e) return -1;
@@ -301,6 +316,7 @@ int FLAGSTATS_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
 
 int FLAGSTATS_u16_x64_superset(const uint16_t* array, uint64_t n, uint64_t* out)
 {
+    FS_ENTRY();
     if (!out) return fail_text("NULL out");
     Engine* e = fsint::default_engine();
     if (!e) return -1;
@@ -342,6 +358,7 @@ FLAGSTATS_func FLAGSTATS_get_function(uint32_t n_len)
 /* ---- explicit contexts ---- */
 FLAGSTATS_hip_ctx* FLAGSTATS_hip_ctx_create(int device)
 {
+    FS_ENTRY_PTR();
     Engine* e = fsint::engine_create(device);
     if (!e) return nullptr;
     FLAGSTATS_hip_ctx* c = new FLAGSTATS_hip_ctx;
@@ -351,21 +368,24 @@ FLAGSTATS_hip_ctx* FLAGSTATS_hip_ctx_create(int device)
 
 void FLAGSTATS_hip_ctx_destroy(FLAGSTATS_hip_ctx* ctx)
 {
+    FS_ENTRY_RELEASE();
     if (!ctx) return;
     fsint::engine_destroy(ctx->engine);  // after a FLAGSTATS_hip_shutdown: only drops the (dead) object
     delete ctx;
 }
 
-int FLAGSTATS_hip_ctx_device(const FLAGSTATS_hip_ctx* ctx) { return (ctx && !ctx->engine->dead.load()) ? ctx->engine->device : -1; }
+int FLAGSTATS_hip_ctx_device(const FLAGSTATS_hip_ctx* ctx) { return (ctx && !fsint::process_forked() && !ctx->engine->dead.load()) ? ctx->engine->device : -1; }
 
 int FLAGSTATS_hip_ctx_u16_x64(FLAGSTATS_hip_ctx* ctx, const uint16_t* array, uint64_t n, uint64_t* out)
 {
+    FS_ENTRY();
     if (!ctx || !out) return fail_text("NULL context or out");
     return fsint::count_host(*ctx->engine, array, n, out);
 }
 
 int FLAGSTATS_hip_ctx_device_u16_sync(FLAGSTATS_hip_ctx* ctx, const uint16_t* d_array, uint64_t n, uint64_t* out)
 {
+    FS_ENTRY();
     if (!ctx || !out) return fail_text("NULL context or out");
     if (n) {
         int dev = -1;
@@ -379,17 +399,20 @@ int FLAGSTATS_hip_ctx_device_u16_sync(FLAGSTATS_hip_ctx* ctx, const uint16_t* d_
 /* ---- device-resident arrays ---- */
 int FLAGSTATS_hip_device_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
 {
+    FS_ENTRY();
     // `stream` is used as given: NULL is HIP's null stream (what torch's default stream is)
     return fsint::count_on_user_stream(d_array, n, d_out, stream, fsint::OP_FLAGSTAT);
 }
 
 int FLAGSTATS_hip_device_u16_store(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
 {
+    FS_ENTRY();
     return fsint::count_on_user_stream(d_array, n, d_out, stream, fsint::OP_FLAGSTAT_STORE);
 }
 
 int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t* out)
 {
+    FS_ENTRY();
     if (!out) return fail_text("NULL out");
     Engine* e = engine_of_array(d_array, n);
     if (!e) return -1;
@@ -398,11 +421,13 @@ int FLAGSTATS_hip_device_u16_sync(const uint16_t* d_array, uint64_t n, uint64_t*
 
 int FLAGSTATS_hip_device_u16_superset(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
 {
+    FS_ENTRY();
     return fsint::count_on_user_stream(d_array, n, d_out, stream, fsint::OP_FLAGSTAT | fsint::OP_SUPERSET);
 }
 
 int FLAGSTATS_hip_device_u16_superset_sync(const uint16_t* d_array, uint64_t n, uint64_t* out)
 {
+    FS_ENTRY();
     if (!out) return fail_text("NULL out");
     Engine* e = engine_of_array(d_array, n);
     if (!e) return -1;
@@ -412,6 +437,7 @@ int FLAGSTATS_hip_device_u16_superset_sync(const uint16_t* d_array, uint64_t n, 
 /* ---- memory helpers ---- */
 void* FLAGSTATS_hip_host_alloc(size_t bytes)
 {
+    FS_ENTRY_PTR();
     Engine* e = fsint::default_engine();
     if (!e) return nullptr;
     DeviceGuard guard(e->device);
@@ -421,11 +447,13 @@ void* FLAGSTATS_hip_host_alloc(size_t bytes)
 
 void FLAGSTATS_hip_host_free(void* p)
 {
+    FS_ENTRY_RELEASE();
     if (p) (void)hipHostFree(p);
 }
 
 void* FLAGSTATS_hip_device_alloc(size_t bytes)
 {
+    FS_ENTRY_PTR();
     Engine* e = fsint::default_engine();
     if (!e) return nullptr;
     DeviceGuard guard(e->device);
@@ -441,6 +469,7 @@ void* FLAGSTATS_hip_device_alloc(size_t bytes)
 
 void* FLAGSTATS_hip_device_alloc_on(int device, size_t bytes)
 {
+    FS_ENTRY_PTR();
     Engine* e = fsint::engine_for_device(device);
     if (!e) return nullptr;
     DeviceGuard guard(e->device);
@@ -456,23 +485,27 @@ void* FLAGSTATS_hip_device_alloc_on(int device, size_t bytes)
 
 void FLAGSTATS_hip_device_free(void* p)
 {
+    FS_ENTRY_RELEASE();
     if (p) (void)hipFree(p);
 }
 
 int FLAGSTATS_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes)
 {
+    FS_ENTRY();
     HIP_TRY(hipMemcpy(d_dst, h_src, bytes, hipMemcpyHostToDevice));
     return 0;
 }
 
 int FLAGSTATS_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes)
 {
+    FS_ENTRY();
     HIP_TRY(hipMemcpy(h_dst, d_src, bytes, hipMemcpyDeviceToHost));
     return 0;
 }
 
 int FLAGSTATS_hip_synchronize(void)
 {
+    FS_ENTRY();
     Engine* e = fsint::default_engine();
     if (!e) return -1;
     DeviceGuard guard(e->device);
@@ -484,6 +517,7 @@ int FLAGSTATS_hip_synchronize(void)
 int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, uint32_t mask,
                                uint64_t first_index, void* stream)
 {
+    FS_ENTRY();
     if (n == 0) return 0;
     int dev = -1;
     int rc = fsint::device_of_pointer(d_array, "d_array", &dev);
@@ -501,6 +535,7 @@ int FLAGSTATS_hip_generate_u16(uint16_t* d_array, uint64_t n, int kind, uint64_t
 int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmup, int reps, float* ms_total,
                                   uint64_t* out)
 {
+    FS_ENTRY();
     if (!ms_total || reps < 1 || warmup < 0) return fail_text("bad timing arguments");
     Engine* ep = engine_of_array(d_array, n);
     if (!ep) return -1;
@@ -534,6 +569,7 @@ int FLAGSTATS_hip_time_device_u16(const uint16_t* d_array, uint64_t n, int warmu
 int FLAGSTATS_hip_time_device_u16_rotating(const uint16_t* d_array, uint64_t n, uint64_t stride_flags, uint32_t slots,
                                            int warmup, int reps, float* ms_total, uint64_t* out)
 {
+    FS_ENTRY();
     if (!ms_total || reps < 1 || warmup < 0 || slots < 1 || stride_flags < n || (stride_flags & 1)) return fail_text("bad timing arguments");
     Engine* ep = engine_of_array(d_array, n);
     if (!ep) return -1;
@@ -568,6 +604,7 @@ int FLAGSTATS_hip_time_device_u16_rotating(const uint16_t* d_array, uint64_t n, 
 
 int FLAGSTATS_hip_sclk_under_load(const uint16_t* d_array, uint64_t n, int launches, double* sclk_mhz)
 {
+    FS_ENTRY();
     if (!sclk_mhz || launches < 1 || launches > 10000) return fail_text("bad arguments");
     Engine* ep = engine_of_array(d_array, n);
     if (!ep) return -1;
@@ -620,6 +657,7 @@ int FLAGSTATS_hip_sclk_under_load(const uint16_t* d_array, uint64_t n, int launc
 /* ---- row f4: plain positional popcount (python/libalgebra.h:3496-3551) ---- */
 int FLAGSTATS_hip_pospopcnt_u16_x64(const uint16_t* array, uint64_t n, uint64_t* out)
 {
+    FS_ENTRY();
     if (!out) return fail_text("NULL out");
     Engine* e = fsint::default_engine();
     if (!e) return -1;
@@ -640,6 +678,7 @@ int STORM_pospopcnt_u16(const uint16_t* data, size_t len, uint32_t* out)
 
 int FLAGSTATS_hip_device_pospopcnt_u16(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* stream)
 {
+    FS_ENTRY();
     return fsint::count_on_user_stream(d_array, n, d_out, stream, fsint::OP_POSPOPCNT);
 }
 
@@ -651,6 +690,7 @@ static int probe_common(const void* d_buf, int warmup, int reps, float* ms_total
                         hipError_t (*launch)(const void*, uint64_t, uint32_t, uint32_t*, hipStream_t, const int*),
                         uint64_t bytes, uint32_t grid_override, const int* params)
 {
+    FS_ENTRY();
     if (!ms_total || reps < 1 || warmup < 0) return fail_text("bad timing arguments");
     int dev = -1;
     int rc = fsint::device_of_pointer(d_buf, "d_buf", &dev);

@@ -153,6 +153,16 @@ class DeviceGuard {
     bool ok_ = false;
 };
 
+// First statement of every C entry that touches engine or HIP state.  0: this process owns the library (the first caller's
+// process claims it).  Non-zero in a child fork()ed after that: the error (naming the fork and the remedy) is recorded and
+// printed -- unless `quiet`, for the release-type entries a child's interpreter may run on objects it inherited -- and no
+// mutex, stream or HIP call has been touched.
+int process_guard(const char* entry, bool quiet = false);
+bool process_forked();                             // true in such a child (never claims)
+#define FS_ENTRY() do { if (fsint::process_guard(__func__)) return -1; } while (0)
+#define FS_ENTRY_PTR() do { if (fsint::process_guard(__func__)) return nullptr; } while (0)
+#define FS_ENTRY_RELEASE() do { if (fsint::process_guard(__func__, true)) return; } while (0)
+
 int fail_text(const char* msg);                    // records (thread-local) + prints, returns -1
 int fail_hip(const char* what, hipError_t e);      // same with the HIP error text, returns non-zero
 int fail_again(const char* full_text, int rc);     // re-records a message another thread already printed

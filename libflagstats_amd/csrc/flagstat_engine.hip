@@ -32,6 +32,15 @@ constexpr uint64_t kSmallPinnedFlags = 1ull << 17; // up to here the pinned buff
 
 thread_local std::string g_err;
 
+// fork(): the reference's entry point is a pure function (libflagstats.h:3024-3070) and works in a forked child; this one is
+// an engine -- a HIP context, streams, helper threads, mutexes, a polling protocol with sequence numbers -- none of which
+// exists in a child.  The pid that first used the library owns it (process_guard); a child forked after that is marked by
+// the atfork handler (and recognised by its pid where no handler ran: vfork, a raw clone) and every entry point refuses it
+// before it touches a mutex, a stream or a HIP call.  Nothing is freed in the child: the memory is the parent's.
+std::atomic<pid_t> g_owner_pid{0};
+std::atomic<bool> g_forked{false};
+void mark_forked_child() { g_forked.store(true, std::memory_order_relaxed); }
+
 std::mutex g_reg_mu;                               // registry only; never held across GPU work
 std::vector<Engine*> g_default;                    // index = device id; the registry holds one reference each
 std::vector<Engine*> g_private;                    // engine_create()d, for shutdown_all
@@ -272,8 +281,46 @@ int engine_setup(Engine& e, int device)
 
 Knobs& knobs()
 {
-    read_env_knobs();
+    if (!g_forked.load(std::memory_order_relaxed)) read_env_knobs();   // (a forked child inherits what its parent read)
     return g_knobs;
+}
+
+bool process_forked()
+{
+    if (g_forked.load(std::memory_order_relaxed)) return true;
+    const pid_t owner = g_owner_pid.load(std::memory_order_relaxed);
+    if (owner != 0 && owner != getpid()) {
+        g_forked.store(true, std::memory_order_relaxed);   // forked without the handler having run
+        return true;
+    }
+    return false;
+}
+
+int process_guard(const char* entry, bool quiet)
+{
+    if (!g_forked.load(std::memory_order_relaxed)) {
+        const pid_t me = getpid();
+        pid_t owner = g_owner_pid.load(std::memory_order_acquire);
+        if (owner == me) return 0;
+        if (owner == 0) {
+            if (g_owner_pid.compare_exchange_strong(owner, me, std::memory_order_acq_rel)) {
+                (void)pthread_atfork(nullptr, nullptr, mark_forked_child);
+                read_env_knobs();   // so that a child never has to (on_error is part of how it is refused)
+                return 0;
+            }
+            if (owner == me) return 0;   // another thread of this process was first
+        }
+        g_forked.store(true, std::memory_order_relaxed);
+    }
+    if (quiet) return -1;
+    char buf[640];
+    std::snprintf(buf, sizeof buf,
+                  "%s was called in a process (pid %d) that was fork()ed from the one that uses the GPU engine (pid %d). A HIP context, "
+                  "its streams and this library's worker threads do not exist in a forked child, so nothing was counted and nothing "
+                  "was touched. Start worker processes with the \"spawn\" start method (Python: multiprocessing.get_context(\"spawn\")), "
+                  "or make the library's first call after the fork.",
+                  entry ? entry : "libflagstats_hip", static_cast<int>(getpid()), static_cast<int>(g_owner_pid.load(std::memory_order_relaxed)));
+    return fail_text(buf);
 }
 
 int fail_hip(const char* what, hipError_t e)
@@ -327,6 +374,7 @@ int default_device() { return g_default_device.load(); }
 
 Engine* engine_for_device(int device)
 {
+    if (process_guard("libflagstats_hip (engine lookup)")) return nullptr;
     read_env_knobs();
     if (device < 0) {
         device = g_default_device.load();
@@ -387,6 +435,7 @@ int select_default_device(int device)
 
 Engine* engine_create(int device)
 {
+    if (process_guard("libflagstats_hip (engine creation)")) return nullptr;
     read_env_knobs();
     if (device < 0) {
         device = g_default_device.load();
@@ -470,6 +519,7 @@ void engine_destroy(Engine* e)
 
 void shutdown_all()
 {
+    if (process_forked()) return;   // the engines are the parent's
     std::vector<Engine*> defaults, privates;
     {
         std::lock_guard<std::mutex> lk(g_reg_mu);

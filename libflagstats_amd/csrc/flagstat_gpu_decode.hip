@@ -1008,6 +1008,7 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
 
 extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t bytes, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
 {
+    FS_ENTRY();
     if (!out) return fsint::fail_text("NULL out");
     if (!image && bytes) return fsint::fail_text("NULL image");
     fsint::Engine* ep = fsint::default_engine();

@@ -134,6 +134,7 @@ void FLAGSTATS_hip_shard_range(uint64_t n, int rank, int world, uint64_t* begin,
 
 int FLAGSTATS_hip_multi_u16_x64(const uint16_t* array, uint64_t n, const int* devices, int ndev, uint64_t* out)
 {
+    FS_ENTRY();
     if (!out) return fail_text("NULL out");
     if (ndev < 1 || ndev > 64) return fail_text("ndev must be 1..64");
     if (n && !array) return fail_text("NULL array with n > 0");
@@ -165,6 +166,7 @@ int FLAGSTATS_hip_multi_u16_x64(const uint16_t* array, uint64_t n, const int* de
 
 int FLAGSTATS_hip_multi_device_u16(const uint16_t* const* d_arrays, const uint64_t* n, int nshards, uint64_t* out)
 {
+    FS_ENTRY();
     if (!out) return fail_text("NULL out");
     if (nshards < 0 || (nshards && (!d_arrays || !n))) return fail_text("bad shard list");
     // every shard is counted where it lives, on its device's default engine; engines are locked in
@@ -214,6 +216,7 @@ int FLAGSTATS_hip_multi_device_u16(const uint16_t* const* d_arrays, const uint64
 /* ---- one process per device: RCCL ---- */
 int FLAGSTATS_hip_comm_unique_id(void* id128)
 {
+    FS_ENTRY();
     if (!id128) return fail_text("NULL id buffer");
     const Rccl* r = rccl();
     if (!r) return -1;
@@ -227,6 +230,7 @@ int FLAGSTATS_hip_comm_unique_id(void* id128)
 
 void* FLAGSTATS_hip_comm_init_rank(const void* id128, int nranks, int rank, int device)
 {
+    FS_ENTRY_PTR();
     if (!id128 || nranks < 1 || rank < 0 || rank >= nranks) {
         fail_text("bad communicator arguments");
         return nullptr;
@@ -250,6 +254,7 @@ void* FLAGSTATS_hip_comm_init_rank(const void* id128, int nranks, int rank, int 
 
 int FLAGSTATS_hip_comm_destroy(void* comm)
 {
+    FS_ENTRY();
     if (!comm) return 0;
     const Rccl* r = rccl();
     if (!r) return -1;
@@ -259,6 +264,7 @@ int FLAGSTATS_hip_comm_destroy(void* comm)
 
 int FLAGSTATS_hip_comm_count(void* comm)
 {
+    FS_ENTRY();
     if (!comm) return fail_text("NULL communicator");
     const Rccl* r = rccl();
     if (!r) return -1;
@@ -273,6 +279,7 @@ int FLAGSTATS_hip_comm_count(void* comm)
 // what it was measured with.
 int FLAGSTATS_hip_comm_library(char* path, uint64_t cap, int* version)
 {
+    FS_ENTRY();
     const Rccl* r = rccl();
     if (!r) return -1;
     if (path && cap) {
@@ -294,6 +301,7 @@ int FLAGSTATS_hip_comm_library(char* path, uint64_t cap, int* version)
 
 int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* stream)
 {
+    FS_ENTRY();
     if (!d_counters || !comm) return fail_text("NULL counters or communicator");
     const Rccl* r = rccl();
     if (!r) return -1;
@@ -312,6 +320,7 @@ int FLAGSTATS_hip_allreduce_counters(uint64_t* d_counters, void* comm, void* str
 
 int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device)
 {
+    FS_ENTRY();
     Engine* e = fsint::engine_for_device(device);
     if (!e) return -1;
     DeviceGuard guard(e->device);
@@ -325,6 +334,7 @@ int FLAGSTATS_hip_stream_wait_stream(void* waiter, void* on, int device)
 int FLAGSTATS_hip_device_u16_allreduce_overlapped(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream,
                                                   void* comm_stream)
 {
+    FS_ENTRY();
     int rc = FLAGSTATS_hip_device_u16_store(d_array, n, d_out, stream);  // K1 + K2 on the launch stream
     if (rc) return rc;
     int dev = -1;
@@ -346,6 +356,7 @@ int FLAGSTATS_hip_device_u16_allreduce_overlapped(const uint16_t* d_array, uint6
 
 int FLAGSTATS_hip_device_u16_allreduce(const uint16_t* d_array, uint64_t n, uint64_t* d_out, void* comm, void* stream)
 {
+    FS_ENTRY();
     int rc = FLAGSTATS_hip_device_u16_store(d_array, n, d_out, stream);  // K1 + K2, d_out = this shard's counters
     if (rc) return rc;
     return FLAGSTATS_hip_allreduce_counters(d_out, comm, stream);

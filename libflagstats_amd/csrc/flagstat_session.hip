@@ -69,6 +69,7 @@ extern "C" {
 
 FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void)
 {
+    FS_ENTRY_PTR();
     fsint::Engine* eng = fsint::default_engine();
     if (!eng) return nullptr;
     fsint::DeviceGuard guard(eng->device);
@@ -107,6 +108,7 @@ FLAGSTATS_hip_stream* FLAGSTATS_hip_stream_open(void)
 
 uint16_t* FLAGSTATS_hip_stream_acquire(FLAGSTATS_hip_stream* s, uint64_t n)
 {
+    FS_ENTRY_PTR();
     if (!s) return nullptr;
     std::lock_guard<std::mutex> lk(s->mu);
     const uint64_t padded = (2 * n + 15) & ~15ull;
@@ -124,6 +126,7 @@ uint16_t* FLAGSTATS_hip_stream_acquire(FLAGSTATS_hip_stream* s, uint64_t n)
 
 int FLAGSTATS_hip_stream_commit(FLAGSTATS_hip_stream* s, uint64_t n)
 {
+    FS_ENTRY();
     if (!s) return fsint::fail_text("NULL session");
     std::lock_guard<std::mutex> lk(s->mu);
     if (n > s->acquired) return fsint::fail_text("session: commit exceeds the acquired size");
@@ -137,6 +140,7 @@ int FLAGSTATS_hip_stream_commit(FLAGSTATS_hip_stream* s, uint64_t n)
 
 int FLAGSTATS_hip_stream_push(FLAGSTATS_hip_stream* s, const uint16_t* array, uint64_t n)
 {
+    FS_ENTRY();
     if (!s) return fsint::fail_text("NULL session");
     if (n && !array) return fsint::fail_text("NULL array with n > 0");
     const uint64_t maxn = (s->cap / 2) & ~7ull;
@@ -154,6 +158,7 @@ int FLAGSTATS_hip_stream_push(FLAGSTATS_hip_stream* s, const uint16_t* array, ui
 
 int FLAGSTATS_hip_stream_finish(FLAGSTATS_hip_stream* s, uint64_t* out)
 {
+    FS_ENTRY();
     if (!s || !out) return fsint::fail_text("NULL session or out");
     std::lock_guard<std::mutex> lk(s->mu);
     fsint::DeviceGuard guard(s->eng->device);
@@ -180,6 +185,7 @@ uint64_t FLAGSTATS_hip_stream_flags(const FLAGSTATS_hip_stream* s) { return s ? 
 
 void FLAGSTATS_hip_stream_close(FLAGSTATS_hip_stream* s)
 {
+    FS_ENTRY_RELEASE();
     if (!s) return;
     {
         std::lock_guard<std::mutex> lk(s->mu);

@@ -73,6 +73,18 @@ def test_overlapped_form_checked_and_calibrated(hip):
     assert d["config"]["allreduce"].split()[0] == "overlapped" and d["parity"].startswith("bit-exact")
 
 
+def test_strong_scaling_calibrates_by_default(hip):
+    """--strong: the shard shrinks with N but K2 + the all-reduce do not, so the in-line form cannot reach the 7.5x target
+    (DESIGN.md "Multi-GPU", budget table) -- a strong run times both forms and takes the faster one without being asked;
+    an explicit --no-overlap / --overlap still wins."""
+    d = run_bench("--force-dist", "--strong", "--cpu-seconds", "0")
+    assert d["scaling"] == "strong" and d["config"]["global_flags"] == 2 ** 27
+    assert "calibrated with stream events" in d["config"]["allreduce"]
+    assert d["parity"].startswith("bit-exact")
+    d = run_bench("--force-dist", "--strong", "--no-overlap", "--cpu-seconds", "0")
+    assert d["config"]["allreduce"] == "in-line" and d["parity"].startswith("bit-exact")
+
+
 def test_two_ranks_self_spawned_on_one_gpu(hip):
     """`bench.py --gpus 2` with no launcher: two fresh rank processes, rendezvous on 127.0.0.1, both on GPU 0 (test-only
     --same-device with the gloo backend and torch's all_reduce: a 1-GPU box cannot host two RCCL ranks).  Rank 0's line:

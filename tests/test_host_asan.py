@@ -34,10 +34,39 @@ def _clean(r, what):
     assert r.returncode == 0 and "all checks passed" in r.stdout, (what, r.returncode, r.stdout[-2000:], noise[-3000:])
 
 
-def test_host_code_under_address_and_undefined_behaviour_sanitizers():
+_built = False
+
+
+def _build():
+    """One ASan + UBSan build of the three drivers per test process."""
+    global _built
+    if _built:
+        return
     csrc = os.path.join(ROOT, "libflagstats_amd", "csrc")
     b = subprocess.run(["make", "-C", csrc, "hoststub", "SAN=address,undefined"], capture_output=True, text=True, timeout=1200)
     assert b.returncode == 0, b.stdout[-3000:] + b.stderr[-3000:]
+    _built = True
+
+
+def test_fork_is_refused_at_every_entry_and_leaves_the_parent_intact():
+    """VERDICT r05 item 2.  The reference's FLAGSTATS_u16 is a pure function and works in a forked child
+    (libflagstats.h:3024-3070); the replacement is an engine (HIP context, streams, helper threads, mutexes, a polling
+    protocol) that does not exist there.  tests/hoststub/fork_driver.cpp: a child forked BEFORE the first call owns the
+    library and counts correctly; the parent then counts, opens a session and a context, keeps a thread inside the engine
+    (its lock is held nearly all the time) and forks eight times -- each child calls every entry family and must get an
+    error naming the fork from each, within its alarm (a child that waits for an inherited mutex dies by SIGALRM), with its
+    counters untouched, the release-type entries as silent no-ops and the stateless helpers still working; with the default
+    "on_error" the reference-shaped entry aborts in the child; afterwards the parent's worker thread, session, context and
+    counters are all still right.  Under ASan + UBSan."""
+    _build()
+    r = subprocess.run([os.path.join(BUILD, "fork_driver")], capture_output=True, text=True, timeout=600, env=_env())
+    assert "AddressSanitizer" not in r.stderr and "runtime error" not in r.stderr, r.stderr[-6000:]
+    assert r.returncode == 0 and "all checks passed" in r.stdout, (r.returncode, r.stdout[-2000:], r.stderr[-3000:])
+    assert "fork()ed" in r.stderr and "spawn" in r.stderr   # the refusals are loud and name the remedy
+
+
+def test_host_code_under_address_and_undefined_behaviour_sanitizers():
+    _build()
     blockfiles = os.path.join(GOLDEN, "blockfiles")
     r = subprocess.run([os.path.join(BUILD, "asan_driver"), blockfiles], capture_output=True, text=True, timeout=900, env=_env())
     _clean(r, "threaded scenario")
