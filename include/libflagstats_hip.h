@@ -307,7 +307,7 @@ int FLAGSTATS_hip_file_raw(const char* path, uint64_t* out, FLAGSTATS_blockfile_
  * rule uses) copy 1 MiB slices into the engine's page-locked chunks, which cross PCIe behind them; out[32] += counters.  This is what
  * FLAGSTATS_u16 / FLAGSTATS_u16_x64 (the reference's libflagstats.h:3024-3070 entry) do by themselves for pageable arrays of at least
  * `staged_min_flags` flags (knob, default 2^27 = 256 MiB; 0 = never): hipMemcpyAsync out of pageable memory makes the runtime pin it
- * as it goes, 35-49 GB/s, box by box, out of the 4 KiB pages of a plain malloc against 53-57 GB/s this way
+ * as it goes, 30-49 GB/s, box by box, out of the 4 KiB pages of a plain malloc against 53-57 GB/s this way
  * (profiles/r05/pageable_c.log).  Exported for callers that know their arrays are in small pages and want it from 64 MiB. */
 int FLAGSTATS_hip_host_staged_u16(const uint16_t* array, uint64_t n, int threads, uint64_t* out, FLAGSTATS_blockfile_stats* stats);
 /* the file entries with SUPERSET counters (slots 0 / 16 = n_pair_all, slot 9 = pass-QC reads): what the samtools

@@ -317,9 +317,12 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
 
     // the engine's host pipeline (staging buffers, two streams, counters, pinned chunks) is one resource
     std::lock_guard<std::mutex> lk(eng.mu);
+    if (fsint::engine_alive(eng)) return -1;   // (a call racing FLAGSTATS_hip_shutdown: the engine's streams and buffers are gone)
     fsint::lz4_gpu_other_use(eng);  // (the GPU LZ4 decoder's kept buffers go after eight calls that did not use it)
     fsint::DeviceGuard guard(eng.device);
     if (!guard.ok()) return -1;
+    rc = fsint::engine_second(eng);   // both streams are used below
+    if (rc) return rc;
     uint64_t buf_cap = chunk_cap;   // what the chunk buffers must hold: the largest chunk (a large block has one of its own)
     for (const ChunkRef& c : chunks) buf_cap = c.bytes > buf_cap ? c.bytes : buf_cap;
     buf_cap = (buf_cap + 15) & ~15ull;
@@ -447,8 +450,13 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
         pipe.decode_cpu_s += busy;
     };
     const double t_a = now_s();
-    std::vector<std::thread> pool;
-    for (int t = 0; t < threads && !chunks.empty(); ++t) pool.emplace_back(worker);
+    // the engine's worker pool (threads made on first need, parked between calls): making and joining them per call was ~0.3 ms
+    fsint::WorkerPool& pool = fsint::engine_pool(eng);
+    const bool pooled = threads > 0 && !chunks.empty();
+    if (pooled && !pool.start(threads, [&worker](int) { worker(); })) {
+        for (int i = 0; i < npin; ++i) (void)hipEventDestroy(copied[i]);
+        return -1;
+    }
     const double t_b = now_s();
 
     auto release = [&](size_t upto) {
@@ -501,7 +509,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
         pipe.cv_workers.notify_all();
     }
     const double t_c = now_s();
-    for (auto& t : pool) t.join();
+    if (pooled) pool.wait();
     const double t_d = now_s();
     if (!err) {
         for (int s = 0; s < 2 && !err; ++s) {
@@ -516,7 +524,7 @@ int run_pipeline(fsint::Engine& eng, const Source& in, int threads, uint64_t* ou
     }
     for (int i = 0; i < npin; ++i) (void)hipEventDestroy(copied[i]);
     if (getenv("FLAGSTATS_HIP_TRACE"))
-        fprintf(stderr, "blocks: spawn %.4f loop %.4f join %.4f sync %.4f\n", t_b - t_a, t_c - t_b, t_d - t_c, now_s() - t_d);
+        fprintf(stderr, "blocks: workers started %.4f loop %.4f workers done %.4f sync %.4f\n", t_b - t_a, t_c - t_b, t_d - t_c, now_s() - t_d);
     if (err) return err;
     if (superset) {
         // slot 9 = pass-QC reads = flags - fail-QC reads is taken per launch over the whole chunk, and a chunk
@@ -618,10 +626,6 @@ bool decode_on_gpu(int codec, uint64_t bytes)
 int run_gpu_lz4(fsint::Engine& eng, int codec, const uint8_t* img, int fd, uint64_t bytes, int threads, bool superset, uint64_t* out,
                 FLAGSTATS_blockfile_stats* st)
 {
-    std::lock_guard<std::mutex> lk(eng.mu);
-    if (fsint::engine_alive(eng)) return -1;
-    fsint::DeviceGuard guard(eng.device);
-    if (!guard.ok()) return -1;
     fsint::Lz4GpuSource src;
     src.img = img;
     src.fd = fd;
@@ -630,8 +634,17 @@ int run_gpu_lz4(fsint::Engine& eng, int codec, const uint8_t* img, int fd, uint6
     src.threads = threads;
     src.codec = codec;
     src.by_size = (codec == 0 ? fsint::knobs().lz4_decoder.load() : fsint::knobs().zstd_decoder.load()) == 2;
+    // the index pass and the size rules come first, WITHOUT the engine's lock: a 16-64 MiB file that ends up on the host threads
+    // is handed back here and never makes concurrent small callers wait for its header reads
+    fsint::GpuFileIndexPtr index;
+    const int irc = fsint::lz4_gpu_index(src, index);
+    if (irc) return irc;
+    std::lock_guard<std::mutex> lk(eng.mu);
+    if (fsint::engine_alive(eng)) return -1;
+    fsint::DeviceGuard guard(eng.device);
+    if (!guard.ok()) return -1;
     FLAGSTATS_gpu_lz4_stats g;
-    const int rc = fsint::lz4_gpu_run(eng, src, out, &g);
+    const int rc = fsint::lz4_gpu_run(eng, src, *index, out, &g);
     const bool forced = (codec == 0 ? fsint::knobs().lz4_decoder.load() : fsint::knobs().zstd_decoder.load()) == 1;
     if (rc == fsint::kLz4GpuNoMemory && forced)
         return fsint::fail_text("GPU block decoder: the device cannot hold the file's compressed and decoded bytes");

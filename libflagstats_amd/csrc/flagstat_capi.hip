@@ -632,6 +632,8 @@ int FLAGSTATS_hip_sclk_under_load(const uint16_t* d_array, uint64_t n, int launc
     if (ticks < 1000) ticks = 1000;
     if (ticks > 100000000ull) ticks = 100000000ull;
     constexpr uint32_t kProbes = 8;
+    rc = fsint::engine_second(e);
+    if (rc) return rc;
     uint64_t* d_probe = e.d_out[1];  // 4 KiB
     HIP_TRY(hipMemsetAsync(d_probe, 0, kProbes * 16, e.stream[1]));
     for (int i = 0; i < launches; ++i) {

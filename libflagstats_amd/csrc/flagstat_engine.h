@@ -17,9 +17,14 @@
 #include <sched.h>
 
 #include <atomic>
+#include <condition_variable>
+#include <functional>
 #include <list>
+#include <memory>
 #include <mutex>
+#include <thread>
 #include <utility>
+#include <vector>
 
 struct FLAGSTATS_gpu_lz4_stats;
 
@@ -74,6 +79,34 @@ struct RegisteredHost {
     size_t map_bytes = 0;
     size_t len = 0;            // bytes registered (or to be registered) from ptr
     bool registered = false;   // false after host_alloc_registered(..., false) until host_register_late
+    bool refused = false;      // host_register_late was refused once: not asked again (the memory stays usable, pageable)
+};
+
+// Worker threads kept with an engine (the host-thread block pipeline's decoders, the GPU decoders' file readers): making and
+// joining 8-24 threads per call cost ~0.3 ms, a quarter of a 2-17-block file's whole call (tests/perf/small_file_phases.py).
+// Threads are made on first need and park on a condition variable between jobs.  One job at a time: the owner holds the
+// engine's lock from start() to wait().
+class WorkerPool {
+  public:
+    WorkerPool() = default;
+    ~WorkerPool();
+    WorkerPool(const WorkerPool&) = delete;
+    WorkerPool& operator=(const WorkerPool&) = delete;
+    // fn(t) runs once for every t in [0, n) on n pool threads.  Returns false (nothing started, error recorded) when the
+    // threads cannot be made.  fn must stay valid until wait() has returned.
+    bool start(int n, std::function<void(int)> fn);
+    void wait();   // until every fn(t) of the job has returned
+    int threads() const { return static_cast<int>(threads_.size()); }
+
+  private:
+    void loop(int id, uint64_t born);
+    std::mutex m_;
+    std::condition_variable cv_job_, cv_done_;
+    std::vector<std::thread> threads_;
+    std::function<void(int)> job_;
+    uint64_t generation_ = 0;   // bumped by start(): a parked thread with id < want_ runs the job of a generation once
+    int want_ = 0, running_ = 0;
+    bool stop_ = false;
 };
 
 struct Engine {
@@ -86,6 +119,13 @@ struct Engine {
     int cus = 0;
     int numa_node = -1;                            // host NUMA node closest to the device (-1 unknown)
     std::mutex mu;                                 // guards everything below up to `user_mu`
+    // stream[1], d_out[1] and the runtime's first-use warm-up are made by a helper thread that engine creation does NOT wait
+    // for: engine_second() (below) joins it before anything touches them.  A process that only makes small FLAGSTATS_u16
+    // calls never waits (a stream costs 8-20 ms to make and streams are made one after the other whatever thread asks).
+    std::mutex second_mu;                          // guards the join only
+    std::thread second_maker;
+    hipError_t second_err = hipSuccess;            // written by the helper, read after the join
+    std::unique_ptr<WorkerPool> pool;              // made on first need (run_pipeline, file-mode readers); e.mu held
     hipStream_t stream[2] = {nullptr, nullptr};
     Workspace ws[2];
     uint64_t* d_out[2] = {nullptr, nullptr};       // device uint64[32] per slot
@@ -192,6 +232,11 @@ int check_stream_device(hipStream_t s, int device);
 // per record here); off by default.
 int stream_wait_stream(Engine& e, hipStream_t waiter, hipStream_t on);
 
+// stream[1] / d_out[1] exist when this has returned 0 (joins the creation's helper thread; cheap afterwards).  Callers hold
+// e.mu, or own the engine outright (creation, retirement).
+int engine_second(Engine& e);
+WorkerPool& engine_pool(Engine& e);                // e.mu held
+
 uint32_t grid_for(const Engine& e);
 int ensure_ws(Workspace& w, uint32_t grid, hipStream_t s);  // zeroed (stream-ordered on s) at creation
 // K1 + K2 on `s`: d_out += (or =, OP_FLAGSTAT_STORE) counters of d_array[0..n).  Device must be current.
@@ -244,7 +289,17 @@ struct Lz4GpuSource {
     int codec = 0;          // payloads: 0 = LZ4 blocks, 1 = Zstandard frames
     bool by_size = false;   // the decoder was chosen by the size rule: a file of flags that hardly compress is handed back (kGpuDecodeRejected)
 };
-int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, struct ::FLAGSTATS_gpu_lz4_stats* stats);  // e.mu held, device current
+// The index pass over the block headers, apart from the run: plain host code that touches no engine state, so a caller makes
+// it BEFORE taking e.mu (file mode: one pread per header; a mid-size file that the size rules hand back to the host threads
+// never holds the lock that concurrent small FLAGSTATS_u16 callers wait for).
+// Returns 0 (index made), kGpuDecodeRejected (decoder chosen by size and the rules say host threads) or < 0 (malformed: error recorded).
+struct GpuFileIndex;
+struct GpuFileIndexDeleter {
+    void operator()(GpuFileIndex* p) const;
+};
+using GpuFileIndexPtr = std::unique_ptr<GpuFileIndex, GpuFileIndexDeleter>;
+int lz4_gpu_index(const Lz4GpuSource& in, GpuFileIndexPtr& index);
+int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, const GpuFileIndex& index, uint64_t* out, struct ::FLAGSTATS_gpu_lz4_stats* stats);  // e.mu held, device current
 // > 0 from lz4_gpu_run: the device could not hold the decoder's buffers (nothing was counted; the caller may take the host pipeline)
 constexpr int kLz4GpuNoMemory = 77;
 // > 0 from lz4_gpu_run: the GPU decoder did not take the file -- a Zstandard frame it does not handle or finds damaged, or

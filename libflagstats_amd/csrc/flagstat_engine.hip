@@ -142,8 +142,22 @@ int numa_node_of_device(int device)
     return node;
 }
 
+void join_second(Engine& e)
+{
+    std::lock_guard<std::mutex> lk(e.second_mu);
+    if (e.second_maker.joinable()) e.second_maker.join();
+}
+
+// A one-shot process may return from main while an engine's helper thread is still inside the runtime (making the second
+// stream): the runtime's own exit handlers must not run under it.  Registered after the runtime's first call, so it runs
+// before the runtime's handlers (atexit is last-in, first-out).
+void join_helpers_at_exit();
+std::once_flag g_atexit_once;
+
 void release_engine_resources(Engine& e)
 {
+    join_second(e);
+    e.pool.reset();
     (void)hipDeviceSynchronize();
     for (int i = 0; i < 2; ++i) {
         if (e.ws[i].partials) (void)hipFree(e.ws[i].partials);
@@ -206,49 +220,64 @@ int engine_setup(Engine& e, int device)
     e.cus = prop.multiProcessorCount;
     e.numa_node = numa_node_of_device(device);
     {
-        // A stream costs 7-10 ms to make (a hardware queue; profiles/r05/file_h2d.log: two in 14.5-21 ms) and a one-shot process
-        // pays for both before its first call: the second one is made on a helper thread beside the first and the small
-        // allocations.
-        // The same thread then uses its stream once for a fill and a small copy from pageable memory: the runtime loads its own
-        // fill / copy kernels at their first use (~12 ms, which the first call of a process otherwise pays in line:
-        // profiles/r05/cold_start.log).
-        hipError_t err1 = hipSuccess;
-        std::thread second([&] {
-            err1 = hipSetDevice(device);
+        // A stream costs 7-20 ms to make (a hardware queue; profiles/r05/file_h2d.log, cold_start_final_tree.log) and streams are made
+        // one after the other whatever thread asks.  The second stream, its counters and -- ONCE per process -- the runtime's
+        // first-use warm-up are made by a helper thread that this function does not wait for (engine_second joins it before
+        // anything touches stream[1] / d_out[1]): a process that only makes small FLAGSTATS_u16 calls, which poll their result out
+        // of pinned memory on stream[0] and use neither a fill nor a copy, gets its counters ~17 ms earlier.
+        // The warm-up: a fill and a small copy from pageable memory (the runtime loads its own fill / copy kernels at their first
+        // use, ~12 ms) and copies both ways out of / into page-locked memory (the DMA engines' queues: the first such copy of a
+        // process takes 13-16 ms; 256 KiB: small ones go through a copy kernel, not through the DMA engines).  Side engines,
+        // explicit contexts and the engines of further devices gain nothing from a second warm-up and skip it.
+        static std::atomic<bool> g_warmed{false};
+        const bool warm = !g_warmed.exchange(true);
+        Engine* ep = &e;
+        auto make_second = [ep, device, warm] {
+            Engine& e = *ep;
+            hipError_t err1 = hipSetDevice(device);
             if (err1 == hipSuccess) err1 = hipStreamCreateWithFlags(&e.stream[1], hipStreamNonBlocking);
             if (err1 == hipSuccess) err1 = hipMalloc(&e.d_out[1], 4096);
-            // (first uses: a fill, a copy out of pageable memory -- the runtime's own kernels and staging -- and copies both ways
-            // out of / into page-locked memory -- the DMA engines' queues: the first such copy of a process takes 13-16 ms)
-            // (the page-locked copies are 256 KiB: small ones go through a copy kernel, not through the DMA engines)
-            constexpr size_t kWarm = 256u << 10;
-            void *pinned_warm = nullptr, *device_warm = nullptr;
-            if (err1 == hipSuccess) err1 = hipHostMalloc(&pinned_warm, kWarm, hipHostMallocDefault);
-            if (err1 == hipSuccess) err1 = hipMalloc(&device_warm, kWarm);
-            if (err1 == hipSuccess) err1 = hipMemcpyAsync(device_warm, pinned_warm, kWarm, hipMemcpyHostToDevice, e.stream[1]);
-            if (err1 == hipSuccess) err1 = hipMemcpyAsync(pinned_warm, device_warm, kWarm, hipMemcpyDeviceToHost, e.stream[1]);
-            if (err1 == hipSuccess) err1 = hipStreamSynchronize(e.stream[1]);
-            if (pinned_warm) (void)hipHostFree(pinned_warm);
-            if (device_warm) (void)hipFree(device_warm);
-        });
+            if (err1 == hipSuccess && warm) {
+                constexpr size_t kWarm = 256u << 10;
+                void *pinned_warm = nullptr, *device_warm = nullptr;
+                uint64_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                err1 = hipMemsetAsync(e.d_out[1], 0, 4096, e.stream[1]);
+                if (err1 == hipSuccess) err1 = hipMemcpyAsync(e.d_out[1], zeros, sizeof zeros, hipMemcpyHostToDevice, e.stream[1]);
+                if (err1 == hipSuccess) err1 = hipStreamSynchronize(e.stream[1]);   // (zeros[] is this thread's stack)
+                if (err1 == hipSuccess) err1 = hipHostMalloc(&pinned_warm, kWarm, hipHostMallocDefault);
+                if (err1 == hipSuccess) err1 = hipMalloc(&device_warm, kWarm);
+                if (err1 == hipSuccess) err1 = hipMemcpyAsync(device_warm, pinned_warm, kWarm, hipMemcpyHostToDevice, e.stream[1]);
+                if (err1 == hipSuccess) err1 = hipMemcpyAsync(pinned_warm, device_warm, kWarm, hipMemcpyDeviceToHost, e.stream[1]);
+                if (err1 == hipSuccess) err1 = hipStreamSynchronize(e.stream[1]);
+                if (pinned_warm) (void)hipHostFree(pinned_warm);
+                if (device_warm) (void)hipFree(device_warm);
+            }
+            e.second_err = err1;
+        };
         const clk::time_point t_s0 = clk::now();
         hipError_t err0 = hipStreamCreateWithFlags(&e.stream[0], hipStreamNonBlocking);
         const clk::time_point t_s1 = clk::now();
+        // (after the first stream: the helper's stream would otherwise be made first and this thread would wait for it)
+        std::call_once(g_atexit_once, [] { (void)std::atexit(join_helpers_at_exit); });
+        const char* lz = std::getenv("FLAGSTATS_HIP_EAGER_SECOND");   // (A/B: 1 = wait for the helper here, as r05 did)
+        bool inline_second = false;
+        try {
+            e.second_maker = std::thread(make_second);
+        } catch (const std::system_error&) {
+            inline_second = true;   // (a pids / RLIMIT_NPROC limit: the work is done here instead)
+        }
         if (err0 == hipSuccess) err0 = hipMalloc(&e.d_out[0], 4096);  // uint64[32] (+ room for the tuning build's 8-copy epilogue experiment)
         for (int i = 0; i < 2 && err0 == hipSuccess; ++i) err0 = hipEventCreateWithFlags(&e.chunk_done[i], hipEventDisableTiming);
-        {   // (this thread's share of the first uses: the runtime's fill kernel and its staged copy out of pageable memory)
-            uint64_t zeros[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (err0 == hipSuccess) err0 = hipMemsetAsync(e.d_out[0], 0, 4096, e.stream[0]);
-            if (err0 == hipSuccess) err0 = hipMemcpyAsync(e.d_out[0], zeros, sizeof zeros, hipMemcpyHostToDevice, e.stream[0]);
-            if (err0 == hipSuccess) err0 = hipStreamSynchronize(e.stream[0]);
-        }
+        // (d_out[0] needs no zeroing here: every path that accumulates into it zeroes it first, stream-ordered)
         const clk::time_point t_s2 = clk::now();
-        second.join();
+        if (inline_second) make_second();
+        if (lz && std::atoi(lz) != 0) join_second(e);
         if (timed)
-            std::fprintf(stderr, "engine creation, streams (ms): first stream %.2f | counters + events %.2f | waiting for the helper thread (second stream, its counters, first fill + copy) %.2f\n",
+            std::fprintf(stderr, "engine creation, streams (ms): first stream %.2f | counters + events %.2f | second stream%s: %s %.2f\n",
                          std::chrono::duration<double, std::milli>(t_s1 - t_s0).count(), std::chrono::duration<double, std::milli>(t_s2 - t_s1).count(),
+                         warm ? " + the runtime's first fill and copies" : "", (lz && std::atoi(lz) != 0) || inline_second ? "waited for" : "left to its helper thread, not waited for",
                          std::chrono::duration<double, std::milli>(clk::now() - t_s2).count());
         if (err0 != hipSuccess) return fail_hip("engine creation: stream / counters / events", err0);
-        if (err1 != hipSuccess) return fail_hip("engine creation: second stream", err1);
     }
     lap(3);
     HIP_TRY(hipHostMalloc(&e.h_out, kHostOutBytes, hipHostMallocDefault));
@@ -278,6 +307,100 @@ int engine_setup(Engine& e, int device)
 }
 
 }  // namespace
+
+namespace {
+void join_helpers_at_exit()
+{
+    if (g_forked.load(std::memory_order_relaxed)) return;
+    std::vector<Engine*> all;
+    {
+        std::lock_guard<std::mutex> lk(g_reg_mu);
+        for (Engine* e : g_default)
+            if (e) all.push_back(e);
+        for (Engine* e : g_private) all.push_back(e);
+    }
+    for (Engine* e : all) join_second(*e);
+}
+}  // namespace
+
+int engine_second(Engine& e)
+{
+    join_second(e);
+    if (e.second_err != hipSuccess) return fail_hip("engine creation: second stream (made by the helper thread)", e.second_err);
+    if (!e.stream[1] || !e.d_out[1]) return fail_text("engine creation: the second stream was never made");
+    return 0;
+}
+
+WorkerPool& engine_pool(Engine& e)
+{
+    if (!e.pool) e.pool.reset(new WorkerPool());
+    return *e.pool;
+}
+
+WorkerPool::~WorkerPool()
+{
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        stop_ = true;
+    }
+    cv_job_.notify_all();
+    for (std::thread& t : threads_) t.join();
+}
+
+void WorkerPool::loop(int id, uint64_t born)
+{
+    // `born` = the generation current when start() made this thread: the job of the NEXT generation is its first, however late
+    // the thread gets here (reading generation_ now instead would skip that job if start() has bumped it already)
+    uint64_t seen = born;
+    std::unique_lock<std::mutex> ul(m_);
+    for (;;) {
+        cv_job_.wait(ul, [&] { return stop_ || (generation_ != seen && id < want_); });
+        if (stop_) return;
+        seen = generation_;
+        ul.unlock();
+        job_(id);
+        ul.lock();
+        if (--running_ == 0) cv_done_.notify_all();
+    }
+}
+
+bool WorkerPool::start(int n, std::function<void(int)> fn)
+{
+    if (n < 1) return true;
+    uint64_t born = 0;
+    {
+        std::unique_lock<std::mutex> ul(m_);
+        cv_done_.wait(ul, [&] { return running_ == 0; });   // (one job at a time; the owner normally called wait() already)
+        born = generation_;
+    }
+    try {
+        while (static_cast<int>(threads_.size()) < n) {
+            const int id = static_cast<int>(threads_.size());
+            threads_.emplace_back([this, id, born] { loop(id, born); });
+        }
+    } catch (const std::system_error& ex) {
+        char buf[256];
+        std::snprintf(buf, sizeof buf, "cannot start worker threads (%d of %d made): %s", static_cast<int>(threads_.size()), n, ex.what());
+        fail_text(buf);
+        return false;
+    }
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        job_ = std::move(fn);
+        want_ = n;
+        running_ = n;
+        ++generation_;
+    }
+    cv_job_.notify_all();
+    return true;
+}
+
+void WorkerPool::wait()
+{
+    std::unique_lock<std::mutex> ul(m_);
+    cv_done_.wait(ul, [&] { return running_ == 0; });
+    want_ = 0;
+}
 
 Knobs& knobs()
 {
@@ -848,13 +971,14 @@ RegisteredHost host_alloc_registered(size_t bytes, int numa_node, bool touch_and
 
 bool host_register_late(RegisteredHost& r)
 {
-    if (r.registered || !r.map) return r.registered;
+    if (r.registered || !r.map || r.refused) return r.registered;
     using clk = std::chrono::steady_clock;
     const clk::time_point t2 = clk::now();
     const hipError_t reg = hipHostRegister(r.ptr, r.len, hipHostRegisterDefault);
     g_reg_times[2] = std::chrono::duration<double, std::milli>(clk::now() - t2).count();
     if (reg != hipSuccess) {
         (void)hipGetLastError();
+        r.refused = true;   // not asked again: every attempt walks and tries to pin the whole mapping on the calling thread
         return false;
     }
     r.registered = true;
@@ -989,6 +1113,7 @@ static int count_host_locked(Engine& e, const uint16_t* h, uint64_t n, uint64_t*
     int rc = 0;
     const bool small_in_place = slots == 1 && (op & OP_BASE_MASK) == OP_FLAGSTAT && n <= g_knobs.small_flags.load() &&
                                 n * sizeof(uint16_t) <= kSmallInBytes;
+    if (slots == 2) rc = engine_second(e);
     for (int i = 0; i < slots && !rc && !small_in_place; ++i) rc = stage_reserve(e, i, n < chunk ? n : chunk);
     if (rc) return rc;
     if (slots == 1 && (op & OP_BASE_MASK) == OP_FLAGSTAT) {

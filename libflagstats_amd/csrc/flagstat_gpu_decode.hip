@@ -152,6 +152,7 @@ static int lz4_gpu_streams(Engine& e, int codec)   // (runs on a helper thread: 
     // The first decode stream is the engine's own second stream (idle while the decoder has the engine: every call ends with a
     // stream wait), so ONE stream is made here: a stream costs 8-10 ms, and the first call of a process waited 12 ms for two.
     hipError_t err = hipSuccess;
+    if (engine_second(e)) return -1;   // (joins the engine creation's helper thread: a first call of a process may get here before it is done)
     e.lz4_stream[0] = e.stream[1];
     for (int i = 1; i < Engine::kLz4Streams; ++i)
         if (err == hipSuccess && !e.lz4_stream[i]) err = hipStreamCreateWithFlags(&e.lz4_stream[i], hipStreamNonBlocking);
@@ -192,11 +193,17 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             if (t.joinable()) t.join();
         }
     } joiner{maker};
-    if (!e.lz4_ready)
-        maker = std::thread([&] {
+    if (!e.lz4_ready) {
+        auto make = [&] {
             maker_rc = lz4_gpu_streams(e, in.codec);
             if (maker_rc) maker_err = last_error_text();
-        });
+        };
+        try {
+            maker = std::thread(make);
+        } catch (const std::system_error&) {
+            make();   // (a pids / RLIMIT_NPROC limit: made here, in line)
+        }
+    }
     // The decoded buffer is not needed before the first decode launch, and on some hosts a hipMalloc of a gigabyte and more takes
     // 30 ms where it takes 0.03 on others (profiles/r05/cold_start_exit.log: 1.6 GB, every fresh process of that box): when it
     // has to be made it is made on a thread of its own, beside the index upload, the first reads and the first copies.
@@ -290,8 +297,8 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
         e.lz4_cap[i] = cap;
         return 0;
     };
-    if (e.lz4_cap[1] < want[1])
-        out_maker = std::thread([&] {
+    if (e.lz4_cap[1] < want[1]) {
+        auto make_out = [&] {
             DeviceGuard g2(e.device);
             if (!g2.ok()) {
                 out_err = last_error_text();
@@ -301,7 +308,13 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             const PhaseClock::clk::time_point t0 = PhaseClock::clk::now();
             out_rc = grow(1, want[1], out_err);
             pc_.alloc_out_own += std::chrono::duration<double, std::milli>(PhaseClock::clk::now() - t0).count();   // (read after the join)
-        });
+        };
+        try {
+            out_maker = std::thread(make_out);
+        } catch (const std::system_error&) {
+            make_out();
+        }
+    }
     if (e.lz4_cap[0] < want[0]) {
         std::string text;
         rc = grow(0, want[0], text);
@@ -646,17 +659,24 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
                 if (++done[i] == readers) cv_done.notify_one();
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 0; t < readers && !spans.empty(); ++t) pool.emplace_back(reader, t);
+        // (the engine's worker pool: the sixteen readers are parked threads, not made and joined per call)
+        WorkerPool& pool = engine_pool(e);
+        const bool pooled = readers > 0 && !spans.empty();
+        if (pooled && !pool.start(readers, reader)) {
+            settle();
+            return -1;
+        }
         auto queue_span = [&](size_t i) -> int {
             {
                 std::unique_lock<std::mutex> ul(m);
                 cv_done.wait(ul, [&] { return done[i] == readers; });
                 if (failed) return fail_text("block file: short read");
             }
-            if (!e.lz4_pin_reg.registered) {
-                // (first use of the ring: the spans released so far have been touched by the readers; a refusal leaves ordinary memory,
-                // out of which the copies still work, through the runtime's staging)
+            if (!e.lz4_pin_reg.registered && !e.lz4_pin_reg.refused) {
+                // (first use of the ring: the spans released so far have been touched by the readers -- on the GPU's node; the
+                // registration covers the WHOLE ring, so pages of spans no reader has reached yet are faulted in here, on this
+                // thread's node.  A refusal leaves ordinary memory, out of which the copies still work, through the runtime's
+                // staging, and is not asked for again: RegisteredHost::refused)
                 DeviceGuard g2(e.device);
                 const bool locked = g2.ok() && host_register_late(e.lz4_pin_reg);
                 if (pc_.on) std::fprintf(stderr, "gpu decode, pinned ring of %llu MiB: mapped, touched by the readers' first reads, hipHostRegister %.2f ms%s\n",
@@ -694,7 +714,7 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
             stop = true;
         }
         cv_work.notify_all();
-        for (std::thread& t : pool) t.join();
+        if (pooled) pool.wait();
     }
     if (rc) {
         settle();
@@ -855,17 +875,25 @@ static int lz4_gpu_segment(Engine& e, const Lz4GpuSource& in, uint64_t file_lo, 
 #undef LZG_TRY
 }
 
-int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
+struct GpuFileIndex {
+    std::vector<fsk::GpuBlock> blocks;
+    uint64_t dpos = 0, n_flags = 0, usum = 0;
+    uint32_t max_src = 0, max_dst = 0;
+    double index_ms = 0;
+};
+
+void GpuFileIndexDeleter::operator()(GpuFileIndex* p) const { delete p; }
+
+int lz4_gpu_index(const Lz4GpuSource& in, GpuFileIndexPtr& index)
 {
-    const auto t_start = std::chrono::steady_clock::now();
-    PhaseClock pc;
-    pc.start();
+    const auto t0 = std::chrono::steady_clock::now();
+    index.reset(new GpuFileIndex());
+    GpuFileIndex& ix = *index;
     const uint8_t* img = in.img;
     const uint64_t bytes = in.bytes;
     // index: int32 uncompressed size, int32 compressed size, payload (benchmark/flagstats.cpp:119-138)
-    std::vector<fsk::GpuBlock> blocks;
-    uint64_t pos = 0, dpos = 0, n_flags = 0, usum = 0;
-    uint32_t max_src = 0, max_dst = 0;
+    std::vector<fsk::GpuBlock>& blocks = ix.blocks;
+    uint64_t pos = 0;
     while (pos < bytes) {
         if (bytes - pos < 8) return fail_text("block file: truncated block header");
         int32_t us, cs;
@@ -881,15 +909,41 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         if (static_cast<uint64_t>(cs) > bytes - pos - 8) return fail_text("block file: block payload runs past end of file");
         if (!block_sizes_plausible(in.codec, static_cast<uint64_t>(us), static_cast<uint64_t>(cs)))
             return fail_text("block file: a block header declares more decoded bytes than a payload of its size can hold");
-        blocks.push_back(fsk::GpuBlock{pos + 8, dpos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us)});
-        n_flags += static_cast<uint64_t>(us) >> 1;  // as benchmark/flagstats.cpp:323
-        usum += static_cast<uint64_t>(us);
-        dpos += (static_cast<uint64_t>(us) + 15) & ~15ull;
+        blocks.push_back(fsk::GpuBlock{pos + 8, ix.dpos, static_cast<uint32_t>(cs), static_cast<uint32_t>(us)});
+        ix.n_flags += static_cast<uint64_t>(us) >> 1;  // as benchmark/flagstats.cpp:323
+        ix.usum += static_cast<uint64_t>(us);
+        ix.dpos += (static_cast<uint64_t>(us) + 15) & ~15ull;
         pos += 8 + static_cast<uint64_t>(cs);
-        max_src = static_cast<uint32_t>(cs) > max_src ? static_cast<uint32_t>(cs) : max_src;
-        max_dst = static_cast<uint32_t>(us) > max_dst ? static_cast<uint32_t>(us) : max_dst;
+        ix.max_src = static_cast<uint32_t>(cs) > ix.max_src ? static_cast<uint32_t>(cs) : ix.max_src;
+        ix.max_dst = static_cast<uint32_t>(us) > ix.max_dst ? static_cast<uint32_t>(us) : ix.max_dst;
     }
-    pc.lap(pc.index);
+    ix.index_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    // Flags that hardly compress: the host-thread pipeline then moves about as many bytes over PCIe as the GPU decoder and has
+    // next to nothing to decode (raw blocks, literal runs), while the GPU decoders' literal paths are their slow ones
+    // (profiles/r04/incompressible_blockfiles.log: 11 ms against 14 (LZ4) / 22-29 (Zstandard) for 512 MiB).  With the
+    // decoder chosen by size such a file goes to the host threads: decoded bytes below 1.25 x (LZ4) / 1.9 x (Zstandard) the file's
+    // (where the two decoders cross on blocks with a growing share of noise: profiles/r04/ratio_sweep.log).
+    if (!blocks.empty()) {
+        const uint64_t pct = in.codec == 1 ? 190 : 125;
+        if (in.by_size && ix.usum * 100 < bytes * pct) return kGpuDecodeRejected;
+        // ... and the size rule proper (flagstat_blocks.hip, decode_on_gpu): a file below the knob's compressed size is taken if
+        // it decodes to at least 2.5 x the knob (default: 64 MiB of file or 160 MiB of flags)
+        const uint64_t from = in.codec == 0 ? knobs().lz4_gpu_min_bytes.load() : knobs().zstd_gpu_min_bytes.load();
+        if (in.by_size && bytes < from && ix.usum * 2 < from * 5) return kGpuDecodeRejected;
+    }
+    return 0;
+}
+
+int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, const GpuFileIndex& ix, uint64_t* out, FLAGSTATS_gpu_lz4_stats* stats)
+{
+    const auto t_start = std::chrono::steady_clock::now();
+    PhaseClock pc;
+    pc.start();
+    pc.index = ix.index_ms;   // (made before the engine's lock was taken: lz4_gpu_index)
+    const uint64_t bytes = in.bytes;
+    const std::vector<fsk::GpuBlock>& blocks = ix.blocks;
+    const uint64_t dpos = ix.dpos, n_flags = ix.n_flags, usum = ix.usum;
+    const uint32_t max_src = ix.max_src, max_dst = ix.max_dst;
     FLAGSTATS_gpu_lz4_stats local;
     if (!stats) stats = &local;
     {
@@ -901,19 +955,6 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         stats->uncompressed_bytes = usum;
     }
     if (blocks.empty()) return 0;
-    // Flags that hardly compress: the host-thread pipeline then moves about as many bytes over PCIe as the GPU decoder and has
-    // next to nothing to decode (raw blocks, literal runs), while the GPU decoders' literal paths are their slow ones
-    // (profiles/r04/incompressible_blockfiles.log: 11 ms against 14 (LZ4) / 22-29 (Zstandard) for 512 MiB).  With the
-    // decoder chosen by size such a file goes to the host threads: decoded bytes below 1.25 x (LZ4) / 1.9 x (Zstandard) the file's
-    // (where the two decoders cross on blocks with a growing share of noise: profiles/r04/ratio_sweep.log).
-    {
-        const uint64_t pct = in.codec == 1 ? 190 : 125;
-        if (in.by_size && usum * 100 < bytes * pct) return kGpuDecodeRejected;
-        // ... and the size rule proper (flagstat_blocks.hip, decode_on_gpu): a file below the knob's compressed size is taken if
-        // it decodes to at least 2.5 x the knob (default: 64 MiB of file or 160 MiB of flags)
-        const uint64_t from = in.codec == 0 ? knobs().lz4_gpu_min_bytes.load() : knobs().zstd_gpu_min_bytes.load();
-        if (in.by_size && bytes < from && usum * 2 < from * 5) return kGpuDecodeRejected;
-    }
     // What the kernels cannot address is known from the index -- a capability limit, not damage.  LZ4: the workgroup kernel's
     // records carry 24-bit input and 28-bit output positions (status 10 if it met such a block); a file with a block of 16 MiB of
     // payload or 256 MiB decoded goes to the wave-per-block kernel, which has no such limit.
@@ -991,7 +1032,7 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, uint64_t* out, FLAGSTATS_gpu_
         for (uint64_t c : e.zstd_scratch_cap) held += c;
         if (held > keep) lz4_gpu_release(e, false);
     }
-    stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count();
+    stats->wall_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t_start).count() + ix.index_ms * 1e-3;
     if (pc.on) {
         double keep_rule = 0;
         pc.lap(keep_rule);
@@ -1014,15 +1055,18 @@ extern "C" int FLAGSTATS_hip_blockimage_lz4_gpu(const void* image, uint64_t byte
     fsint::Engine* ep = fsint::default_engine();
     if (!ep) return -1;
     fsint::Engine& e = *ep;
-    std::lock_guard<std::mutex> lk(e.mu);
-    if (fsint::engine_alive(e)) return -1;
-    fsint::DeviceGuard guard(e.device);
-    if (!guard.ok()) return -1;
     static const uint8_t empty = 0;
     fsint::Lz4GpuSource src;
     src.img = image ? static_cast<const uint8_t*>(image) : &empty;
     src.bytes = bytes;
-    const int rc = fsint::lz4_gpu_run(e, src, out, stats);
+    fsint::GpuFileIndexPtr index;
+    int rc = fsint::lz4_gpu_index(src, index);
+    if (rc) return rc;   // (< 0: malformed; by_size is off here, so no size rule applies)
+    std::lock_guard<std::mutex> lk(e.mu);
+    if (fsint::engine_alive(e)) return -1;
+    fsint::DeviceGuard guard(e.device);
+    if (!guard.ok()) return -1;
+    rc = fsint::lz4_gpu_run(e, src, *index, out, stats);
     // (this entry has no host pipeline behind it: the "not taken" codes are errors here)
     if (rc == fsint::kLz4GpuNoMemory) return fsint::fail_text("GPU block decoder: the device cannot hold the file's compressed and decoded bytes");
     if (rc == fsint::kGpuDecodeRejected) return fsint::fail_text("GPU block decoder: the file is not one the decoder takes");

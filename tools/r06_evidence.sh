@@ -1,12 +1,25 @@
 #!/bin/bash
 # Round 6's measured evidence (everything lands in gpurun_out/r06/, summaries are copied to profiles/r06):
-#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: dist distprof
+#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests cold small dist distprof
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06
 mkdir -p $O
 PARTS="${*:-dist distprof}"
 has() { case " $PARTS " in *" $1 "*) return 0;; *) return 1;; esac; }
+if has tests; then
+    # the driver's round-end command
+    timeout 1100 python3 -m pytest tests -x -q -m gpu > $O/gpu_tests.log 2>&1 || { tail -30 $O/gpu_tests.log; exit 1; }
+    tail -3 $O/gpu_tests.log
+fi
+if has cold; then
+    # the one-shot table with the engine's second stream left to its helper thread (default) and waited for (r05)
+    timeout 900 python3 tests/perf/cold_start.py --samples 5 --gap-s 2 2>&1 | grep -v amdgpu.ids > $O/cold_start.log || exit 1
+    FLAGSTATS_HIP_EAGER_SECOND=1 timeout 900 python3 tests/perf/cold_start.py --samples 5 --gap-s 2 --which u16,hc9 2>&1 | grep -v amdgpu.ids > $O/cold_start_eager_second_stream.log || exit 1
+fi
+if has small; then
+    timeout 600 python3 tests/perf/small_file_phases.py 2>&1 | grep -v amdgpu.ids > $O/small_file_phases.log || exit 1
+fi
 if has dist; then
     # the N > 1 step on HEAD at world size 1, every form, 8 GiB and 1 GiB shards
     timeout 1100 python3 tools/dist_step.py --sizes "2**32,2**29" --steps 200 --warmup 20 --repeat 2 2>&1 | grep -v amdgpu.ids > $O/dist_step_world1.log
@@ -31,5 +44,4 @@ if has distprof; then
     done
     unset RANK LOCAL_RANK WORLD_SIZE MASTER_ADDR
 fi
-tail -40 $O/dist_step_world1.log | cut -c1-300
-head -12 $O/dist_step_kernel_stats_*.csv | cut -c1-300
+for f in $O/cold_start.log $O/small_file_phases.log $O/dist_step_world1.log; do if [ -f $f ]; then tail -30 $f | cut -c1-330; fi; done
