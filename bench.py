@@ -28,7 +28,6 @@ sample).
 """
 import argparse
 import ctypes
-import hashlib
 import json
 import os
 import sys
@@ -43,13 +42,12 @@ METRIC = "Gflags/s + achieved HBM GB/s vs roofline, 8 GiB uint16, 1/2/4/8 MI355X
 
 
 def kernel_source_id():
-    """Identity of the K1/K2 source the shipped .so was built from (profiles/traffic.json carries the
-    same id: a PMC figure measured on another build of the kernel is not reported)."""
-    h = hashlib.sha256()
-    for f in ("flagstat_kernels.hip", "flagstat_device.h", "flagstat_kernels.h"):
-        with open(os.path.join(ROOT, "libflagstats_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """Identity of the K1 / K2 DEVICE code inside the shipped .so (sha256 over .text + .rodata of its gfx950 code object:
+    libflagstats_amd/kernel_id.py).  profiles/traffic.json carries the id of the build its PMC figures were measured on: a
+    figure measured on another build of the kernel is not reported.  (Until r05 this hashed three source files, and a
+    host-side edit invalidated measurements of byte-identical device code.)"""
+    from libflagstats_amd.kernel_id import kernel_id
+    return kernel_id()
 
 
 def usable_cpus():
@@ -83,7 +81,7 @@ def usable_cpus():
     return n, note
 
 
-def cpu_baseline(seconds: float, sample_flags: int, seed: int):
+def cpu_baseline(seconds: float, sample_flags: int, seed: int, dram_flags_per_core: int = 2 ** 27):
     """Time the reference's own kernel (what FLAGSTATS_get_function returns on this host,
     libflagstats.h:2976-3022) on a prefix of the rank-0 workload: 1 thread, then every core with
     pinned threads and shard-local memory (ref_dispatch_mt_bench, oracle/ref_wrap.cpp)."""
@@ -163,12 +161,59 @@ def cpu_baseline(seconds: float, sample_flags: int, seed: int):
                 "sample": "%d flags (%.0f MiB) in %d pinned, shard-local shards x %d passes, median of 3 runs; %s"
                           % (per * cores, per * cores * 2 / 2 ** 20, cores, reps, cores_note)}
 
+    # all cores over DRAM: the same pinned threads, each ONE pass over its contiguous shard (>= 256 MiB: far beyond the caches)
+    # of the first cores x 2^27 flags of the rank-0 workload -- BASELINE.md section 4 step 3's form, and the honest neighbour of
+    # an HBM-bound GPU figure (the cache-resident figure above flatters the CPU).  The shards are generated by threads pinned
+    # like their readers, so a shard's pages lie where it is read.
+    dram = None
+    if ref is not None and hasattr(ref, "ref_dispatch_mt_shards") and dram_flags_per_core > 0:
+        import threading
+        per = int(dram_flags_per_core)
+        total = per * cores
+        try:
+            big = np.empty(total, dtype=np.uint16)
+        except MemoryError:
+            big = None
+        if big is not None:
+            allowed = sorted(os.sched_getaffinity(0))
+
+            def fill(k):
+                try:
+                    os.sched_setaffinity(0, {allowed[k % len(allowed)]})   # (pid 0 = the calling thread)
+                except OSError:
+                    pass
+                lib.oracle_generate_u16(oracle.GEN_UNIFORM, seed, 0xFFFF, k * per, per,
+                                        ctypes.cast(big.ctypes.data + 2 * k * per, ctypes.POINTER(ctypes.c_uint16)))
+
+            tg = time.perf_counter()
+            ths = [threading.Thread(target=fill, args=(k,)) for k in range(cores)]
+            for t in ths:
+                t.start()
+            for t in ths:
+                t.join()
+            gen_s = time.perf_counter() - tg
+            rounds = 3
+            secs = (ctypes.c_double * rounds)()
+            out = np.zeros(32, dtype=np.uint64)
+            ref.ref_dispatch_mt_shards.restype = ctypes.c_int
+            ref.ref_dispatch_mt_shards.argtypes = [ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                                   ctypes.POINTER(ctypes.c_double), u64p]
+            if ref.ref_dispatch_mt_shards(big.ctypes.data, total, cores, rounds, secs, out.ctypes.data_as(u64p)) == 0:
+                rates = sorted(total / s_ / 1e9 for s_ in secs)
+                dram = {"value": round(rates[1], 4), "unit": "Gflags/s", "cores": cores, "min": round(rates[0], 4), "max": round(rates[2], 4),
+                        "GBs": round(rates[1] * 2, 1),
+                        "sample": "first %d flags (%.2f GiB) of the rank-0 workload as %d contiguous shards of %.0f MiB, one pinned thread and "
+                                  "ONE pass each per round, median of %d rounds (generated in %.1f s by threads pinned like the readers); %s"
+                                  % (total, total * 2 / 2 ** 30, cores, per * 2 / 2 ** 20, rounds, gen_s, cores_note)}
+            del big
+
     return {
         "value": round(one, 4), "unit": "Gflags/s", "cores": 1, "kind": kind, "kernel": name,
         "sample": "first %d flags (%.0f MiB) of the rank-0 workload, %d passes in %.1f s, 1 thread"
                   % (sample_flags, sample_flags * 2 / 2 ** 20, passes, dt),
         "scalar_exact_variant": exact,
         "all_cores": allc,
+        "all_cores_dram": dram,
     }
 
 
@@ -288,6 +333,8 @@ def main():
     ap.add_argument("--flags-per-gpu", type=int, default=2 ** 32, help="default 2^32 flags = 8 GiB uint16")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="0 disables the CPU baseline leg")
     ap.add_argument("--cpu-sample", type=int, default=2 ** 27)
+    ap.add_argument("--cpu-dram-per-core", type=int, default=2 ** 27,
+                    help="flags per core of the all-cores-over-DRAM leg (default 2^27 = 256 MiB per pinned thread; 0: skip)")
     ap.add_argument("--seed", type=int, default=2026)
     ap.add_argument("--probe-reps", type=int, default=40,
                     help="read-only bandwidth probe launches before the warm-up steps (0: no probe; the first timed "
@@ -688,7 +735,7 @@ def main():
                 print("PARITY MISMATCH", got, want, file=sys.stderr)
         cpu = None
         if args.cpu_seconds > 0 and world == 1:
-            cpu = cpu_baseline(args.cpu_seconds, min(args.cpu_sample, n), args.seed)
+            cpu = cpu_baseline(args.cpu_seconds, min(args.cpu_sample, n), args.seed, args.cpu_dram_per_core)
         traffic = None
         traffic_note = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")

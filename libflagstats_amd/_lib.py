@@ -1,4 +1,5 @@
-"""ctypes binding of the C-ABI library ``libflagstats_hip.so`` (include/libflagstats_hip.h).
+"""ctypes binding of the C-ABI library ``libflagstats_hip.so`` (include/libflagstats_hip.h; measurement entries:
+include/libflagstats_hip_probe.h).
 
 The library is built in-tree by ``__graft_entry__.build()`` (or
 ``make -C libflagstats_amd/csrc``).  If it is missing this module raises -- there
@@ -29,7 +30,7 @@ class BlockfileStats(ctypes.Structure):
 
 
 class GpuLz4Stats(ctypes.Structure):
-    """FLAGSTATS_gpu_lz4_stats of include/libflagstats_hip.h."""
+    """FLAGSTATS_gpu_lz4_stats of include/libflagstats_hip_probe.h."""
     _fields_ = [("n_blocks", ctypes.c_uint64), ("n_flags", ctypes.c_uint64), ("bad_blocks", ctypes.c_uint64),
                 ("compressed_bytes", ctypes.c_uint64), ("decoded_bytes", ctypes.c_uint64),
                 ("h2d_ms", ctypes.c_double), ("decode_ms", ctypes.c_double), ("count_ms", ctypes.c_double),
@@ -39,7 +40,7 @@ class GpuLz4Stats(ctypes.Structure):
                 ("segments", ctypes.c_uint64)]
 
 
-# name -> (restype, argtypes); mirrors include/libflagstats_hip.h one to one
+# name -> (restype, argtypes); mirrors include/libflagstats_hip.h + libflagstats_hip_probe.h one to one
 SIGNATURES = {
     "FLAGSTATS_u16": (ctypes.c_uint64, [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_void_p]),
     "FLAGSTATS_get_function": (FLAGSTATS_func, [ctypes.c_uint32]),

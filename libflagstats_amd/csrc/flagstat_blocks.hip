@@ -36,7 +36,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/libflagstats_hip.h"
+#include "../../include/libflagstats_hip_probe.h"
 #include "flagstat_engine.h"
 #include "lz4_block_decode.h"
 

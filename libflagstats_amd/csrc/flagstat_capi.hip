@@ -9,7 +9,7 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "../../include/libflagstats_hip.h"
+#include "../../include/libflagstats_hip_probe.h"
 #include "flagstat_engine.h"
 #include "flagstat_kernels.h"
 
@@ -192,7 +192,7 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
     } else if (!std::strcmp(key, "dyn_lg_queues")) {
         if (value > 4) return fail_text("dyn_lg_queues must be 0..4");
         k.dyn_lgq = static_cast<uint32_t>(value);
-        fsk_set_dyn_queues(k.dyn_lgq.load());
+        if (fsk_tuning_build()) fsk_set_dyn_queues(k.dyn_lgq.load());
     } else if (!std::strcmp(key, "dyn_first_pct") || !std::strcmp(key, "dyn_div") || !std::strcmp(key, "dyn_cmax") ||
                !std::strcmp(key, "dyn_min_steps")) {
         // K1's dynamic schedule (variant bit 7, flagstat_kernels.h DynSched)
@@ -201,7 +201,7 @@ int FLAGSTATS_hip_set(const char* key, uint64_t value)
             value > 0xFFFFFFFFull)
             return fail_text("dyn_first_pct 0..100, dyn_div 1..64, dyn_cmax 1..65535");
         slot = static_cast<uint32_t>(value);
-        fsk_set_dyn(k.dyn_first_pct.load(), k.dyn_div.load(), k.dyn_cmax.load(), k.dyn_min_steps.load());
+        if (fsk_tuning_build()) fsk_set_dyn(k.dyn_first_pct.load(), k.dyn_div.load(), k.dyn_cmax.load(), k.dyn_min_steps.load());
     } else if (!std::strcmp(key, "chunk_flags")) {
         if (value < 8) return fail_text("chunk_flags must be >= 8");
         k.chunk_flags = value;

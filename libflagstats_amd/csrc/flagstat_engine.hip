@@ -100,8 +100,10 @@ void read_env_knobs()
         g_knobs.group_max_steps = env_u64("FLAGSTATS_HIP_GROUP_MAX_STEPS", g_knobs.group_max_steps);
         fsk_set_group_max_steps(g_knobs.group_max_steps.load());
         g_knobs.dyn_lgq = static_cast<uint32_t>(env_u64("FLAGSTATS_HIP_DYN_LG_QUEUES", g_knobs.dyn_lgq));
-        fsk_set_dyn_queues(g_knobs.dyn_lgq.load());
-        fsk_set_dyn(g_knobs.dyn_first_pct.load(), g_knobs.dyn_div.load(), g_knobs.dyn_cmax.load(), g_knobs.dyn_min_steps.load());
+        if (fsk_tuning_build()) {   // (the dynamic schedule exists in the measurement build only)
+            fsk_set_dyn_queues(g_knobs.dyn_lgq.load());
+            fsk_set_dyn(g_knobs.dyn_first_pct.load(), g_knobs.dyn_div.load(), g_knobs.dyn_cmax.load(), g_knobs.dyn_min_steps.load());
+        }
         g_knobs.fuse = fsk_tuning_build() ? static_cast<int>(env_u64("FLAGSTATS_HIP_FUSE", static_cast<uint64_t>(g_knobs.fuse))) : 0;
         g_knobs.epilogue = static_cast<int>(env_u64("FLAGSTATS_HIP_EPILOGUE", static_cast<uint64_t>(g_knobs.epilogue)));
         g_knobs.numa = static_cast<int>(env_u64("FLAGSTATS_HIP_NUMA", static_cast<uint64_t>(g_knobs.numa)));
@@ -397,9 +399,26 @@ bool WorkerPool::start(int n, std::function<void(int)> fn)
 
 void WorkerPool::wait()
 {
-    std::unique_lock<std::mutex> ul(m_);
-    cv_done_.wait(ul, [&] { return running_ == 0; });
-    want_ = 0;
+    {
+        std::unique_lock<std::mutex> ul(m_);
+        cv_done_.wait(ul, [&] { return running_ == 0; });
+        want_ = 0;
+    }
+    // env FLAGSTATS_HIP_POOL=0 (A/B, tests/perf/small_file_phases.py): threads made and joined per call, as until r05
+    static const bool per_call = [] {
+        const char* k = std::getenv("FLAGSTATS_HIP_POOL");
+        return k && std::atoi(k) == 0;
+    }();
+    if (per_call) {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            stop_ = true;
+        }
+        cv_job_.notify_all();
+        for (std::thread& t : threads_) t.join();
+        threads_.clear();
+        stop_ = false;
+    }
 }
 
 Knobs& knobs()

@@ -41,7 +41,7 @@
 #include <sched.h>
 #include <unistd.h>
 
-#include "../../include/libflagstats_hip.h"
+#include "../../include/libflagstats_hip_probe.h"
 #include "flagstat_engine.h"
 #include "flagstat_kernels.h"
 #include "flagstat_lz4_kernels.h"
@@ -940,6 +940,15 @@ int lz4_gpu_run(Engine& e, const Lz4GpuSource& in, const GpuFileIndex& ix, uint6
     PhaseClock pc;
     pc.start();
     pc.index = ix.index_ms;   // (made before the engine's lock was taken: lz4_gpu_index)
+    // The engine's second stream is this decoder's first decode stream.  In a process whose engine has only just been made its
+    // helper thread may still be at it: wait for it HERE, with nothing else going on -- joined later, from the stream-making
+    // thread below, the helper's runtime calls ran beside this thread's allocations and index upload and slowed each other down
+    // (one-shot HC-9 file: 132 ms start -> counters against 128; profiles/r06/cold_start.log, cold_start_eager_second_stream.log)
+    {
+        const int src = engine_second(e);
+        if (src) return src;
+    }
+    pc.lap(pc.streams);
     const uint64_t bytes = in.bytes;
     const std::vector<fsk::GpuBlock>& blocks = ix.blocks;
     const uint64_t dpos = ix.dpos, n_flags = ix.n_flags, usum = ix.usum;

@@ -12,7 +12,7 @@ constexpr int kThreads = 256;                       // 4 waves per workgroup
 constexpr int kUnroll = 8;                          // 16-B vectors per lane per step
 constexpr int kVecPerStep = kThreads * kUnroll;     // 2048 vectors = 32 KiB = 16384 flags
 constexpr int kGroupTicketWord = 288;               // workspace block (u64 words): 8 group tickets, 16 words apart
-constexpr int kGroupCopyWord = 512;                 // ... and 8 copies of the 32 slots (flagstat_kernels.hip: grouped_epilogue)
+constexpr int kGroupCopyWord = 512;                 // ... and 8 copies of the 32 slots (flagstat_count_core.h: grouped_epilogue)
 constexpr int kInternal = 21;                       // 19 live counters (libflagstats.h:118-142) + primary-paired reads x {pass, fail}
 
 // K1's dynamic schedule (STAGE 4): round 0 = c0 grid-stride steps per workgroup; the rest is cut into 2^lgq queues,
@@ -70,24 +70,28 @@ hipError_t fsk_launch(const uint16_t* d_array, uint64_t n, uint32_t grid, int va
                       uint32_t* d_ticket, uint64_t* d_out32, hipStream_t stream, uint64_t* signal_word = nullptr,
                       uint64_t signal_value = 0);
 int fsk_variant_supported(int variant);   // K1 schedule compiled into this build?
-// dynamic schedule policy (variant bit 7): first_pct = share of the steps in the static round 0 (0..100), div and cmax
-// as in DynSched; arrays of fewer than min_steps_per_wg full steps per workgroup stay fully static
-void fsk_set_dyn(uint32_t first_pct, uint32_t div, uint32_t cmax, uint32_t min_steps_per_wg);
-void fsk_set_dyn_queues(uint32_t lg_queues);
+// measurement build only (defined in flagstat_kernels_tuning.hip, `make tuning`; NULL in the product library -- callers
+// check fsk_tuning_build() first).  Dynamic schedule policy (variant bit 7): first_pct = share of the steps in the static
+// round 0 (0..100), div and cmax as in DynSched; arrays of fewer than min_steps_per_wg full steps per workgroup stay fully static
+void fsk_set_dyn(uint32_t first_pct, uint32_t div, uint32_t cmax, uint32_t min_steps_per_wg) __attribute__((weak));
+void fsk_set_dyn_queues(uint32_t lg_queues) __attribute__((weak));   // 2^lg_queues (<= 16) counters
+void fsk_set_anatomy(int bits) __attribute__((weak));                // skip parts of K1 to time the rest (results wrong)
+// what the product launcher shares with the measurement build's: the epilogue policy knobs, the last mode word, K2
+void fsk_launch_policy(int* stagger, uint32_t* group_min_grid, uint64_t* group_max_steps);
+void fsk_note_mode(int mode);
+hipError_t fsk_launch_finalize(uint64_t* d_partials, uint32_t grid, uint64_t* d_out32, int mode, uint64_t n, fsk::HostSignal sig,
+                               hipStream_t stream);
 // K1's direct epilogue adds to per-XCD copies first when the grid has at least this many workgroups (0: always)
 void fsk_set_group_min_grid(uint32_t min_grid);
 // ... and at most this many steps per workgroup (default 40); beyond that workgroups finish apart and add straight to out[]
 void fsk_set_group_max_steps(uint64_t max_steps_per_workgroup);
 int fsk_last_mode(void);                  // K1 mode word of the most recent fsk_launch (bit 3 = two-level epilogue); tests
-void fsk_set_epoch_stagger(int on);            // 1 (default): wave w of a workgroup starts its first epoch at step count 64 * w   // 2^lg_queues (<= 16) counters
-void fsk_set_anatomy(int bits);           // tuning builds only: skip parts of K1 to time the rest (results wrong)
-int fsk_tuning_build(void);               // 1: built with -DFLAGSTAT_TUNING_VARIANTS (make TUNING=1)
+void fsk_set_epoch_stagger(int on);       // 1 (default): wave w of a workgroup starts its first epoch at step count 64 * w
+int fsk_tuning_build(void);               // 1: the measurement build (make tuning / make TUNING=1): flagstat_kernels_tuning.hip is linked
 // positional popcount (flagstat_pospopcnt.hip): d_out16[16] += bit counts.  d_partials as for fsk_launch.
 // direct != 0: the count kernel adds its workgroup totals to d_out16 with atomics (device memory only), no finalize launch.
 hipError_t fsk_launch_pospopcnt(const uint16_t* d_array, uint64_t n, uint32_t grid, uint64_t* d_partials,
                                 uint64_t* d_out16, hipStream_t stream, int direct);
-// read-only bandwidth probe (measurement only)
-hipError_t fsk_read_probe(const void* d_buf, uint64_t bytes, uint32_t grid, int nt, uint32_t* d_sink, hipStream_t stream);
 // shader clock under load (measurement only): d_out[2 * b] = shader-clock cycles, d_out[2 * b + 1] = 100 MHz reference ticks
 // that workgroup b (one wave) spent spinning; ticks <= 1e8 (1 s)
 hipError_t fsk_clock_probe(uint64_t* d_out, uint32_t grid, uint64_t ticks, hipStream_t stream);

@@ -182,6 +182,64 @@ double ref_dispatch_mt_bench(uint64_t per_thread_flags, int threads, uint32_t re
     return e - b;
 }
 
+/* All cores over DRAM-resident data (contiguous shards of the workload): `threads` workers,
+ * worker k pinned to the k-th CPU this process may run on, reads the k-th contiguous shard of the CALLER's array (which the
+ * caller generated with the same pinning, so a shard's pages lie where its reader runs), ONE pass of the dispatcher's kernel
+ * per round, a barrier before each round; seconds[r] = first start .. last end of round r.  A shard of 256 MiB and more is
+ * far beyond the caches: every round reads DRAM.  out[32] += the counters of one pass.  Returns 0. */
+int ref_dispatch_mt_shards(const uint16_t* a, uint64_t n, int threads, int rounds, double* seconds, uint64_t out[32])
+{
+    if (threads < 1 || rounds < 1 || !seconds) return -1;
+    cpu_set_t allowed;
+    CPU_ZERO(&allowed);
+    std::vector<int> cpus;
+    if (sched_getaffinity(0, sizeof allowed, &allowed) == 0)
+        for (int c = 0; c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET(c, &allowed)) cpus.push_back(c);
+    std::atomic<int> arrived{0};
+    std::atomic<int> phase{0};
+    std::vector<std::vector<uint64_t>> part(threads, std::vector<uint64_t>(32, 0));
+    std::vector<std::vector<double>> t_begin(rounds, std::vector<double>(threads, 0.0)), t_end(rounds, std::vector<double>(threads, 0.0));
+    auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    auto barrier = [&](int target_phase) {
+        if (arrived.fetch_add(1) + 1 == threads * target_phase) phase.store(target_phase);
+        while (phase.load() < target_phase) std::this_thread::yield();
+    };
+    auto work = [&](int k) {
+        if (!cpus.empty()) {
+            cpu_set_t one;
+            CPU_ZERO(&one);
+            CPU_SET(cpus[k % cpus.size()], &one);
+            (void)pthread_setaffinity_np(pthread_self(), sizeof one, &one);
+        }
+        const uint64_t per = n / static_cast<uint64_t>(threads);
+        const uint64_t b = per * static_cast<uint64_t>(k), e = (k == threads - 1) ? n : b + per;
+        for (int r = 0; r < rounds; ++r) {
+            uint64_t acc[32] = {0};
+            barrier(r + 1);
+            t_begin[r][k] = now();
+            ref_dispatch_x64(a + b, e - b, acc);
+            t_end[r][k] = now();
+            if (r == 0)
+                for (int i = 0; i < 32; ++i) part[k][i] = acc[i];
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int k = 0; k < threads; ++k) pool.emplace_back(work, k);
+    for (auto& t : pool) t.join();
+    for (int r = 0; r < rounds; ++r) {
+        double b = t_begin[r][0], e = t_end[r][0];
+        for (int k = 1; k < threads; ++k) {
+            if (t_begin[r][k] < b) b = t_begin[r][k];
+            if (t_end[r][k] > e) e = t_end[r][k];
+        }
+        seconds[r] = e - b;
+    }
+    for (int k = 0; k < threads; ++k)
+        for (int i = 0; i < 32; ++i) out[i] += part[k][i];
+    return 0;
+}
+
 void ref_scalar_x64(const uint16_t* a, uint64_t n, uint64_t out[32])
 {
     const uint64_t CH = 1ull << 30;

@@ -11,8 +11,13 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# tests of the MEASUREMENT build (make tuning) are not part of the product's suite: neither `-m gpu` nor `-m "not gpu"` sees them
+collect_ignore_glob = [] if os.environ.get("FLAGSTATS_TUNING_TESTS") else ["tuning/*"]
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "tuning: needs a real MI355X AND the measurement build of the library (tests/tuning/)")
 
 
 def load_golden(name):

@@ -18,7 +18,7 @@
 #include <sys/wait.h>
 #include <unistd.h>
 
-#include "../../include/libflagstats_hip.h"
+#include "../../include/libflagstats_hip_probe.h"
 extern "C" {
 #include "../../oracle/flagstat_oracle.h"
 }

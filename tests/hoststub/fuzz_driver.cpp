@@ -21,7 +21,7 @@
 #include <string>
 #include <vector>
 
-#include "../../include/libflagstats_hip.h"
+#include "../../include/libflagstats_hip_probe.h"
 extern "C" {
 #include "../../oracle/flagstat_oracle.h"
 }

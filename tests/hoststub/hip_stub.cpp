@@ -20,7 +20,7 @@
 #include <thread>
 #include <vector>
 
-#include "../../include/libflagstats_hip.h"
+#include "../../include/libflagstats_hip_probe.h"
 #include "../../libflagstats_amd/csrc/flagstat_engine.h"
 #include "../../libflagstats_amd/csrc/flagstat_kernels.h"
 
@@ -477,7 +477,6 @@ hipError_t fsk_generate(uint16_t* d_array, uint64_t n, int kind, uint64_t seed, 
     return hipSuccess;
 }
 
-hipError_t fsk_read_probe(const void*, uint64_t, uint32_t, int, uint32_t*, hipStream_t) { return hipSuccess; }
 hipError_t fsk_read_probe_policy(const void*, uint64_t, int, uint32_t, uint32_t*, hipStream_t) { return hipSuccess; }
 hipError_t fsk_read_probe2(const void*, uint64_t, int, int, uint32_t, uint32_t, int, uint32_t*, hipStream_t) { return hipSuccess; }
 hipError_t fsk_clock_probe(uint64_t* d_out, uint32_t grid, uint64_t ticks, hipStream_t stream)

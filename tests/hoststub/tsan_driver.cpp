@@ -10,7 +10,7 @@
 #include <vector>
 #include <unistd.h>
 
-#include "../../include/libflagstats_hip.h"
+#include "../../include/libflagstats_hip_probe.h"
 extern "C" {
 #include "../../oracle/flagstat_oracle.h"
 }

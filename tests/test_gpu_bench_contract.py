@@ -20,7 +20,8 @@ def run_bench(*extra):
         port = sk.getsockname()[1]
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--flags-per-gpu", str(2 ** 27), "--steps", "6",
-                        "--warmup", "2", "--cpu-seconds", "0.5", "--cpu-sample", str(2 ** 22), "--probe-reps", "3", *extra],
+                        "--warmup", "2", "--cpu-seconds", "0.5", "--cpu-sample", str(2 ** 22), "--cpu-dram-per-core", str(2 ** 23),
+                        "--probe-reps", "3", *extra],
                        capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stdout + r.stderr
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
@@ -45,6 +46,12 @@ def test_single_gpu_line(hip):
     assert abs(d["ms_per_step"] / r["event_ms_per_launch"] - 1.0) < 0.1
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] == 1 and c["value"] > 0 and "sample" in c
+    if c["kind"] == "reference":
+        # the all-core neighbours: cache-resident shards (flatters the CPU) and ONE pass over contiguous DRAM-resident shards of the
+        # workload -- here 16 MiB per core, 256 MiB in the default run
+        a, m = c["all_cores"], c["all_cores_dram"]
+        assert a["cores"] == m["cores"] >= 1 and a["value"] > 0 and m["value"] > 0 and "contiguous shards" in m["sample"]
+        assert m["min"] <= m["value"] <= m["max"]
     assert d["parity"].startswith("bit-exact")
 
 

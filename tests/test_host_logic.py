@@ -56,14 +56,16 @@ def test_shard_ranges_cover_exactly():
 
 
 def declared_symbols():
-    text = open(os.path.join(ROOT, "include", "libflagstats_hip.h")).read()
+    # the product ABI and the measurement entries (two headers, one library)
+    text = open(os.path.join(ROOT, "include", "libflagstats_hip.h")).read() + open(os.path.join(ROOT, "include", "libflagstats_hip_probe.h")).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
     names = re.findall(r"\b((?:FLAGSTATS?|STORM)_[A-Za-z0-9_]+)\s*\(", text)
     return sorted(set(n for n in names if n != "FLAGSTATS_func"))
 
 
 def test_library_exports_every_declared_symbol():
-    """The C-ABI .so loads without a GPU and exports everything include/libflagstats_hip.h declares."""
+    """The C-ABI .so loads without a GPU and exports everything include/libflagstats_hip.h and libflagstats_hip_probe.h declare;
+    a reader finds the three reference symbols and their contract on the first screen of the product header."""
     from libflagstats_amd import _lib
     lib = _lib.lib()
     syms = declared_symbols()
@@ -76,6 +78,12 @@ def test_library_exports_every_declared_symbol():
     text = open(os.path.join(ROOT, "include", "libflagstats_hip.h")).read()
     for cite in ("libflagstats.h:3024", "libflagstats.h:2976", "libflagstats.h:2970"):
         assert cite in text
+    first_screen = "\n".join(text.splitlines()[:60])
+    for sym in ("FLAGSTATS_u16(", "FLAGSTATS_get_function(", "FLAGSTAT_hip(", "FLAGSTATS_func"):
+        assert sym in first_screen, sym
+    probe = open(os.path.join(ROOT, "include", "libflagstats_hip_probe.h")).read()
+    for sym in ("FLAGSTATS_hip_read_probe", "FLAGSTATS_hip_time_device_u16", "FLAGSTATS_hip_sclk_under_load"):
+        assert sym in probe and sym not in text, sym
 
 
 def test_header_shim_consumer_compiles_and_links(tmp_path):
@@ -138,3 +146,36 @@ def test_product_never_imports_oracle():
         if f.endswith((".py", ".sh")):
             src = open(os.path.join(ROOT, "tools", f)).read()
             assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_shipped_kernel_file_carries_the_product_only():
+    """one kernel, one body.  The shipped K1 / K2 file carries the three schedules the library ships and
+    no measurement-build conditionals; the losers of the sweeps live in flagstat_kernels_tuning.hip, which only `make tuning`
+    compiles; the product library therefore has no tuning launcher and refuses every other schedule."""
+    csrc = os.path.join(ROOT, "libflagstats_amd", "csrc")
+    text = open(os.path.join(csrc, "flagstat_kernels.hip")).read()
+    assert len(text.splitlines()) < 700
+    assert "#ifdef" not in text and "#ifndef" not in text and "FLAGSTAT_TUNING_VARIANTS" not in text
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    srcs = [ln for ln in mk.splitlines() if ln.startswith("SRCS")][0]
+    assert "flagstat_kernels_tuning.hip" not in srcs          # only added under TUNING=1
+    import ctypes
+    from libflagstats_amd import _lib
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    if not os.environ.get("FLAGSTATS_HIP_LIB"):
+        assert lib.fsk_tuning_build() == 0
+        assert [lib.fsk_variant_supported(v) for v in (9, 25, 71)] == [1, 1, 1]
+        assert not any(lib.fsk_variant_supported(v) for v in (0, 1, 13, 17, 27, 29, 41, 57, 61, 63, 65, 67, 69, 73, 75, 77, 79, 81, 89, 153))
+
+
+def test_kernel_id_is_the_device_codes_not_the_sources():
+    """bench.py's kernel_source_id = sha256 over .text + .rodata of the gfx950 code object that defines fsk::flagstat_count,
+    read out of the built .so (libflagstats_amd/kernel_id.py): a host-side edit no longer invalidates profiles/traffic.json."""
+    from libflagstats_amd.kernel_id import _code_objects, kernel_id
+    kid = kernel_id()
+    assert re.fullmatch(r"[0-9a-f]{16}", kid)
+    from libflagstats_amd import _lib
+    cos = list(_code_objects(open(_lib.LIB_PATH, "rb").read()))
+    assert len(cos) >= 5                                           # K1/K2, pospopcnt, generate, probes, LZ4, Zstandard
+    import bench
+    assert bench.kernel_source_id() == kid

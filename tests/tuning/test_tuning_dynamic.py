@@ -1,11 +1,17 @@
 """GPU: K1's dynamic schedule (variant bit 7: guided self-scheduling through device counters, grabbed by a
 scheduler wave) -- every policy corner against the oracle, and the counters' self-reset across launches.
-The schedule balanced the XCDs and was not faster (profiles/r03/dyn_sweep*.log), so it is carried by the tuning
-build only: run with FLAGSTATS_HIP_LIB=libflagstats_amd/libflagstats_hip_tuning.so; the shipped library must refuse it."""
+The schedule balanced the XCDs and was not faster (profiles/r03/dyn_sweep*.log), so it is carried by the measurement
+build only (flagstat_kernels_tuning.hip) and this file is NOT part of the product's test suite (tests/conftest.py leaves
+tests/tuning/ out unless asked):
+
+    make -C libflagstats_amd/csrc tuning
+    FLAGSTATS_TUNING_TESTS=1 FLAGSTATS_HIP_LIB=$PWD/libflagstats_amd/libflagstats_hip_tuning.so python -m pytest tests/tuning -m tuning
+
+(that the shipped library refuses variant 153 is checked where the product is tested: tests/test_gpu_parity.py)."""
 import numpy as np
 import pytest
 
-pytestmark = pytest.mark.gpu
+pytestmark = pytest.mark.tuning
 
 STEP = 16384   # flags per 32 KiB step
 
@@ -15,9 +21,7 @@ def dyn(hip):
     from libflagstats_amd import _lib
     keys = (b"variant", b"blocks_per_cu", b"epilogue", b"dyn_first_pct", b"dyn_div", b"dyn_cmax", b"dyn_min_steps", b"dyn_lg_queues")
     old = {k: hip.FLAGSTATS_hip_get(k) for k in keys}
-    if not hip.FLAGSTATS_hip_get(b"tuning_build"):
-        assert hip.FLAGSTATS_hip_set(b"variant", 153) != 0 and b"TUNING=1" in hip.FLAGSTATS_hip_last_error()
-        pytest.skip("variant 153 is compiled into the tuning build only")
+    assert hip.FLAGSTATS_hip_get(b"tuning_build"), "load the measurement build: FLAGSTATS_HIP_LIB=.../libflagstats_hip_tuning.so"
     _lib.check(hip.FLAGSTATS_hip_set(b"variant", 153), "variant 153")
     yield hip
     for k, v in old.items():

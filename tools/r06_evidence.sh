@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6's measured evidence (everything lands in gpurun_out/r06/, summaries are copied to profiles/r06):
-#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests cold small dist distprof
+#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests tuning bench cold small dist distprof
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06
@@ -18,7 +18,21 @@ if has cold; then
     FLAGSTATS_HIP_EAGER_SECOND=1 timeout 900 python3 tests/perf/cold_start.py --samples 5 --gap-s 2 --which u16,hc9 2>&1 | grep -v amdgpu.ids > $O/cold_start_eager_second_stream.log || exit 1
 fi
 if has small; then
-    timeout 600 python3 tests/perf/small_file_phases.py 2>&1 | grep -v amdgpu.ids > $O/small_file_phases.log || exit 1
+    # the worker pool kept with the engine against threads made and joined per call (r05), same box, alternating
+    for rep in 1 2; do
+        timeout 600 python3 tests/perf/small_file_phases.py 2>&1 | grep -v amdgpu.ids > $O/small_file_phases_pool_$rep.log || exit 1
+        FLAGSTATS_HIP_POOL=0 timeout 600 python3 tests/perf/small_file_phases.py 2>&1 | grep -v amdgpu.ids > $O/small_file_phases_threads_per_call_$rep.log || exit 1
+    done
+fi
+if has tuning; then
+    # the measurement build: its own tests (tests/tuning) and every schedule through the parity / fuzz tests that take the library from FLAGSTATS_HIP_LIB
+    FLAGSTATS_TUNING_TESTS=1 FLAGSTATS_HIP_LIB=$PWD/libflagstats_amd/libflagstats_hip_tuning.so timeout 900 python3 -m pytest tests/tuning tests/test_gpu_parity.py tests/test_gpu_fuzz.py tests/test_gpu_epilogue.py -x -q -m "gpu or tuning" > $O/tuning_build_tests.log 2>&1 || { tail -30 $O/tuning_build_tests.log; exit 1; }
+    tail -3 $O/tuning_build_tests.log
+fi
+if has bench; then
+    timeout 900 python3 bench.py > $O/bench_default.log 2>&1 || { tail -20 $O/bench_default.log; exit 1; }
+    timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.log 2>&1 || exit 1
+    tail -1 $O/bench_default.log | cut -c1-600
 fi
 if has dist; then
     # the N > 1 step on HEAD at world size 1, every form, 8 GiB and 1 GiB shards

@@ -10,7 +10,6 @@ streaming read, WRITE_SIZE is exact:  bytes = 2 * FETCH_SIZE * 1024 + WRITE_SIZE
 import argparse
 import csv
 import glob
-import hashlib
 import json
 import os
 import sys
@@ -19,11 +18,10 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_source_id():
-    h = hashlib.sha256()
-    for f in ("flagstat_kernels.hip", "flagstat_device.h", "flagstat_kernels.h"):
-        with open(os.path.join(ROOT, "libflagstats_amd", "csrc", f), "rb") as fh:
-            h.update(fh.read())
-    return h.hexdigest()[:16]
+    """id of the K1 / K2 device code of the in-tree library (the one that was profiled): libflagstats_amd/kernel_id.py"""
+    sys.path.insert(0, ROOT)
+    from libflagstats_amd.kernel_id import kernel_id
+    return kernel_id()
 
 
 def find(src, sub, pattern):
