@@ -494,7 +494,7 @@ def main():
     torch.cuda.synchronize()
 
     # Strong scaling shrinks the shard with N (8 GiB total: 1 GiB shards at N = 8, K1 ~150 us) while K2 + the all-reduce
-    # do not shrink: in line they cost more than the 7 us per step that 7.5x leaves (DESIGN.md "Multi-GPU", budget table),
+    # do not shrink: in line they cost more than the 3-4 us per step that 7.5x leaves (DESIGN.md "Multi-GPU", budget table),
     # so --strong times both forms first and takes the faster one unless a form was asked for explicitly.
     if args.strong and multi and not (args.overlap or args.no_overlap):
         args.calibrate = True

@@ -24,7 +24,7 @@
 //     (knob "lz4_gpu_keep_bytes"), on every failure, and by FLAGSTATS_hip_shutdown;
 //   * compressed and decoded bytes of a run are resident together, so a file larger than a third of the free device
 //     memory (or 16 GiB of flags) goes through in several segments.
-// Measurements: profiles/r04/lz4_*.log; DESIGN.md section 4.
+// Measurements: profiles/r04/lz4_*.log, profiles/r05/; DESIGN.md section 6, development notes in HISTORY.md.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
