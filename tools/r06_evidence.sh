@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6's measured evidence (everything lands in gpurun_out/r06/, summaries are copied to profiles/r06):
-#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests tuning bench cold small dist distprof
+#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests tuning bench cold small soak dist distprof
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06
@@ -33,6 +33,14 @@ if has bench; then
     timeout 900 python3 bench.py > $O/bench_default.log 2>&1 || { tail -20 $O/bench_default.log; exit 1; }
     timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.log 2>&1 || exit 1
     tail -1 $O/bench_default.log | cut -c1-600
+fi
+if has soak; then
+    # the engine's helper thread, the worker pool and the index-before-lock change under concurrency: fresh processes creating
+    # engines and counting at once, four caller threads mixing every entry family, the host paths from two threads
+    timeout 600 python3 tests/perf/soak_concurrency.py 60 2>&1 | grep -v amdgpu.ids > $O/soak_concurrency.log || { tail -20 $O/soak_concurrency.log; exit 1; }
+    timeout 600 python3 tests/perf/stress_mixed.py --seconds 60 2>&1 | grep -v amdgpu.ids > $O/stress_mixed.log || { tail -20 $O/stress_mixed.log; exit 1; }
+    timeout 900 python3 tests/perf/soak_host_paths.py --rounds 300 2>&1 | grep -v amdgpu.ids > $O/soak_host_paths.log || { tail -20 $O/soak_host_paths.log; exit 1; }
+    tail -3 $O/soak_concurrency.log $O/stress_mixed.log $O/soak_host_paths.log | cut -c1-300
 fi
 if has dist; then
     # the N > 1 step on HEAD at world size 1, every form, 8 GiB and 1 GiB shards
