@@ -658,6 +658,24 @@ def main():
         t = torch.tensor([a0.elapsed_time(a1) * 100.0], dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         allreduce_us = round(float(t[0]), 2)
+    # N > 1, untimed: every rank's OWN K1 (the N = 1 form: one launch, atomic epilogue, no K2, no collective) over its shard, 20
+    # launches between stream events -- so that a scaling number can be taken apart without a second run: step - K1 alone = what
+    # K2 + the collective + waiting for the slowest rank cost; the spread of K1 alone over the ranks = chip-to-chip variation
+    per_rank_k1_ms = None
+    if multi:
+        k1_scratch = torch.zeros(32, dtype=torch.int64, device=dev)
+        for _ in range(3):
+            device.count_torch(flags, k1_scratch)
+        k0, k1e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        k0.record()
+        for _ in range(20):
+            device.count_torch(flags, k1_scratch)
+        k1e.record()
+        k1e.synchronize()
+        mine = torch.zeros(world, dtype=torch.float64, device=dev if args.backend == "nccl" else "cpu")
+        mine[rank] = k0.elapsed_time(k1e) / 20.0
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        per_rank_k1_ms = [round(float(x), 5) for x in mine.cpu()]
     if not multi:
         counters.zero_()      # stream-ordered behind the warm-up steps: ONE sync gap before the timed region, not two
     # the per-step events exist (torch creates the HIP event at the first record) BEFORE the barrier: the GPU idles
@@ -762,6 +780,7 @@ def main():
                        "rccl_nranks": rccl_nranks,
                        "rccl_library": rccl_library if comm else None,
                        "per_rank_ms": per_rank_ms,
+                       "per_rank_k1_alone_ms": per_rank_k1_ms,
                        "slowest_rank": (max(range(world), key=lambda r: per_rank_ms[r]) if per_rank_ms else None),
                        "allreduce_us": allreduce_us,
                        "kernel_variant": int(lib.FLAGSTATS_hip_get(b"variant")),

@@ -104,6 +104,9 @@ def test_two_ranks_self_spawned_on_one_gpu(hip):
     c = d["config"]
     assert len(c["per_rank_ms"]) == 2 and all(t > 0 for t in c["per_rank_ms"]) and c["slowest_rank"] in (0, 1)
     assert c["per_rank_ms"][c["slowest_rank"]] == max(c["per_rank_ms"]) and c["allreduce_us"] > 0
+    # ... and every rank's own K1 in the N = 1 form (no K2, no collective), measured in the same run: the step minus this is what
+    # the multi-GPU form costs on that rank
+    assert len(c["per_rank_k1_alone_ms"]) == 2 and all(0 < k <= 1.5 * t for k, t in zip(c["per_rank_k1_alone_ms"], c["per_rank_ms"]))
 
 
 def test_a_rank_that_dies_in_set_up_fails_the_run_quickly(hip):
