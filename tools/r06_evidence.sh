@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6's measured evidence (everything lands in gpurun_out/r06/, summaries are copied to profiles/r06):
-#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests tuning bench cold small soak dist distprof
+#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests tuning bench cold small smallcalls soak dist distprof
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06
@@ -33,6 +33,11 @@ if has bench; then
     timeout 900 python3 bench.py > $O/bench_default.log 2>&1 || { tail -20 $O/bench_default.log; exit 1; }
     timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.log 2>&1 || exit 1
     tail -1 $O/bench_default.log | cut -c1-600
+fi
+if has smallcalls; then
+    # the drop-in entry per call on HEAD (every entry now starts with the fork guard's getpid())
+    timeout 600 python3 tests/perf/bench_small_calls.py 2>&1 | grep -v amdgpu.ids > $O/small_calls.log || { tail -n 20 $O/small_calls.log; exit 1; }
+    cat $O/small_calls.log | cut -c1-200
 fi
 if has soak; then
     # the engine's helper thread, the worker pool and the index-before-lock change under concurrency: fresh processes creating
