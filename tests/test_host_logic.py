@@ -179,3 +179,50 @@ def test_kernel_id_is_the_device_codes_not_the_sources():
     assert len(cos) >= 5                                           # K1/K2, pospopcnt, generate, probes, LZ4, Zstandard
     import bench
     assert bench.kernel_source_id() == kid
+
+
+def test_fork_is_detected_by_the_library_and_the_binding_without_a_gpu():
+    """VERDICT r05 item 2, the half that needs no GPU: the first entry call claims the library for this process; a child
+    fork()ed after that is told so by FLAGSTATS_hip_forked(), refused by the C entries with a text naming the fork and the
+    remedy, and `_lib.lib()` raises FlagstatsHipError with the same advice.  The parent is unaffected.  (Every entry family, with
+    a parent thread inside the engine during the fork: tests/test_host_asan.py; on the GPU: tests/test_gpu_fork.py.)"""
+    import json
+    from libflagstats_amd import _lib
+    lib = _lib.lib()
+    lib.FLAGSTATS_hip_available()            # any entry claims the library (no GPU here: it answers 0)
+    assert lib.FLAGSTATS_hip_forked() == 0
+    r, w = os.pipe()
+    pid = os.fork()
+    if pid == 0:
+        rep = {}
+        try:
+            raw = _lib._lib
+            rep["forked"] = int(raw.FLAGSTATS_hip_forked())
+            out = np.zeros(32, dtype=np.uint64)
+            a = np.arange(64, dtype=np.uint16)
+            rep["rc"] = int(raw.FLAGSTATS_u16_x64(a.ctypes.data, a.size, out.ctypes.data))
+            rep["text"] = raw.FLAGSTATS_hip_last_error().decode(errors="replace")
+            try:
+                _lib.lib()
+                rep["py"] = "no exception"
+            except Exception as e:  # noqa: BLE001
+                rep["py"] = "%s: %s" % (type(e).__name__, e)
+        except BaseException as e:  # noqa: BLE001
+            rep["crash"] = repr(e)
+        os.write(w, json.dumps(rep).encode())
+        os._exit(0)
+    os.close(w)
+    data = b""
+    while True:
+        chunk = os.read(r, 65536)
+        if not chunk:
+            break
+        data += chunk
+    os.close(r)
+    _, status = os.waitpid(pid, 0)
+    assert os.WIFEXITED(status) and os.WEXITSTATUS(status) == 0
+    rep = json.loads(data)
+    assert "crash" not in rep, rep
+    assert rep["forked"] == 1 and rep["rc"] != 0 and "fork()ed" in rep["text"] and "spawn" in rep["text"], rep
+    assert rep["py"].startswith("FlagstatsHipError") and "spawn" in rep["py"], rep
+    assert lib.FLAGSTATS_hip_forked() == 0 and _lib.lib() is lib
