@@ -59,3 +59,28 @@ def test_two_rank_shard_and_allreduce():
         assert big == ((2 ** 62) * 2 + 1) - 2 ** 64   # wraps exactly like uint64 addition
     assert spans[0] == (0, n // 2) and spans[1] == (n // 2, n)
     assert np.uint64(2 ** 63 + 1) == np.array([big], dtype=np.int64).view(np.uint64)[0]
+
+
+def test_eight_rank_shard_and_allreduce():
+    """The north_star's world size, rehearsed on the CPU: eight ranks, an array length that is no multiple of eight (the remainder
+    goes to the last rank), every rank ends up with the whole array's counters and the shards tile [0, n) exactly."""
+    import oracle
+    n, seed, world = 8_000_005, 23, 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n, seed, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    want = oracle.flagstat_generated(oracle.GEN_UNIFORM, seed, 0xFFFF, 0, n, threads=2).tolist()
+    spans = {}
+    for rank, total, span, big in res:
+        assert total == want
+        spans[rank] = tuple(span)
+        assert big == (((2 ** 62) * 8 + sum(range(8))) % 2 ** 64)   # eight times 2^62 wraps to 28 exactly like uint64 addition
+    per = n // world
+    assert [spans[r] for r in range(world)] == [(per * r, n if r == world - 1 else per * (r + 1)) for r in range(world)]
