@@ -65,12 +65,18 @@ static std::vector<unsigned char> make_image(const std::vector<uint16_t>& flags,
 static void block_pipeline(const std::vector<uint16_t>& flags, const uint64_t* want)
 {
     const std::vector<unsigned char> img = make_image(flags, {51200, 512000, 7, 300001, 123456});
-    for (int threads : {1, 5, 20}) {
+    // The decoders are threads of the ENGINE's worker pool (made on first need, parked between calls): the counts go up and
+    // down, so a job runs on fewer threads than the pool holds, then on more than it has (the pool grows), call after call --
+    // every job must run on exactly the number asked for (a parked thread that joined in, or one that missed its job, shows as
+    // a wrong count or a hang).
+    for (int threads : {1, 5, 20, 2, 20, 1, 9}) {
         uint64_t out[32] = {0};
         FLAGSTATS_blockfile_stats st;
         const int rc = FLAGSTATS_hip_blockimage_lz4(img.data(), img.size(), threads, out, &st);
         CHECK(rc == 0 && same(out, want), "block image, %d decoder threads: rc %d (%s)", threads, rc, FLAGSTATS_hip_last_error());
         CHECK(st.n_flags == flags.size(), "block image: %llu flags seen", static_cast<unsigned long long>(st.n_flags));
+        const int expect = static_cast<uint64_t>(threads) < st.n_blocks ? threads : static_cast<int>(st.n_blocks);   // (never more than blocks)
+        CHECK(st.threads == expect, "block image: %d decoder threads asked for, %d expected, %d ran", threads, expect, st.threads);
     }
 }
 
