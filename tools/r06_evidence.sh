@@ -1,6 +1,6 @@
 #!/bin/bash
 # Round 6's measured evidence (everything lands in gpurun_out/r06/, summaries are copied to profiles/r06):
-#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests tuning bench cold small smallcalls soak dist distprof
+#   gpurun -- 'bash tools/r06_evidence.sh [part ...]'      parts: tests tuning bench cold small decoders smallcalls soak dist distprof
 set -x
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 O=gpurun_out/r06
@@ -33,6 +33,13 @@ if has bench; then
     timeout 900 python3 bench.py > $O/bench_default.log 2>&1 || { tail -20 $O/bench_default.log; exit 1; }
     timeout 900 python3 bench.py --gpus 1 --steps 20 --warmup 5 > $O/bench_driver_args.log 2>&1 || exit 1
     tail -1 $O/bench_default.log | cut -c1-600
+fi
+if has decoders; then
+    # the block-file entries on the final tree (the kernels are r05's; the orchestration changed: pooled readers / decoders, the index
+    # pass before the lock, the engine's helper joined first): host threads against GPU decode, image and file mode
+    timeout 900 python3 tests/perf/lz4_decoder_sweep.py --modes fast:2,hc:9 --sizes "2**23,2**27,824541892,2**31" --file-flags 824541892 --reps 5 2>&1 | grep -v amdgpu.ids > $O/lz4_decoder_sweep.log || { tail -n 20 $O/lz4_decoder_sweep.log; exit 1; }
+    timeout 900 python3 tests/perf/lz4_decoder_sweep.py --modes zstd:1 --sizes "2**26,2**27,824541892,2**31" --file-flags 824541892 --reps 4 2>&1 | grep -v amdgpu.ids > $O/zstd_decoder_sweep.log || { tail -n 20 $O/zstd_decoder_sweep.log; exit 1; }
+    cat $O/lz4_decoder_sweep.log $O/zstd_decoder_sweep.log | cut -c1-230
 fi
 if has smallcalls; then
     # the drop-in entry per call on HEAD (every entry now starts with the fork guard's getpid())
