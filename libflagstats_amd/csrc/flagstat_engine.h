@@ -125,6 +125,7 @@ struct Engine {
     std::mutex second_mu;                          // guards the join only
     std::thread second_maker;
     hipError_t second_err = hipSuccess;            // written by the helper, read after the join
+    std::atomic<bool> second_hurry{false};         // cuts the helper's head start for a first small call short (engine_setup, engine_second)
     std::unique_ptr<WorkerPool> pool;              // made on first need (run_pipeline, file-mode readers); e.mu held
     hipStream_t stream[2] = {nullptr, nullptr};
     Workspace ws[2];

@@ -146,6 +146,7 @@ int numa_node_of_device(int device)
 
 void join_second(Engine& e)
 {
+    e.second_hurry.store(true, std::memory_order_release);
     std::lock_guard<std::mutex> lk(e.second_mu);
     if (e.second_maker.joinable()) e.second_maker.join();
 }
@@ -236,6 +237,12 @@ int engine_setup(Engine& e, int device)
         Engine* ep = &e;
         auto make_second = [ep, device, warm] {
             Engine& e = *ep;
+            // A few milliseconds of head start for the caller: making a stream holds a lock of the runtime for 8-20 ms, and a
+            // first small call that arrives meanwhile waits for it with its launch (first call 8.7 ms instead of 1.0:
+            // profiles/r06/cold_start.log).  Whoever needs the second stream cuts the wait short (engine_second).
+            // (polled in half-millisecond naps: a timed condition-variable wait is pthread_cond_clockwait, which this image's
+            // ThreadSanitizer does not know and reports as a mutex held twice)
+            for (int nap = 0; nap < 8 && !e.second_hurry.load(std::memory_order_acquire); ++nap) usleep(500);
             hipError_t err1 = hipSetDevice(device);
             if (err1 == hipSuccess) err1 = hipStreamCreateWithFlags(&e.stream[1], hipStreamNonBlocking);
             if (err1 == hipSuccess) err1 = hipMalloc(&e.d_out[1], 4096);
